@@ -1,0 +1,236 @@
+/* ORACLE -- TEST INFRASTRUCTURE ONLY.  Nothing under opus_amd/ may include, link or call this.
+ *
+ * CPU restatement of the reference's packet framing (lu-zero/opus src/packet.rs) and per-packet driver
+ * (src/decoder.rs:48-127), plus the 8/12/16 -> 48 kHz resampler the reference lacks (the
+ * build's own design, "parity unpinned").  Framing follows RFC 6716 section 3 where packet.rs is
+ * defective (SURVEY section 8 notes: code-1 split at packet.rs:133, code-3 VBR last frame at :177-188,
+ * empty packet at :215).
+ */
+#include <math.h>
+#include <stdlib.h>
+#include "orc_rangedec.h"
+#include "orc_api.h"
+
+/* ------------------------------------------------------------------ entropy KAT shims */
+void orc_kat_reverse_bits(const uint8_t *buf, int len, const int *widths, int n, uint32_t *out)
+{   /* entropy.rs:82-133 */
+    OrcRd rd;
+    orc_rd_init(&rd, buf, len);
+    for (int i = 0; i < n; i++) out[i] = orc_rd_rawbits(&rd, widths[i]);
+}
+void orc_kat_laplace(const uint8_t *buf, int len, const int *symbol, const int *decay, int n, int *out)
+{   /* entropy.rs:135-257 */
+    OrcRd rd;
+    orc_rd_init(&rd, buf, len);
+    for (int i = 0; i < n; i++) out[i] = orc_rd_laplace(&rd, symbol[i], decay[i]);
+}
+
+/* ------------------------------------------------------------------ packet.rs */
+static int frame_len_1or2(const uint8_t *b, int avail, int *used)   /* packet.rs:77-89 */
+{
+    if (avail < 1) return -1;
+    int v = b[0];
+    if (v >= 252) {
+        if (avail < 2) return -1;
+        *used = 2;
+        return v + 4 * b[1];
+    }
+    *used = 1;
+    return v;
+}
+
+int orc_packet_parse(const uint8_t *buf, int len, OrcPacket *p)   /* packet.rs:202-317 */
+{
+    memset(p, 0, sizeof *p);
+    if (len < 1) return -1;
+    int toc = buf[0], config = toc >> 3;
+    p->code = toc & 3;
+    p->stereo = (toc >> 2) & 1;
+    if (config < 12) {
+        p->mode = 0; p->bandwidth = config >> 2;
+        static const int d[4] = {480, 960, 1920, 2880};
+        p->frame_size = d[config & 3];
+    } else if (config < 16) {
+        p->mode = 1; p->bandwidth = config < 14 ? 3 : 4;
+        p->frame_size = (config & 1) ? 960 : 480;
+    } else {
+        p->mode = 2;
+        static const int bw[4] = {0, 2, 3, 4};
+        p->bandwidth = bw[(config - 16) >> 2];
+        p->frame_size = 120 << (config & 3);
+    }
+    int pos = 1, rem = len - 1;
+    switch (p->code) {
+    case 0:
+        p->nframes = 1; p->off[0] = pos; p->len[0] = rem;
+        break;
+    case 1:
+        if (rem & 1) return -1;
+        p->nframes = 2;
+        p->off[0] = pos; p->len[0] = rem / 2;
+        p->off[1] = pos + rem / 2; p->len[1] = rem / 2;
+        break;
+    case 2: {
+        int used, l = frame_len_1or2(buf + pos, rem, &used);
+        if (l < 0 || l + used > rem) return -1;
+        p->nframes = 2;
+        p->off[0] = pos + used; p->len[0] = l;
+        p->off[1] = pos + used + l; p->len[1] = rem - used - l;
+        break;
+    }
+    default: {
+        if (rem < 1) return -1;
+        int fc = buf[pos], vbr = fc >> 7, pad = (fc >> 6) & 1, count = fc & 0x3f;
+        pos++; rem--;
+        if (count == 0 || count * p->frame_size > 5760) return -1;
+        if (pad) {                                   /* packet.rs:91-111 */
+            int padding = 0, b;
+            do {
+                if (rem < 1) return -1;
+                b = buf[pos++]; rem--;
+                padding += b == 255 ? 254 : b;
+            } while (b == 255);
+            if (padding > rem) return -1;
+            p->padding = padding;
+            rem -= padding;
+        }
+        p->nframes = count;
+        if (vbr) {
+            int total = 0;
+            for (int i = 0; i < count - 1; i++) {
+                int used, l = frame_len_1or2(buf + pos, rem, &used);
+                if (l < 0) return -1;
+                pos += used; rem -= used;
+                p->len[i] = l; total += l;
+            }
+            if (total > rem) return -1;
+            for (int i = 0; i < count - 1; i++) { p->off[i] = pos; pos += p->len[i]; }
+            p->off[count - 1] = pos; p->len[count - 1] = rem - total;
+        } else {
+            if (rem % count) return -1;
+            int l = rem / count;
+            for (int i = 0; i < count; i++) { p->off[i] = pos + i * l; p->len[i] = l; }
+        }
+    }
+    }
+    for (int i = 0; i < p->nframes; i++) if (p->len[i] > 1275) return -1;
+    return 0;
+}
+
+/* ------------------------------------------------------------------ resampler (no reference code) */
+/* Zero-stuff by L = 48/rate_khz, 73-tap Kaiser(beta 8) windowed-sinc low-pass at 0.46*fs_in, gain L.
+ * Group delay 36 samples @48 kHz for every input rate.  y[m] = sum_k h[m - kL] x[k], k ascending. */
+#define RS_HALF 36
+#define RS_TAPS (2 * RS_HALF + 1)
+static float g_rs[3][RS_TAPS];
+static int g_rs_init = 0;
+static double bessel_i0(double x) { double s = 1, t = 1; for (int k = 1; k < 40; k++) { t *= (x / (2 * k)) * (x / (2 * k)); s += t; } return s; }
+static void rs_init(void)
+{
+    static const int rates[3] = {8, 12, 16};
+    for (int r = 0; r < 3; r++) {
+        int L = 48 / rates[r];
+        double fc = 0.46 * rates[r] / 48.0;          /* cycles/sample at 48 kHz */
+        for (int n = 0; n < RS_TAPS; n++) {
+            double t = n - RS_HALF;
+            double sinc = t == 0 ? 2 * fc : sin(2 * M_PI * fc * t) / (M_PI * t);
+            double w = bessel_i0(8.0 * sqrt(1 - (t / RS_HALF) * (t / RS_HALF))) / bessel_i0(8.0);
+            g_rs[r][n] = (float)(L * sinc * w);
+        }
+    }
+    g_rs_init = 1;
+}
+const float *orc_resample_taps(int rate_khz) { if (!g_rs_init) rs_init(); return g_rs[rate_khz == 8 ? 0 : rate_khz == 12 ? 1 : 2]; }
+
+void orc_resample_to_48k(const float *in, int n_in, int rate_khz, float *hist, float *out)
+{   /* hist: last 32 input samples of the previous call (zeros at reset), updated on return */
+    const float *h = orc_resample_taps(rate_khz);
+    int L = 48 / rate_khz;
+    for (int m = 0; m < n_in * L; m++) {
+        int k_hi = m / L;                                   /* floor(m/L) */
+        int k_lo = (m - 2 * RS_HALF + L - 1 + 64 * L) / L - 64;   /* ceil((m-72)/L) */
+        float acc = 0;
+        for (int k = k_lo; k <= k_hi; k++) {
+            float x = k >= 0 ? in[k] : hist[32 + k];
+            acc += h[m - k * L] * x;
+        }
+        out[m] = acc;
+    }
+    float nh[32];
+    for (int i = 0; i < 32; i++) { int k = n_in - 32 + i; nh[i] = k >= 0 ? in[k] : hist[32 + k]; }
+    memcpy(hist, nh, sizeof nh);
+}
+
+/* ------------------------------------------------------------------ decoder.rs driver */
+struct OrcDecoder {
+    int channels, prev_mode;
+    OrcSilk *silk;
+    OrcCelt *celt;
+    float rs_hist[2][32];
+};
+
+OrcDecoder *orc_decoder_create(int channels)   /* decoder.rs:133-182 (configure) */
+{
+    OrcDecoder *d = (OrcDecoder *)calloc(1, sizeof *d);
+    d->channels = channels; d->prev_mode = -1;
+    d->silk = orc_silk_create(channels > 1);
+    d->celt = orc_celt_create(channels);
+    return d;
+}
+void orc_decoder_destroy(OrcDecoder *d) { orc_silk_destroy(d->silk); orc_celt_destroy(d->celt); free(d); }
+void orc_decoder_set_celt_trace(OrcDecoder *d, OrcCeltTrace *t) { orc_celt_set_trace(d->celt, t); }
+
+int orc_decoder_decode(OrcDecoder *d, const uint8_t *pkt, int len, float *pcm, int cap)
+{   /* decoder.rs:48-127 */
+    OrcPacket p;
+    if (orc_packet_parse(pkt, len, &p)) return -1;
+    int CC = d->channels, total = p.nframes * p.frame_size;
+    if (total > cap) return -3;
+    static const int celt_end[5] = {13, 17, 17, 19, 21};     /* packet.rs:33-42 */
+    static const int silk_rate[3] = {8, 12, 16};
+    if (p.mode != d->prev_mode && d->prev_mode >= 0) {
+        if (p.mode != 0) orc_celt_reset(d->celt);
+        if (d->prev_mode == 2) { orc_silk_flush(d->silk); memset(d->rs_hist, 0, sizeof d->rs_hist); }
+    }
+    for (int f = 0; f < p.nframes; f++) {
+        OrcRd rd;
+        int flen = p.len[f], N = p.frame_size;
+        float *dst = pcm + (size_t)f * N * CC;
+        float ch[2][2880];
+        memset(ch, 0, sizeof ch);
+        orc_rd_init(&rd, pkt + p.off[f], flen);
+        if (p.mode != 2) {
+            float sl[960], sr[960];
+            int bw = p.bandwidth < 2 ? p.bandwidth : 2;
+            int n = orc_silk_decode(d->silk, &rd, bw, N / 48, p.stereo, sl, sr);
+            if (n < 0) return n;
+            /* reference output buffers: right is always written, left only for stereo_out (:2104-2113) */
+            if (CC == 2) {
+                orc_resample_to_48k(sl, n, silk_rate[bw], d->rs_hist[0], ch[0]);
+                orc_resample_to_48k(sr, n, silk_rate[bw], d->rs_hist[1], ch[1]);
+            } else orc_resample_to_48k(sr, n, silk_rate[bw], d->rs_hist[0], ch[0]);
+        } else orc_silk_flush(d->silk);                       /* decoder.rs:79 */
+        int consumed = orc_rd_tell(&rd), redundancy = 0;     /* decoder.rs:82-115 */
+        if (p.mode == 1 && consumed + 37 <= flen * 8) redundancy = orc_rd_logp(&rd, 12);
+        else if (p.mode == 0 && consumed + 17 <= flen * 8) redundancy = 1;
+        if (redundancy) {
+            (void)orc_rd_logp(&rd, 1);                        /* celt_to_silk position flag */
+            int rbytes = p.mode == 1 ? (int)orc_rd_uniform(&rd, 256) + 2 : flen - ((orc_rd_tell(&rd) + 7) >> 3);
+            if (rbytes >= flen) return -1;
+            int nl = flen - rbytes;
+            if (nl * 8 < orc_rd_tell(&rd)) { nl = 0; }
+            rd.len = nl; rd.size_bits = nl * 8;               /* RFC 6716 4.5.1: the 5 ms redundant frame is not decoded here */
+        }
+        if (p.mode != 0 && N <= 960) {
+            float c0[960], c1[960];
+            int start = p.mode == 1 ? 17 : 0;
+            orc_celt_decode_frame(d->celt, &rd, N, start, celt_end[p.bandwidth], p.stereo + 1, c0, c1);
+            for (int i = 0; i < N; i++) { ch[0][i] += c0[i]; if (CC == 2) ch[1][i] += c1[i]; }
+        }
+        for (int i = 0; i < N; i++) for (int c = 0; c < CC; c++) dst[i * CC + c] = ch[c][i];
+    }
+    d->prev_mode = p.mode;
+    return total;
+}
+
+void orc_kat_rd_init(OrcRd *rd, const uint8_t *buf, int len) { orc_rd_init(rd, buf, len); }

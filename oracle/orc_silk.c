@@ -1,0 +1,510 @@
+/* ORACLE -- TEST INFRASTRUCTURE ONLY.  Nothing under opus_amd/ may include, link or call this.
+ *
+ * CPU restatement (plain C, f32, fixed operation order; build with -ffp-contract=off) of the reference's
+ * SILK decoder, lu-zero/opus src/silk/decoder.rs.  Pinned bit-exactly by the reference's goldens:
+ * src/silk/tests.rs:22-514 (480 samples), :516-845 (160+160), :847-870 (lsf_to_lpc).
+ * Like the reference (silk/decoder.rs:2070-2072) LBRR frames are reported as unsupported.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include "orc_rangedec.h"
+#include "orc_api.h"
+
+#define LTP_ORDER 5
+#define RES_HISTORY (288 + LTP_ORDER / 2)     /* silk/decoder.rs:691 */
+#define LPC_HISTORY 322                       /* silk/decoder.rs:692 */
+
+typedef struct {                /* silk/decoder.rs:1296-1314 */
+    int active, voiced, high;
+    int log_gain, coded, prev_voiced;
+    int16_t nlsfs[16];
+    float lpc[16], interpolated_lpc[16];
+    int interpolated, interp_factor4, previous_lag;
+    float output[2 * LPC_HISTORY], lpc_history[2 * LPC_HISTORY];
+} SilkFrame;
+
+struct OrcSilk {
+    int stereo_out;
+    float weight0, weight1, prev0, prev1;     /* silk/decoder.rs:23-26 */
+    SilkFrame mid, side;
+};
+
+static inline int32_t mul_shift(int32_t a, int32_t b, int bits) { return (int32_t)(((int64_t)a * b) >> bits); } /* :105 */
+static inline int32_t mul_round(int32_t a, int64_t b, int bits) { return (int32_t)((((int64_t)a * b) + (1ll << (bits - 1))) >> bits); } /* :112 */
+
+static int log2lin(int x)   /* silk/decoder.rs:95-101 */
+{
+    int i = 1 << (x >> 7), f = x & 127;
+    return i + ((-174 * f * (128 - f) >> 16) + f) * (i >> 7);
+}
+
+typedef struct {
+    int order, step;
+    const uint16_t *stage1;        /* [2] icdf offsets */
+    const uint16_t *map;           /* [32][order] icdf offsets */
+    const uint8_t *pred_weight;    /* [2][order-1] */
+    const uint8_t *pred_index;     /* [32][order-1] */
+    const uint16_t *weight;        /* [32][order] */
+    const uint8_t *codebook;       /* [32][order] */
+    const int16_t *min_spacing;    /* [order+1] */
+    const uint8_t *ordering;       /* [order] */
+} BandTab;
+
+static const BandTab TAB_NB_MB = {10, 11796, ICDF_SILK_LSF_STAGE1_NB_MB, &ICDF_SILK_LSF_STAGE2_NB_MB[0][0],
+    &SILK_LSF_PRED_WEIGHT_NB_MB[0][0], &SILK_LSF_PRED_WEIGHT_INDEX_NB_MB[0][0], &SILK_LSF_WEIGHT_NB_MB[0][0],
+    &SILK_LSF_CODEBOOK_NB_MB[0][0], SILK_LSF_MIN_SPACING_NB_MB, SILK_LSF_ORDERING_NB_MB};
+static const BandTab TAB_WB = {16, 9830, ICDF_SILK_LSF_STAGE1_WB, &ICDF_SILK_LSF_STAGE2_WB[0][0],
+    &SILK_LSF_PRED_WEIGHT_WB[0][0], &SILK_LSF_PRED_WEIGHT_INDEX_WB[0][0], &SILK_LSF_WEIGHT_WB[0][0],
+    &SILK_LSF_CODEBOOK_WB[0][0], SILK_LSF_MIN_SPACING_WB, SILK_LSF_ORDERING_WB};
+
+static int cmp_i16(const void *a, const void *b) { return (int)*(const int16_t *)a - (int)*(const int16_t *)b; }
+
+static void stabilize(const BandTab *t, int16_t *nlsf)   /* silk/decoder.rs:137-204 */
+{
+    int order = t->order;
+    const int16_t *ms = t->min_spacing;
+    for (int it = 0; it < 20; it++) {
+        int k = 0, min_diff = 0;
+        for (int i = 0; i <= order; i++) {
+            int low = i == 0 ? 0 : nlsf[i - 1];
+            int high = i == order ? 32768 : nlsf[i];
+            int diff = high - low - ms[i];
+            if (diff < min_diff) { min_diff = diff; k = i; }
+        }
+        if (min_diff == 0) return;
+        if (k == 0) nlsf[0] = ms[0];
+        else if (k == order) nlsf[order - 1] = (int16_t)(32768 - ms[order]);
+        else {
+            int half_delta = ms[k] >> 1, lo_sum = 0, hi_sum = 0;
+            for (int i = 0; i < k; i++) lo_sum += ms[i];
+            for (int i = k + 1; i <= order; i++) hi_sum += ms[i];
+            int min_center = lo_sum + half_delta, max_center = 32768 - hi_sum - half_delta;
+            int delta = nlsf[k - 1] + nlsf[k];
+            int center = (delta >> 1) + (delta & 1);
+            if (center < min_center) center = min_center;
+            if (center > max_center) center = max_center;
+            nlsf[k - 1] = (int16_t)(center - half_delta);
+            nlsf[k] = (int16_t)(nlsf[k - 1] + ms[k]);
+        }
+    }
+    qsort(nlsf, order, sizeof(int16_t), cmp_i16);
+    int prev = 0;
+    for (int i = 0; i < order; i++) {
+        int v = prev + ms[i];
+        if (nlsf[i] < v) nlsf[i] = (int16_t)v;
+        prev = nlsf[i];
+    }
+    int next = 32768;
+    for (int i = order - 1; i >= 0; i--) {
+        int v = next - ms[i + 1];
+        if (nlsf[i] > v) nlsf[i] = (int16_t)v;
+        next = nlsf[i];
+    }
+}
+
+static int is_stable(const int16_t *lpcs, int order)   /* silk/decoder.rs:206-260 */
+{
+    int32_t dc = 0, even[16], odd[16], invgain = 1 << 30;
+    for (int i = 0; i < order; i++) { dc += lpcs[i]; even[i] = lpcs[i] * 4096; odd[i] = 0; }
+    if (dc > 4096) return 0;
+    int k = order - 1;
+    int32_t a = even[k];
+    for (;;) {
+        if (abs(a) > 16773022) return 0;
+        int32_t rc = -a * 128;
+        int32_t div = (1 << 30) - mul_shift(rc, rc, 32);
+        invgain = mul_shift(invgain, div, 32) << 2;
+        if (k == 0) return invgain >= 107374;
+        int b1 = orc_ilog((uint32_t)div), b2 = b1 - 16;
+        int32_t inv = ((1 << 29) - 1) / (div >> (b2 + 1));
+        int32_t err = (1 << 29) - mul_shift((int32_t)((uint32_t)div << (15 - b2)), inv, 16);
+        int32_t gain = (int32_t)((uint32_t)inv << 16) + (err * inv >> 13);
+        int32_t *prev = (k & 1) ? even : odd, *cur = (k & 1) ? odd : even;
+        for (int j = 0; j < k; j++) {
+            int32_t v = prev[j] - mul_shift(prev[k - j - 1], rc, 31);
+            cur[j] = mul_shift(v, gain, b1);
+        }
+        k--;
+        a = cur[k];
+    }
+}
+
+static void range_limit(float *lpcs, int32_t *a, int order)   /* silk/decoder.rs:262-324 */
+{
+    int16_t lpc[16];
+    int deadline = 1;
+    for (int it = 0; it < 10; it++) {
+        int k = 0; int32_t maxabs = -1;
+        for (int i = 0; i < order; i++) { int32_t v = abs(a[i]); if (v > maxabs) { maxabs = v; k = i; } }
+        uint32_t m = (uint32_t)((maxabs + (1 << 4)) >> 5);
+        if (m > 32767) {
+            uint32_t mx = m < 163838 ? m : 163838;   /* RFC 6716 4.2.7.5.7 caps at 163838 (the reference uses max) */
+            uint32_t start = 65470 - ((mx - 32767) << 14) / ((mx * (uint32_t)(k + 1)) >> 2);
+            uint32_t chirp = start;
+            for (int i = 0; i < order; i++) {
+                a[i] = mul_round(a[i], chirp, 16);
+                chirp = (start * chirp + 32768) >> 16;
+            }
+        } else { deadline = 0; break; }
+    }
+    if (deadline) {
+        for (int i = 0; i < order; i++) {
+            int32_t v = (a[i] + 16) >> 5;
+            if (v > 32767) v = 32767;
+            if (v < -32768) v = -32768;
+            lpc[i] = (int16_t)v;
+            a[i] = v << 5;
+        }
+    } else {
+        for (int i = 0; i < order; i++) lpc[i] = (int16_t)((a[i] + 16) >> 5);
+    }
+    for (int i = 1; i <= 16; i++) {
+        if (is_stable(lpc, order)) break;
+        uint32_t start = 65536u - (1u << i), chirp = start;
+        for (int j = 0; j < order; j++) {
+            a[j] = mul_round(a[j], chirp, 16);
+            lpc[j] = (int16_t)((a[j] + (1 << 4)) >> 5);
+            chirp = (start * chirp + 32768) >> 16;
+        }
+    }
+    for (int i = 0; i < order; i++) lpcs[i] = (float)lpc[i] / 4096.f;
+}
+
+static void lsf_to_lpc(const BandTab *t, float *lpcs, const int16_t *nlsf)   /* silk/decoder.rs:326-397 */
+{
+    int order = t->order, half = order / 2;
+    int32_t lsps[16], p[9], q[9], a[16];
+    for (int i = 0; i < order; i++) {
+        int idx = nlsf[i] >> 8, off = nlsf[i] & 255;
+        int c = SILK_COSINE[idx], nc = SILK_COSINE[idx + 1];
+        lsps[t->ordering[i]] = (c * 256 + (nc - c) * off + 4) >> 3;
+    }
+    memset(p, 0, sizeof p); memset(q, 0, sizeof q);
+    p[0] = q[0] = 65536;
+    p[1] = -lsps[0];
+    q[1] = -lsps[1];
+    for (int i = 0; i < half - 1; i++) {
+        int32_t l0 = lsps[2 + 2 * i], l1 = lsps[3 + 2 * i];
+        p[i + 2] = p[i] * 2 - mul_round(l0, p[i + 1], 16);
+        q[i + 2] = q[i] * 2 - mul_round(l1, q[i + 1], 16);
+        for (int j = i + 1; j >= 2; j--) {
+            p[j] += p[j - 2] - mul_round(l0, p[j - 1], 16);
+            q[j] += q[j - 2] - mul_round(l1, q[j - 1], 16);
+        }
+        p[1] -= l0;
+        q[1] -= l1;
+    }
+    for (int i = 0; i < half; i++) {
+        int32_t ps = p[i] + p[i + 1], qs = q[i + 1] - q[i];
+        a[i] = -ps - qs;
+        a[order - 1 - i] = -ps + qs;
+    }
+    range_limit(lpcs, a, order);
+}
+
+void orc_lsf_to_lpc(const int16_t *nlsf, int order, float *lpc) { lsf_to_lpc(order == 16 ? &TAB_WB : &TAB_NB_MB, lpc, nlsf); }
+
+static float parse_subframe_gain(SilkFrame *f, OrcRd *rd, int coded)   /* silk/decoder.rs:1326-1344 */
+{
+    if (coded) {
+        int idx = f->voiced + f->active;
+        int msb = orc_rd_icdf(rd, ICDF_SILK_MSB_SUBFRAME_GAIN[idx]);
+        int lsb = orc_rd_icdf(rd, ICDF_SILK_LSB_SUBFRAME_GAIN);
+        int v = (msb << 3) | lsb;
+        f->log_gain = v > f->log_gain - 16 ? v : f->log_gain - 16;
+    } else {
+        int delta = orc_rd_icdf(rd, ICDF_SILK_DELTA_SUBFRAME_GAIN);
+        int v = delta * 2 - 16;
+        if (f->log_gain + delta - 4 > v) v = f->log_gain + delta - 4;
+        if (v < 0) v = 0;
+        if (v > 63) v = 63;
+        f->log_gain = v;
+    }
+    int lg = (f->log_gain * 0x1D1C71 >> 16) + 2090;
+    return (float)log2lin(lg) / 65536.0f;
+}
+
+static void parse_lpc(SilkFrame *f, OrcRd *rd, const BandTab *t, int interpolate)   /* silk/decoder.rs:1347-1463 */
+{
+    int order = t->order;
+    int s1 = orc_rd_icdf(rd, t->stage1[f->voiced]);
+    int s2[16];
+    for (int i = 0; i < order; i++) {
+        int v = orc_rd_icdf(rd, t->map[s1 * order + i]) - 4;
+        if (v == -4) v -= orc_rd_icdf(rd, ICDF_SILK_LSF_STAGE2_EXTENSION);
+        else if (v == 4) v += orc_rd_icdf(rd, ICDF_SILK_LSF_STAGE2_EXTENSION);
+        s2[i] = v;
+    }
+    int16_t res[16], nlsf[16];
+    int have_prev = 0; int16_t prev = 0;
+    for (int i = order - 1; i >= 0; i--) {
+        int fix = s2[i] < 0 ? 102 : s2[i] > 0 ? -102 : 0;
+        int16_t ds = (int16_t)(((s2[i] * 1024 + fix) * t->step) >> 16);
+        int16_t r = ds;
+        if (have_prev) {
+            int w = t->pred_weight[t->pred_index[s1 * (order - 1) + i] * (order - 1) + i];
+            r = (int16_t)(ds + (int16_t)(((int)prev * w) >> 8));
+        }
+        prev = r; have_prev = 1;
+        res[i] = r;
+    }
+    for (int i = 0; i < order; i++) {
+        int v = ((int)t->codebook[s1 * order + i] << 7) + ((int)res[i] << 14) / (int)t->weight[s1 * order + i];
+        if (v < 0) v = 0;
+        if (v > 32767) v = 32767;
+        nlsf[i] = (int16_t)v;
+    }
+    stabilize(t, nlsf);
+    f->interpolated = 0;
+    if (interpolate) {
+        int w = orc_rd_icdf(rd, ICDF_SILK_LSF_INTERPOLATION_INDEX);
+        if (w != 4 && f->coded) {
+            f->interpolated = 1;
+            if (w != 0) {
+                int16_t in[16];
+                for (int i = 0; i < order; i++) in[i] = (int16_t)(f->nlsfs[i] + (((int16_t)(nlsf[i] - f->nlsfs[i]) * w) >> 2));
+                lsf_to_lpc(t, f->interpolated_lpc, in);
+            } else memcpy(f->interpolated_lpc, f->lpc, order * sizeof(float));
+            f->interp_factor4 = 0;
+        } else f->interp_factor4 = 1;
+    } else f->interp_factor4 = 1;
+    memcpy(f->nlsfs, nlsf, order * sizeof(int16_t));
+    lsf_to_lpc(t, f->lpc, nlsf);
+}
+
+typedef struct { float gain; int pitch_lag; float ltp_taps[5]; } SubFrame;
+
+static void parse_pitch_lags(SilkFrame *f, OrcRd *rd, SubFrame *sf, int nsf, int bw, int absolute)   /* :1465-1507 */
+{
+    static const int MIN_LAG[3] = {16, 24, 32}, MAX_LAG[3] = {144, 216, 288}, SCALE[3] = {4, 6, 8};
+    int lag = 0, have = 0;
+    if (!absolute) {
+        int delta = orc_rd_icdf(rd, ICDF_SILK_PITCH_DELTA);
+        if (delta != 0) { lag = f->previous_lag + delta - 9; have = 1; }
+    }
+    if (!have) {
+        int high = orc_rd_icdf(rd, ICDF_SILK_PITCH_HIGH_PART);
+        int low = orc_rd_icdf(rd, ICDF_SILK_PITCH_LOW_PART[bw]);
+        lag = high * SCALE[bw] + low + MIN_LAG[bw];
+    }
+    f->previous_lag = lag;
+    const int8_t *offs;
+    if (nsf == 2) {
+        int idx = orc_rd_icdf(rd, bw == 0 ? ICDF_SILK_PITCH_CONTOUR_NB[0] : ICDF_SILK_PITCH_CONTOUR_MB_WB[0]);
+        offs = bw == 0 ? SILK_PITCH_OFFSET_NB_10MS[idx] : SILK_PITCH_OFFSET_MB_WB_10MS[idx];
+    } else {
+        int idx = orc_rd_icdf(rd, bw == 0 ? ICDF_SILK_PITCH_CONTOUR_NB[1] : ICDF_SILK_PITCH_CONTOUR_MB_WB[1]);
+        offs = bw == 0 ? SILK_PITCH_OFFSET_NB_20MS[idx] : SILK_PITCH_OFFSET_MB_WB_20MS[idx];
+    }
+    for (int i = 0; i < nsf; i++) {
+        int v = lag + offs[i];
+        if (v > MAX_LAG[bw]) v = MAX_LAG[bw];
+        if (v < MIN_LAG[bw]) v = MIN_LAG[bw];
+        sf[i].pitch_lag = v;
+    }
+}
+
+static void split_loc(OrcRd *rd, int level, int avail, int *out)   /* silk/decoder.rs:1564-1578 */
+{
+    if (avail == 0) { out[0] = out[1] = 0; return; }
+    out[0] = orc_rd_icdf(rd, ICDF_SILK_PULSE_LOCATION[level][avail - 1]);
+    out[1] = avail - out[0];
+}
+
+static void parse_excitation(SilkFrame *f, OrcRd *rd, float *residuals, int bw, int long_frame)   /* :1522-1640 */
+{
+    static const int SHELL[3][2] = {{5, 10}, {8, 15}, {10, 20}};
+    int shell_blocks = SHELL[bw][long_frame];
+    int pulsecount[20], lsbcount[20], exc[320];
+    uint32_t seed = orc_rd_icdf(rd, ICDF_SILK_LCG_SEED);
+    int ratelevel = orc_rd_icdf(rd, ICDF_SILK_EXC_RATE[f->voiced]);
+    for (int i = 0; i < shell_blocks; i++) {
+        int p = orc_rd_icdf(rd, ICDF_SILK_PULSE_COUNT[ratelevel]), l = 0;
+        if (p == 17) {
+            while (p == 17 && ++l != 10) p = orc_rd_icdf(rd, ICDF_SILK_PULSE_COUNT[9]);
+            if (l == 10) p = orc_rd_icdf(rd, ICDF_SILK_PULSE_COUNT[10]);
+        }
+        pulsecount[i] = p; lsbcount[i] = l;
+    }
+    for (int i = 0; i < shell_blocks; i++) {
+        int *loc = exc + 16 * i;
+        if (pulsecount[i] == 0) { memset(loc, 0, 16 * sizeof(int)); continue; }
+        int d0[2], d1[2], d2[2], d3[2];
+        split_loc(rd, 0, pulsecount[i], d0);
+        for (int a = 0; a < 2; a++) {
+            split_loc(rd, 1, d0[a], d1);
+            for (int b = 0; b < 2; b++) {
+                split_loc(rd, 2, d1[b], d2);
+                for (int c = 0; c < 2; c++) {
+                    split_loc(rd, 3, d2[c], d3);
+                    loc[8 * a + 4 * b + 2 * c] = d3[0];
+                    loc[8 * a + 4 * b + 2 * c + 1] = d3[1];
+                }
+            }
+        }
+    }
+    for (int i = 0; i < shell_blocks; i++)
+        for (int j = 0; j < 16; j++)
+            for (int b = 0; b < lsbcount[i]; b++) exc[16 * i + j] = (exc[16 * i + j] << 1) | orc_rd_icdf(rd, ICDF_SILK_EXC_LSB);
+    int sig = f->voiced + f->active, qo = f->high;
+    for (int i = 0; i < shell_blocks; i++)
+        for (int j = 0; j < 16; j++)
+            if (exc[16 * i + j] != 0) {
+                int pulse = pulsecount[i] < 6 ? pulsecount[i] : 6;
+                if (orc_rd_icdf(rd, ICDF_SILK_EXC_SIGN[sig][qo][pulse]) == 0) exc[16 * i + j] = -exc[16 * i + j];
+            }
+    for (int i = 0; i < shell_blocks * 16; i++) {
+        int l = exc[i];
+        int ex1 = l * 256 | SILK_QUANT_OFFSET[f->voiced][qo];
+        int ex = ex1 - 20 * ((l > 0) - (l < 0));
+        seed = seed * 196314165u + 907633515u;
+        if (seed & 0x80000000u) ex = -ex;
+        seed += (uint32_t)l;
+        residuals[i] = (float)ex / 8388608.0f;
+    }
+}
+
+static void frame_flush(SilkFrame *f) { if (f->coded) memset(f, 0, sizeof *f); }   /* silk/decoder.rs:1642-1662 */
+
+static inline float clampf(float v, float lo, float hi) { v = v > lo ? v : lo; return v < hi ? v : hi; }
+
+static void frame_parse(SilkFrame *f, OrcRd *rd, int bw, int subframes, int sf_size, int vad, int first)
+{   /* silk/decoder.rs:1664-1903 */
+    int f_size = sf_size * subframes;
+    if (vad) { int t = orc_rd_icdf(rd, ICDF_SILK_FRAME_TYPE_ACTIVE); f->active = 1; f->voiced = t >> 1; f->high = t & 1; }
+    else { f->active = 0; f->voiced = 0; f->high = orc_rd_icdf(rd, ICDF_SILK_FRAME_TYPE_INACTIVE) != 0; }
+    SubFrame sfs[4];
+    float residuals[LPC_HISTORY + RES_HISTORY];
+    memset(sfs, 0, sizeof sfs);
+    memset(residuals, 0, sizeof residuals);
+    for (int i = 0; i < subframes; i++) sfs[i].gain = parse_subframe_gain(f, rd, i == 0 && (first || !f->coded));
+    int long_frame = subframes == 4;
+    const BandTab *t = bw == 2 ? &TAB_WB : &TAB_NB_MB;
+    int order = t->order;
+    parse_lpc(f, rd, t, long_frame);
+    if (f->voiced) {
+        parse_pitch_lags(f, rd, sfs, subframes, bw, first || !f->prev_voiced);
+        int per = orc_rd_icdf(rd, ICDF_SILK_LTP_PERIODICITY);   /* silk/decoder.rs:1509-1520 */
+        for (int i = 0; i < subframes; i++) {
+            int idx = orc_rd_icdf(rd, ICDF_SILK_LTP_FILTER[per]);
+            const int8_t *taps = SILK_LTP_TAPS + SILK_LTP_TAPS_ROW[per] + 5 * idx;
+            for (int k = 0; k < 5; k++) sfs[i].ltp_taps[k] = (float)taps[k] / 128.f;
+        }
+    }
+    float ltpscale = (f->voiced && first ? (float)SILK_LTP_SCALE[orc_rd_icdf(rd, ICDF_SILK_LTP_SCALE_INDEX)] : 15565.f) / 16384.f;
+    parse_excitation(f, rd, residuals + RES_HISTORY, bw, long_frame);
+
+    for (int i = 0; i < subframes; i++) {
+        const SubFrame *sf = &sfs[i];
+        const float *lpc_coeff = (i < 2 && f->interpolated) ? f->interpolated_lpc : f->lpc;
+        if (f->voiced) {
+            int before = sf->pitch_lag + LTP_ORDER / 2, end; float scale;
+            if (i < 2 || f->interp_factor4) { end = i * sf_size; scale = ltpscale; }
+            else { end = (i - 2) * sf_size; scale = 1.f; }
+            if (before > end) {                    /* re-whiten, :1794-1828 */
+                int start = LPC_HISTORY + i * sf_size - before, stop = LPC_HISTORY + i * sf_size - end;
+                int start_res = RES_HISTORY + i * sf_size - before;
+                for (int n = 0; n < stop - start; n++) {
+                    float sum = f->output[start + n];
+                    for (int k = 0; k < order; k++) sum -= lpc_coeff[k] * f->output[start + n - 1 - k];
+                    residuals[start_res + n] = clampf(sum, -1.f, 1.f) * scale / sf->gain;
+                }
+            }
+            if (end != 0) {                        /* :1830-1841 */
+                float rescale = sfs[i - 1].gain / sfs[i].gain;
+                for (int n = RES_HISTORY + i * sf_size - end; n < RES_HISTORY + i * sf_size; n++) residuals[n] *= rescale;
+            }
+            for (int n = RES_HISTORY + i * sf_size; n < RES_HISTORY + (i + 1) * sf_size; n++) {   /* LTP :1843-1860 */
+                float sum = residuals[n];
+                for (int o = 0; o < LTP_ORDER; o++) sum += sf->ltp_taps[o] * residuals[n - sf->pitch_lag + LTP_ORDER / 2 - o];
+                residuals[n] = sum;
+            }
+        }
+        const float *res = residuals + RES_HISTORY + i * sf_size;      /* LPC :1864-1884 */
+        float *out = f->output + LPC_HISTORY + i * sf_size;
+        float *lpc = f->lpc_history + LPC_HISTORY + i * sf_size - order;
+        for (int j = 0; j < sf_size; j++) {
+            float sum = res[j] * sf->gain;
+            for (int k = 0; k < order; k++) sum += lpc_coeff[k] * lpc[j + order - k - 1];
+            lpc[j + order] = sum;
+            out[j] = clampf(sum, -1.f, 1.f);
+        }
+    }
+    f->prev_voiced = f->voiced;
+    for (int i = 0; i < LPC_HISTORY; i++) {
+        f->lpc_history[i] = f->lpc_history[i + f_size];
+        f->output[i] = f->output[i + f_size];
+    }
+    f->coded = 1;
+}
+
+OrcSilk *orc_silk_create(int stereo_out) { OrcSilk *s = (OrcSilk *)calloc(1, sizeof *s); s->stereo_out = stereo_out; return s; }
+void orc_silk_destroy(OrcSilk *s) { free(s); }
+void orc_silk_flush(OrcSilk *s)   /* silk/decoder.rs:1934-1940 */
+{
+    frame_flush(&s->mid); frame_flush(&s->side);
+    s->prev0 = s->prev1 = 0;
+}
+
+static int parse_stereo_weight(OrcSilk *s, OrcRd *rd, int vad)   /* silk/decoder.rs:1979-2010 */
+{
+    static const int WQ13[16] = {-13732, -10050, -8266, -7526, -6500, -5000, -2950, -820, 820, 2950, 5000, 6500, 7526, 8266, 10050, 13732};
+    int n = orc_rd_icdf(rd, ICDF_SILK_STEREO_STAGE1);
+    int i0 = orc_rd_icdf(rd, ICDF_SILK_STEREO_STAGE2) + 3 * (n / 5);
+    int i1 = orc_rd_icdf(rd, ICDF_SILK_STEREO_STAGE3) * 2 + 1;
+    int i2 = orc_rd_icdf(rd, ICDF_SILK_STEREO_STAGE2) + 3 * (n % 5);
+    int i3 = orc_rd_icdf(rd, ICDF_SILK_STEREO_STAGE3) * 2 + 1;
+    int w0 = WQ13[i0] + (((WQ13[i0 + 1] - WQ13[i0]) * 6554) >> 16) * i1;
+    int w1 = WQ13[i2] + (((WQ13[i2 + 1] - WQ13[i2]) * 6554) >> 16) * i3;
+    s->weight0 = (float)(w0 - w1) / 8192.f;
+    s->weight1 = (float)w1 / 8192.f;
+    return vad ? 0 : orc_rd_icdf(rd, ICDF_SILK_MID_ONLY) != 0;
+}
+
+static void unmix_ms(OrcSilk *s, int bw, int f_size, float *left, float *right)   /* silk/decoder.rs:2012-2061 */
+{
+    int in_start = LPC_HISTORY - f_size;
+    float w0 = s->weight0, w1 = s->weight1, w0p = s->prev0, w1p = s->prev1;
+    int n1 = bw == 0 ? 64 : bw == 1 ? 96 : 128;
+    float w0d = (w0 - w0p) / (float)n1, w1d = (w1 - w1p) / (float)n1;
+    const float *mid = s->mid.output + in_start - 2, *side = s->side.output + in_start - 1;
+    for (int i = 0; i < f_size; i++) {
+        float i0 = w0, i1 = w1;
+        if (i < n1) { i0 = w0p + (float)i * w0d; i1 = w1p + (float)i * w1d; }
+        float p0 = 0.25f * (mid[i] + 2.0f * mid[i + 1] + mid[i + 2]);
+        float si0 = side[i] + i0 * p0;
+        right[i] = clampf((1.0f + i1) * mid[i + 1] + si0, -1.f, 1.f);
+        left[i] = clampf((1.0f - i1) * mid[i + 1] - si0, -1.f, 1.f);
+    }
+    s->prev0 = s->weight0;
+    s->prev1 = s->weight1;
+}
+
+int orc_silk_decode(OrcSilk *s, OrcRd *rd, int bw, int duration_ms, int stereo, float *left, float *right)
+{   /* silk/decoder.rs:1942-1977 (setup) + :2063-2127 (decode) */
+    int frames = duration_ms <= 20 ? 1 : duration_ms / 20;
+    int subframes = duration_ms == 10 ? 2 : 4;
+    int sf_size = bw == 0 ? 40 : bw == 1 ? 60 : 80, f_size = sf_size * subframes;
+    int mid_vad[3] = {0, 0, 0}, side_vad[3] = {0, 0, 0};
+    for (int i = 0; i < frames; i++) mid_vad[i] = orc_rd_logp(rd, 1);
+    if (orc_rd_logp(rd, 1)) return -2;                       /* LBRR unsupported, :2070-2072 */
+    if (stereo) {
+        for (int i = 0; i < frames; i++) side_vad[i] = orc_rd_logp(rd, 1);
+        if (orc_rd_logp(rd, 1)) return -2;
+    }
+    for (int i = 0; i < frames; i++) {
+        int first = i == 0;
+        int midonly = stereo ? parse_stereo_weight(s, rd, side_vad[i]) : 0;
+        frame_parse(&s->mid, rd, bw, subframes, sf_size, mid_vad[i], first);
+        if (stereo && !midonly) frame_parse(&s->side, rd, bw, subframes, sf_size, side_vad[i], first);
+        if (midonly) frame_flush(&s->side);
+        float *l = left + i * f_size, *r = right + i * f_size;
+        if (stereo && s->stereo_out) unmix_ms(s, bw, f_size, l, r);
+        else {
+            const float *in = s->mid.output + LPC_HISTORY - f_size - 2;
+            if (s->stereo_out) memcpy(l, in, f_size * sizeof(float));
+            memcpy(r, in, f_size * sizeof(float));
+        }
+    }
+    return frames * f_size;
+}

@@ -1,0 +1,129 @@
+"""The oracle against every known-answer vector the reference's own unit tests hold."""
+import ctypes as C
+
+import numpy as np
+
+import orc
+
+L = orc.lib()
+K = orc.kats()
+
+
+def test_reverse_bitread():  # entropy.rs:82-133
+    k = K["reverse_bitread"]
+    buf = bytes(k["buf"])
+    w = (C.c_int * len(k["reads"]))(*[r[0] for r in k["reads"]])
+    out = (C.c_uint32 * len(k["reads"]))()
+    L.orc_kat_reverse_bits(buf, len(buf), w, len(k["reads"]), out)
+    assert list(out) == [r[1] for r in k["reads"]]
+
+
+def test_decode_laplace():  # entropy.rs:135-257
+    k = K["decode_laplace"]
+    buf = bytes(k["buf"])
+    n = len(k["triples"])
+    sym = (C.c_int * n)(*[t[1] for t in k["triples"]])
+    dec = (C.c_int * n)(*[t[2] for t in k["triples"]])
+    out = (C.c_int * n)()
+    L.orc_kat_laplace(buf, len(buf), sym, dec, n, out)
+    assert list(out) == [t[0] for t in k["triples"]]
+
+
+def test_cwrsi():  # celt/decoder.rs:2414-2434
+    for k in K["cwrsi"]:
+        y = (C.c_int * k["n"])()
+        assert L.orc_cwrsi(k["n"], k["k"], k["i"], y) == k["norm"]
+        assert list(y) == k["y"]
+
+
+def test_cwrsi_exhaustive_small():
+    """every index of small (N,K) codebooks decodes to a distinct vector with sum|y| = K"""
+    for n in range(2, 7):
+        for k in range(1, 6):
+            v = L.orc_pvq_v(n, k)
+            seen = set()
+            y = (C.c_int * n)()
+            for i in range(v):
+                norm = L.orc_cwrsi(n, k, i, y)
+                t = tuple(y)
+                assert sum(abs(a) for a in t) == k and norm == sum(a * a for a in t)
+                seen.add(t)
+            assert len(seen) == v
+
+
+def test_extract_collapse_mask():  # celt/decoder.rs:2398-2411
+    for k in K["extract_collapse_mask"]:
+        y = (C.c_int * len(k["y"]))(*k["y"])
+        assert L.orc_extract_collapse_mask(y, len(k["y"]), k["b"]) == k["mask"]
+
+
+def test_stereo_merge():  # celt/decoder.rs:2330-2396
+    k = K["stereo_merge"]
+    x = np.array(k["x"], np.float32)
+    y = np.array(k["y"], np.float32)
+    L.orc_stereo_merge(x.ctypes.data, y.ctypes.data, C.c_float(k["mid"]), k["n"])
+    assert np.array_equal(x, np.array(k["ox"], np.float32))
+    assert np.array_equal(y, np.array(k["oy"], np.float32))
+
+
+def _haar_naive(a, n0, stride):  # celt/decoder.rs:2436-2449 (the reference test's own naive form)
+    a = a.copy()
+    r = np.float32(0.70710678118654752440)
+    for i in range(stride):
+        for j in range(n0 // 2):
+            x0, x1 = a[stride * 2 * j + i], a[stride * (2 * j + 1) + i]
+            a[stride * 2 * j + i] = np.float32(x0 + x1) * r
+            a[stride * (2 * j + 1) + i] = np.float32(x0 - x1) * r
+    return a
+
+
+def test_haar1():  # celt/decoder.rs:2451-2481
+    for name in ("haar1_32_1", "haar1_16_2"):
+        k = K[name]
+        a = np.array(k["a"], np.float32)
+        b = _haar_naive(a, k["n0"], k["stride"])
+        L.orc_haar1(a.ctypes.data_as(C.c_void_p), k["n0"], k["stride"])
+        assert np.array_equal(a, b)
+
+
+def test_lsf_to_lpc():  # silk/tests.rs:847-870
+    k = K["lsf_to_lpc"]
+    nlsf = (C.c_int16 * 10)(*k["nlsf"])
+    lpc = np.zeros(10, np.float32)
+    L.orc_lsf_to_lpc(nlsf, 10, lpc.ctypes.data_as(C.c_void_p))
+    assert np.array_equal(lpc, np.array(k["lpc"], np.float32))
+
+
+def _silk_packet(pkt, stereo_out=True):
+    """silk/tests.rs:5-20: Packet::from_slice + Silk::setup + decode per frame"""
+    p = orc.Packet()
+    raw = bytes(pkt)
+    assert L.orc_packet_parse(raw, len(raw), C.byref(p)) == 0
+    assert p.mode == 0
+    s = L.orc_silk_create(int(stereo_out))
+    left = np.zeros(960, np.float32)
+    right = np.zeros(960, np.float32)
+    n = 0
+    rd = C.create_string_buffer(256)
+    for f in range(p.nframes):
+        frame = raw[p.off[f]:p.off[f] + p.len[f]]
+        L.orc_kat_rd_init(rd, frame, len(frame))
+        n = L.orc_silk_decode(C.c_void_p(s), rd, p.bandwidth, p.frame_size // 48, p.stereo,
+                              left.ctypes.data_as(C.c_void_p), right.ctypes.data_as(C.c_void_p))
+        assert n > 0
+    L.orc_silk_destroy(s)
+    return left[:n], right[:n]
+
+
+def test_silk_midonly_to_stereo():  # silk/tests.rs:22-514, exact f32
+    k = K["silk_midonly_to_stereo"]
+    l, r = _silk_packet(k["packet"])
+    assert np.array_equal(r, np.array(k["right"], np.float32))
+    assert np.array_equal(l, np.array(k["left"], np.float32))
+
+
+def test_silk_unmix():  # silk/tests.rs:516-845, exact f32
+    k = K["silk_unmix"]
+    l, r = _silk_packet(k["packet"])
+    assert np.array_equal(r, np.array(k["right"], np.float32))
+    assert np.array_equal(l, np.array(k["left"], np.float32))
