@@ -1,0 +1,171 @@
+/* opusgpu.h -- C ABI of the opus_amd batched Opus decode engine (MI355X / gfx950).
+ *
+ * This is the drop-in boundary for the decode path of lu-zero/opus.  The reference exposes one object,
+ * `OPUS_DESCR: &dyn Descriptor` (src/decoder.rs:190-197), whose `create()` returns a rust-av
+ * `Decoder` with five methods (src/decoder.rs:42-188).  A Rust `impl Decoder` would bind the functions
+ * below one to one (INTEGRATION.md shows the stub); every function cites the method it replaces.
+ *
+ * Three layers, all plain C (pointers + sizes, no C++/torch types):
+ *   1. opusgpu_decoder_*  one stream, same call order as the reference:
+ *                         set_extradata -> configure -> (send_packet -> receive_frame)* -> flush
+ *   2. opusgpu_batch_*    thousands of independent streams per call (what north_star adds)
+ *   3. opusgpu_parse_* / opusgpu_launch_*   the thin inner FFI: host side-info emission and the raw
+ *                         kernel launches on caller-owned device memory (no allocation inside)
+ *
+ * Errors mirror av_codec::error::Error as used by the reference (packet.rs:84,130,145,163,192;
+ * decoder.rs:104,160,167; silk/decoder.rs:2071).  Nothing here aborts or panics.
+ */
+#ifndef OPUSGPU_H
+#define OPUSGPU_H
+#include <stddef.h>
+#include <stdint.h>
+#include "opusgpu_sideinfo.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    OPUSGPU_OK = 0,
+    OPUSGPU_INVALID_DATA = -1,          /* Error::InvalidData */
+    OPUSGPU_CONFIG_INVALID = -2,        /* Error::ConfigurationInvalid (decoder.rs:160) */
+    OPUSGPU_CONFIG_INCOMPLETE = -3,     /* Error::ConfigurationIncomplete (decoder.rs:167) */
+    OPUSGPU_UNSUPPORTED = -4,           /* Error::Unsupported (silk/decoder.rs:2071: LBRR; >2 channels decoder.rs:171) */
+    OPUSGPU_MORE_DATA_NEEDED = -5,      /* Error::MoreDataNeeded (decoder.rs:129) */
+    OPUSGPU_DEVICE = -6,                /* HIP runtime error / no GPU; opusgpu_last_error() has the text */
+    OPUSGPU_BAD_ARG = -7
+};
+
+#define OPUSGPU_MAX_FRAME 5760          /* 120 ms @ 48 kHz: the longest packet (RFC 6716 3.2.5) */
+
+const char *opusgpu_version(void);
+const char *opusgpu_last_error(void);   /* thread-local text of the last OPUSGPU_DEVICE failure */
+const char *opusgpu_strerror(int code);
+
+/* ------------------------------------------------------------------------------------------------
+ * Layer 1: one stream.  Replaces `struct Dec` + `impl Decoder for Dec` (src/decoder.rs:16-188).
+ * Not thread-safe per handle, exactly as the reference's `&mut self` methods. */
+typedef struct opusgpu_decoder opusgpu_decoder;
+
+/* Descriptor::create (decoder.rs:33-35).  device = HIP device ordinal. */
+int opusgpu_decoder_create(opusgpu_decoder **out, int device);
+void opusgpu_decoder_destroy(opusgpu_decoder *);
+/* Decoder::set_extradata (decoder.rs:45-47): the OpusHead blob, copied. */
+int opusgpu_decoder_set_extradata(opusgpu_decoder *, const uint8_t *extra, size_t len);
+/* Decoder::configure (decoder.rs:133-182): channels from byte 9; > 2 channels -> OPUSGPU_UNSUPPORTED
+ * (the reference hits unimplemented!(), decoder.rs:170-171); no extradata -> 2 channels. */
+int opusgpu_decoder_configure(opusgpu_decoder *);
+/* Decoder::send_packet (decoder.rs:48-127): parse, decode on the GPU, queue the PCM. */
+int opusgpu_decoder_send_packet(opusgpu_decoder *, const uint8_t *pkt, size_t len);
+/* Decoder::receive_frame (decoder.rs:128-132, unimplemented!() in the reference): pops the oldest
+ * decoded packet as interleaved f32 @ 48 kHz.  OPUSGPU_MORE_DATA_NEEDED when the queue is empty. */
+int opusgpu_decoder_receive_frame(opusgpu_decoder *, float *pcm, size_t cap_floats, size_t *nsamples, int *channels);
+/* Decoder::flush (decoder.rs:184-187, unimplemented!() in the reference): drop queued output and
+ * reset all decoder state (Silk::flush silk/decoder.rs:1934-1940 + CELT reset). */
+int opusgpu_decoder_flush(opusgpu_decoder *);
+
+/* ------------------------------------------------------------------------------------------------
+ * Layer 2: a batch of independent streams on one GPU (one handle per GPU; streams shard across GPUs
+ * with no collective).  Each stream is a `Dec` of the reference. */
+typedef struct opusgpu_batch opusgpu_batch;
+
+int opusgpu_batch_create(opusgpu_batch **out, uint32_t nstreams, int channels, int device);
+void opusgpu_batch_destroy(opusgpu_batch *);
+/* Host half of send_packet for n (stream, packet) pairs: framing + range decoding + side-info
+ * emission (packet.rs, entropy.rs, the integer control of celt/decoder.rs and silk/decoder.rs).
+ * A stream may appear at most once per call.  errors[i] (optional) receives the per-packet code: a
+ * bad packet never poisons the batch.  Returns OPUSGPU_OK or a global failure. */
+int opusgpu_batch_send(opusgpu_batch *, const uint8_t *const *pkts, const uint32_t *lens,
+                       const uint32_t *stream_ids, uint32_t n, int32_t *errors);
+/* Device half: H2D of the side-info, then the kernels, on the batch's HIP stream.  Asynchronous. */
+int opusgpu_batch_decode(opusgpu_batch *);
+int opusgpu_batch_sync(opusgpu_batch *);
+/* Device-resident result of the last decode: interleaved f32, row s = stream s,
+ * row stride *stride_floats, nsamples[s] valid samples per channel (host array owned by the batch,
+ * valid until the next batch_send). */
+int opusgpu_batch_pcm(opusgpu_batch *, const float **d_pcm, size_t *stride_floats, const uint32_t **nsamples);
+/* Copy stream s's result to the host (synchronises). */
+int opusgpu_batch_read(opusgpu_batch *, uint32_t stream, float *pcm, size_t cap_floats, size_t *nsamples);
+int opusgpu_batch_flush(opusgpu_batch *, uint32_t stream);
+/* Side-info the last batch_send produced (host memory owned by the batch; parity tests read it). */
+int opusgpu_batch_sideinfo(opusgpu_batch *, const OgCeltHdr **celt, uint32_t *ncelt, const OgCeltLeaf **leaves,
+                           uint32_t *nleaves, const OgSilkFrame **silk, uint32_t *nsilk);
+
+/* ------------------------------------------------------------------------------------------------
+ * Layer 3a: host parser for one stream, no GPU involved.  What the reference's Rust host would keep
+ * (north_star): Packet::from_slice (packet.rs:202-317), RangeDecoder (entropy.rs:264-543),
+ * Celt::decode's parse half (celt/decoder.rs:2222-2323), Silk::decode's parse half
+ * (silk/decoder.rs:2063-2127) and the send_packet driver (decoder.rs:48-127). */
+typedef struct opusgpu_parser opusgpu_parser;
+
+typedef struct {               /* one Opus frame of a packet */
+    uint8_t mode;              /* 0 SILK, 1 hybrid, 2 CELT (packet.rs:13-18) */
+    uint8_t bandwidth;         /* 0 NB .. 4 FB (packet.rs:23-30) */
+    uint8_t stereo;            /* packet stereo flag */
+    uint8_t nsilk;             /* SILK frames emitted for this Opus frame (0-3) */
+    uint16_t frame_size;       /* samples per channel @ 48 kHz */
+    uint16_t has_celt;
+    uint32_t celt_index;       /* index into the celt[] output */
+    uint32_t silk_index;       /* index of the first SILK frame in silk[] */
+    uint32_t final_range;      /* range decoder state after the frame (celt/decoder.rs:2322) */
+} OgFrameInfo;
+
+int opusgpu_parser_create(opusgpu_parser **out, int channels);
+void opusgpu_parser_destroy(opusgpu_parser *);
+void opusgpu_parser_reset(opusgpu_parser *);
+/* Parses one packet.  Appends to the caller's arrays (capacities in, counts in/out through the
+ * n* pointers).  Returns the number of Opus frames (1-48) or a negative error. */
+int opusgpu_parser_parse(opusgpu_parser *, const uint8_t *pkt, size_t len, OgFrameInfo *frames /* [48] */,
+                         OgCeltHdr *celt, uint32_t celt_cap, uint32_t *ncelt,
+                         OgCeltLeaf *leaves, uint32_t leaf_cap, uint32_t *nleaves,
+                         OgSilkFrame *silk, uint32_t silk_cap, uint32_t *nsilk);
+/* Packet::from_slice alone (packet.rs:202-317). */
+typedef struct {
+    int32_t mode, bandwidth, frame_size, stereo, code, nframes, padding;
+    int32_t off[48], len[48];
+} OgPacket;
+int opusgpu_packet_parse(const uint8_t *pkt, size_t len, OgPacket *out);
+
+/* ------------------------------------------------------------------------------------------------
+ * Layer 3b: raw kernel launches on caller-owned device memory.  `stream` is a hipStream_t passed as
+ * void* (NULL = default stream).  No allocation, no synchronisation.  All pointers are device
+ * pointers unless noted. */
+
+typedef struct {               /* per-stream CELT synthesis state in HBM (celt/decoder.rs:34-43 `buf`,
+                                  `deemph_coeff`; the reference never fills them) */
+    float hist[2][1024];       /* ring of post-filtered, pre-de-emphasis output; index = sample & 1023 */
+    float overlap[2][60];      /* IMDCT tail awaiting the next frame's TDAC mirror */
+    float deemph[2];
+    uint32_t pos;              /* absolute sample position of the next frame (ring phase) */
+    uint32_t pad_;
+} OgCeltState;
+
+typedef struct {               /* optional stage dumps for parity tests; any pointer may be NULL */
+    int16_t *pulses;           /* [nframes][2][960]  PVQ pulse vectors at their coefficient positions */
+    float *norm;               /* [nframes][2][960]  normalised coefficients after band decoding */
+    float *freq;               /* [nframes][2][960]  denormalised MDCT coefficients */
+    uint8_t *collapse;         /* [nframes][2][21]   collapse masks */
+} OgCeltDebug;
+
+/* One-time per-device set-up of the constant tables (twiddles, window, PVQ U table). Called lazily by
+ * the launches too; exposed so a caller can pay the allocation before graph capture. */
+int opusgpu_init(int device);
+
+/* CELT: PVQ decode + band shaping + anti-collapse + denormalise + IMDCT + TDAC window + comb
+ * post-filter + de-emphasis, fused; one workgroup per frame.  Replaces the device-side math of
+ * celt/decoder.rs:453-837, :1601-1663 and the synthesis the reference lacks.
+ * Frames [i*frames_per_group, (i+1)*frames_per_group) must belong to one stream, in time order. */
+int opusgpu_launch_celt(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, uint32_t nframes,
+                        uint32_t frames_per_group, OgCeltState *state, float *pcm, size_t pcm_stride_floats,
+                        const OgCeltDebug *debug /* host struct, may be NULL */, void *stream);
+
+/* Bytes of OgCeltState[] / PCM a caller must provide are sizeof-derived; helpers for FFI users: */
+size_t opusgpu_sizeof_celt_state(void);
+size_t opusgpu_sizeof_celt_hdr(void);
+size_t opusgpu_sizeof_celt_leaf(void);
+size_t opusgpu_sizeof_silk_frame(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,60 @@
+// Host-side parsers of the opus_amd engine: packet framing, CELT and SILK side-info emission.
+#pragma once
+#include <cstdint>
+#include <vector>
+#include "../../../include/opusgpu_sideinfo.h"
+#include "rangedec.hpp"
+
+namespace og {
+
+// ---- packet framing: replaces Packet::from_slice (lu-zero/opus src/packet.rs:202-317) ----------
+enum Mode { MODE_SILK = 0, MODE_HYBRID = 1, MODE_CELT = 2 };          // packet.rs:13-18
+enum Bandwidth { BW_NB = 0, BW_MB = 1, BW_WB = 2, BW_SWB = 3, BW_FB = 4 };   // packet.rs:23-30
+
+struct Packet {
+    int mode, bandwidth, frame_size, stereo, code, nframes, padding;
+    int off[48], len[48];
+    int celt_end_band() const { static const int e[5] = {13, 17, 17, 19, 21}; return e[bandwidth]; }  // packet.rs:33-42
+};
+// 0 on success, negative OPUSGPU_* error otherwise (never aborts; packet.rs:215-225 panics instead)
+int parse_packet(const uint8_t *buf, int len, Packet *p);
+
+// ---- CELT: the sequential half of Celt::decode (src/celt/decoder.rs:2222-2323) ------------------
+struct CeltHostState {          // what must survive between frames on the host (celt/decoder.rs:34-88)
+    int channels = 2;
+    float oldE[2][21], logE1[2][21], logE2[2][21];
+    uint16_t pf_period = 0, pf_period_old = 0;
+    uint8_t pf_gain_q = 0, pf_gain_q_old = 0, pf_tapset = 0, pf_tapset_old = 0;
+    uint32_t rng = 0;
+    bool pending_reset = true;
+    CeltHostState() { reset(); }
+    void reset();
+};
+
+// Parses one CELT frame from rd (positioned after any SILK part), fills hdr and appends its leaves.
+// N = 120/240/480/960, [start,end) band range, C coded channels.  Returns 0, or <0 if the decoder
+// ran past the end of the frame (corrupt data; the frame is still emitted, as the reference would).
+int celt_parse_frame(CeltHostState &st, RangeDec &rd, int N, int start, int end, int C, OgCeltHdr *hdr,
+                     std::vector<OgCeltLeaf> &leaves);
+
+// ---- SILK: the entropy half of Silk::decode (src/silk/decoder.rs:2063-2127) ---------------------
+struct SilkChanHost {           // silk/decoder.rs:1296-1307 (the parse-side fields of SilkFrame)
+    int log_gain = 0, coded = 0, prev_voiced = 0, previous_lag = 0;
+    int16_t nlsfs[16] = {0};
+    float lpc[16] = {0};
+    bool flushed = true;        // device history must be cleared before the next coded frame
+    void flush();
+};
+struct SilkHostState {
+    int stereo_out = 1;
+    SilkChanHost mid, side;
+    bool stereo_reset = true;   // prev0/prev1 = 0 (silk/decoder.rs:1938-1939)
+    bool resampler_reset = true; // device resampler history must be cleared (build's own stage)
+    void flush();
+};
+// Parses the SILK part of one Opus frame (1-3 internal 20 ms frames); appends one OgSilkFrame each.
+// Returns number of internal frames, or <0 (OPUSGPU_UNSUPPORTED for LBRR, silk/decoder.rs:2070).
+int silk_parse(SilkHostState &st, RangeDec &rd, int bandwidth, int duration_ms, int stereo_pkt,
+               std::vector<OgSilkFrame> &out);
+
+}  // namespace og

@@ -1,0 +1,27 @@
+// One stream's host-side decoder state: what `struct Dec` holds in the reference (src/decoder.rs:16-30),
+// minus every sample buffer (those live in HBM).
+#pragma once
+#include <cstddef>
+#include <vector>
+#include "parse.hpp"
+#include "../../../include/opusgpu.h"
+
+namespace og {
+
+class StreamParser {
+public:
+    explicit StreamParser(int channels);
+    void reset();                                   // Decoder::flush (decoder.rs:184-187)
+    int channels() const { return channels_; }
+    // Parses one packet, appending records.  Returns the number of Opus frames or a negative OPUSGPU_* code.
+    int parse(const uint8_t *pkt, size_t len, OgFrameInfo *frames /*[48]*/, std::vector<OgCeltHdr> &celt,
+              std::vector<OgCeltLeaf> &leaves, std::vector<OgSilkFrame> &silk);
+
+private:
+    int channels_;
+    int prev_mode_ = -1;
+    CeltHostState celt_;
+    SilkHostState silk_;
+};
+
+}  // namespace og
