@@ -45,8 +45,8 @@ typedef struct {             /* one band of one frame, 12 bytes */
 } OgCeltBand;
 
 enum {                       /* OgCeltLeaf.meta */
-    OG_L_LOGB_MASK = 3,      /* log2 of the leaf's block count B */
-    OG_L_CMSHIFT_SHIFT = 2,  /* bits 2-4: shift of the leaf's collapse mask inside its quant_band (:1934) */
+    OG_L_LOGB_MASK = 7,      /* log2 of the leaf's block count B (1..16: tf time-division can double 8 short blocks) */
+    OG_L_FILL_DEAD = 8,      /* compute_theta cleared this subtree's fill bits (itheta 0 / 16384, :1567-1577) */
     OG_L_CH_Y = 32,          /* leaf writes the Y (second channel) buffer */
     OG_L_N1 = 64,            /* decode_band_1 leaf: index is the sign bit (celt/decoder.rs:1466-1495) */
     OG_L_HAS_LOWBAND = 128   /* a folding source exists for this leaf's quant_band */
@@ -54,12 +54,15 @@ enum {                       /* OgCeltLeaf.meta */
 
 typedef struct {             /* one decode_band_no_split / decode_band_1 call, 16 bytes */
     uint32_t index;          /* decode_uniform(V(N,K)) result (celt/decoder.rs:670) or N==1 sign */
-    uint32_t fillmap;        /* nibble j = bit of the quant_band root fill that feeds leaf fill bit j, 0xF = none */
     float gain;              /* product of mid/side gains down the recursion (:1912,1932,1949,1970) */
     uint8_t off;             /* offset inside the band */
     uint8_t n;               /* dimension N */
     uint8_t k;               /* pulses K, 0 = fill path (celt/decoder.rs:1626-1661) */
     uint8_t meta;
+    uint8_t cmshift;         /* position of the leaf's blocks inside its quant_band: its collapse mask is
+                                shifted left by this (:1934) and its fill is the quant_band fill shifted right by it */
+    uint8_t band;            /* band index */
+    uint16_t reserved;
 } OgCeltLeaf;
 
 typedef struct {             /* one CELT frame; fixed stride */

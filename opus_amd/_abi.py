@@ -9,7 +9,7 @@ OK, INVALID_DATA, CONFIG_INVALID, CONFIG_INCOMPLETE, UNSUPPORTED, MORE_DATA_NEED
 
 F_TRANSIENT, F_SILENCE, F_STEREO, F_ANTICOLLAPSE, F_RESET, F_OUT_STEREO, F_ACCUM = 1, 2, 4, 8, 16, 32, 64
 B_JOINT, B_INV, B_N2SWAP, B_N2NEG, B_DUAL, B_MIDFILL0, B_MERGE_NORM, B_LAST = 1, 2, 4, 8, 16, 32, 64, 128
-L_LOGB_MASK, L_CMSHIFT_SHIFT, L_CH_Y, L_N1, L_HAS_LOWBAND = 3, 2, 32, 64, 128
+L_LOGB_MASK, L_FILL_DEAD, L_CH_Y, L_N1, L_HAS_LOWBAND = 7, 8, 32, 64, 128
 
 
 class CeltBand(C.Structure):
@@ -19,8 +19,8 @@ class CeltBand(C.Structure):
 
 
 class CeltLeaf(C.Structure):
-    _fields_ = [("index", C.c_uint32), ("fillmap", C.c_uint32), ("gain", C.c_float), ("off", C.c_uint8),
-                ("n", C.c_uint8), ("k", C.c_uint8), ("meta", C.c_uint8)]
+    _fields_ = [("index", C.c_uint32), ("gain", C.c_float), ("off", C.c_uint8), ("n", C.c_uint8), ("k", C.c_uint8),
+                ("meta", C.c_uint8), ("cmshift", C.c_uint8), ("band", C.c_uint8), ("reserved", C.c_uint16)]
 
 
 class CeltHdr(C.Structure):

@@ -1,0 +1,786 @@
+// CELT frame decode, device side: one workgroup turns one frame's side-info (OgCeltHdr + leaves) into
+// PCM.  Fuses what SURVEY.md section 2.1 lists as K1 (PVQ index -> pulse vector, normalise, spreading
+// rotation, collapse mask), K2 (folding / noise fill, Haar + Hadamard reordering, stereo merge) and K3
+// (anti-collapse, denormalise, IMDCT, TDAC window, comb post-filter, de-emphasis): coefficients never
+// leave LDS between the stages.
+//
+// Reference anchors (lu-zero/opus): cwrsi celt/decoder.rs:541-660, unquantize :766-786, exp_rotation
+// :676-721, extract_collapse_mask :723-736, decode_band_no_split fill paths :1633-1661, haar1 :453-466,
+// (de)interleave_hadamard :472-538, stereo_merge :796-827, decode_band post-processing :1994-2032,
+// decode_bands :2037-2220.  Everything after band decoding is absent from the reference and follows
+// RFC 6716 4.3.5-4.3.7 (the reference only keeps the state fields, celt/decoder.rs:22-43, :90-94).
+//
+// HBM-bound by design (no MFMA: nothing here is a dense contraction); see DESIGN.md for the roofline.
+#pragma once
+#include "wg.h"
+#include "../../../include/opusgpu.h"
+
+#include "celt_frame_types.h"
+
+struct OgCeltLds {
+    float X[2][960];                  // coefficients (bands) -> MDCT bins -> FFT ping buffer -> de-emphasised PCM
+    union {
+        float norm[2][800];           // folding source (celt/decoder.rs `norm_mid`/`norm_side`)
+        OgCf A[2][480];               // FFT pong buffer
+    } u;
+    union {
+        float out[2][OG_OUTLEN];      // [history | frame | tail] time-domain buffer
+        struct {
+            uint32_t pvq_u[1272];
+            uint16_t pvq_row[16];
+            float scratch[176];       // transformed lowband copy
+            float tmp[176];           // Hadamard reorder bounce buffer
+        } b;
+    } v;
+    uint16_t leaf_cm[OG_MAXLEAF];
+    uint8_t collapse[2][24];
+    float red[4];
+    float carry[2][64];
+};
+
+#if !defined(OG_NO_TABLES)
+#ifndef RFC_TBL
+#if defined(__HIP__)
+#define RFC_TBL static __device__ const
+#else
+#define RFC_TBL static const
+#endif
+#endif
+#include "../rfc6716_tables.h"
+RFC_TBL float CELT_EMEANS[21] = {   /* RFC 6716 4.3.2 mean band energy (log2 units); not in the reference */
+    6.437500f, 6.250000f, 5.750000f, 5.312500f, 5.062500f, 4.812500f, 4.500000f, 4.375000f, 4.875000f,
+    4.687500f, 4.562500f, 4.437500f, 4.875000f, 4.625000f, 4.312500f, 4.500000f, 4.375000f, 4.625000f,
+    4.750000f, 4.437500f, 3.750000f};
+#endif
+
+OG_DEV uint32_t og_lcg(uint32_t s) { return 1664525u * s + 1013904223u; }   // celt/decoder.rs:1595-1599
+
+// ------------------------------------------------------------------------------------------------
+// K1: one lane expands one PVQ leaf.  Serial in N by nature (celt/decoder.rs:541-660); the
+// parallelism is across the ~10^5 leaves of a batch.
+OG_DEV uint32_t og_u(const uint32_t *U, const uint16_t *row, int n, int k)
+{
+    int lo = n < k ? n : k, hi = n < k ? k : n;
+    return U[row[lo] + hi];
+}
+
+// Writes the pulse vector as floats to x[0..n), returns ||y||^2; *cm = collapse mask for `blocks` blocks.
+OG_DEV uint32_t og_cwrsi(const uint32_t *U, const uint16_t *row, int n, int k, uint32_t i, float *x, int blocks,
+                         int *cm_out, int16_t *dbg)
+{
+    uint32_t yy = 0, p, q;
+    int s, k0, val, cm = 0, pos = 0;
+    const int nb = n / blocks;
+    int bl = nb, bi = 0;
+#define OG_PUT(v)                                                                                                   \
+    {                                                                                                               \
+        x[pos] = (float)(v);                                                                                        \
+        if (dbg) dbg[pos] = (int16_t)(v);                                                                           \
+        yy += (uint32_t)((v) * (v));                                                                                \
+        if (v) cm |= 1 << bi;                                                                                       \
+        pos++;                                                                                                      \
+        if (--bl == 0) { bl = nb; bi++; }                                                                           \
+    }
+    while (n > 2) {
+        if (k >= n) {                                   // lots of pulses
+            p = og_u(U, row, n, k + 1);
+            s = -(int)(i >= p);
+            i -= p & (uint32_t)s;
+            k0 = k;
+            q = og_u(U, row, n, n);
+            if (q > i) {
+                k = n;
+                do p = og_u(U, row, --k, n); while (p > i);
+            } else {
+                for (p = og_u(U, row, n, k); p > i; p = og_u(U, row, n, k)) k--;
+            }
+            i -= p;
+            val = (k0 - k + s) ^ s;
+            OG_PUT(val)
+        } else {                                        // lots of dimensions
+            p = og_u(U, row, k, n);
+            q = og_u(U, row, k + 1, n);
+            if (p <= i && i < q) {
+                i -= p;
+                OG_PUT(0)
+            } else {
+                s = -(int)(i >= q);
+                i -= q & (uint32_t)s;
+                k0 = k;
+                do p = og_u(U, row, --k, n); while (p > i);
+                i -= p;
+                val = (k0 - k + s) ^ s;
+                OG_PUT(val)
+            }
+        }
+        n--;
+    }
+    p = 2 * (uint32_t)k + 1;                            // n == 2
+    s = -(int)(i >= p);
+    i -= p & (uint32_t)s;
+    k0 = k;
+    k = (int)((i + 1) >> 1);
+    if (k) i -= 2 * (uint32_t)k - 1;
+    val = (k0 - k + s) ^ s;
+    OG_PUT(val)
+    s = -(int)i;                                        // n == 1
+    val = (k + s) ^ s;
+    OG_PUT(val)
+#undef OG_PUT
+    *cm_out = blocks <= 1 ? 1 : cm;
+    return yy;
+}
+
+OG_DEV void og_exp_rotation1(float *x, int len, int stride, float c, float s)   // RFC 6716 vq.c; celt/decoder.rs:676-692
+{
+    for (int i = 0; i < len - stride; i++) {
+        float x1 = x[i], x2 = x[i + stride];
+        x[i + stride] = c * x2 + s * x1;
+        x[i] = c * x1 - s * x2;
+    }
+    for (int i = len - 2 * stride - 1; i >= 0; i--) {
+        float x1 = x[i], x2 = x[i + stride];
+        x[i + stride] = c * x2 + s * x1;
+        x[i] = c * x1 - s * x2;
+    }
+}
+
+OG_DEV void og_exp_rotation(float *x, int len, int stride, int k, int spread)   // celt/decoder.rs:694-721
+{
+    if (2 * k >= len || spread == 0) return;
+    const float gain = (float)len / (float)(len + (20 - 5 * spread) * k);
+    const float theta = 0.5f * gain * gain;
+    const float c = cosf(0.5f * 3.14159265358979323846f * theta), s = cosf(0.5f * 3.14159265358979323846f * (1.f - theta));
+    int stride2 = 0;
+    if (len >= 8 * stride) {
+        stride2 = 1;
+        while ((stride2 * stride2 + stride2) * stride + (stride >> 2) < len) stride2++;
+    }
+    len /= stride;
+    for (int i = 0; i < stride; i++) {
+        if (stride2) og_exp_rotation1(x + i * len, len, stride2, s, c);
+        og_exp_rotation1(x + i * len, len, 1, c, s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2 building blocks: workgroup-collective vector operations on LDS (each ends in a barrier).
+OG_DEV void og_wg_haar1(float *x, int n0, int stride)   // celt/decoder.rs:453-466
+{
+    const float r = 0.70710678118654752440f;
+    const int sh = __builtin_ctz((unsigned)stride), total = (n0 >> 1) * stride;
+    OG_LANES_BEGIN(tid)
+    for (int p = tid; p < total; p += OG_WG) {
+        int i = p & (stride - 1), j = p >> sh;
+        float a = x[stride * 2 * j + i], b = x[stride * (2 * j + 1) + i];
+        x[stride * 2 * j + i] = (a + b) * r;
+        x[stride * (2 * j + 1) + i] = (a - b) * r;
+    }
+    OG_LANES_END
+}
+
+// celt/decoder.rs:472-538.  inverse = 0: deinterleave (frequency order -> block order), 1: interleave.
+OG_DEV void og_wg_hadamard_reorder(float *x, float *tmp, int n0, int stride, int hadamard, int inverse)
+{
+    const int sh = __builtin_ctz((unsigned)stride), n = n0 * stride;
+    const uint8_t *ord = CELT_HADAMARD_ORDERY + stride - 2;
+    OG_LANES_BEGIN(tid)
+    for (int p = tid; p < n; p += OG_WG) {
+        int i = p & (stride - 1), j = p >> sh;
+        int row = hadamard ? ord[i] : i;
+        if (inverse) tmp[j * stride + i] = x[row * n0 + j];
+        else tmp[row * n0 + j] = x[j * stride + i];
+    }
+    OG_LANES_END
+    OG_LANES_BEGIN(tid)
+    for (int p = tid; p < n; p += OG_WG) x[p] = tmp[p];
+    OG_LANES_END
+}
+
+// x *= gain / ||x||  (celt/decoder.rs:788-794); the sum runs in the oracle's order on one lane
+OG_DEV void og_wg_renormalize(float *x, int n, float gain, float *red)
+{
+    OG_LANES_BEGIN(tid)
+    if (tid == 0) {
+        float e = 1e-15f;
+        for (int i = 0; i < n; i++) e += x[i] * x[i];
+        red[0] = gain / sqrtf(e);
+    }
+    OG_LANES_END
+    OG_LANES_BEGIN(tid)
+    const float g = red[0];
+    for (int p = tid; p < n; p += OG_WG) x[p] *= g;
+    OG_LANES_END
+}
+
+struct OgBandCtx {
+    const OgCeltHdr *h;
+    const OgCeltLeaf *lv;             // the frame's leaves
+    const OgCeltTables *T;
+    OgCeltLds *L;
+    uint32_t seed;                    // uniform across the workgroup
+    int lm;
+};
+
+// One quant_band call (celt/decoder.rs:1665-1768 pre, :1601-1663 leaves, :1994-2032 post) on channel
+// buffer x, for the leaves of band `bd` whose OG_L_CH_Y flag equals chy.  PVQ leaves were expanded by K1.
+OG_DEV int og_quant_band(OgBandCtx &c, const OgCeltBand &bd, int chy, float *x, int n, int B, const float *lowband,
+                         float *lowband_out, int fill)
+{
+    OgCeltLds &L = *c.L;
+    const OgCeltLeaf *lv = c.lv + bd.leaf0;
+    const int nl = bd.nleaves;
+    if (n == 1) {                                       // celt/decoder.rs:1466-1495
+        OG_LANES_BEGIN(tid)
+        if (tid == 0) {
+            float v = 1.f;
+            for (int l = 0; l < nl; l++)
+                if (((lv[l].meta & OG_L_CH_Y) != 0) == (chy != 0)) v = lv[l].index ? -1.f : 1.f;
+            x[0] = v;
+            if (lowband_out) lowband_out[0] = v;
+        }
+        OG_LANES_END
+        return 1;
+    }
+    const int n0 = n, long_blocks = B == 1;
+    int n_b = n / B, tf_change = bd.tf_change, recombine = tf_change > 0 ? tf_change : 0, time_divide = 0;
+    bool need_lowband = false;
+    if (lowband)
+        for (int l = 0; l < nl; l++)
+            if (((lv[l].meta & OG_L_CH_Y) != 0) == (chy != 0) && lv[l].k == 0 && (lv[l].meta & OG_L_HAS_LOWBAND)) need_lowband = true;
+    float *lb = L.v.b.scratch;
+    if (need_lowband) {
+        OG_LANES_BEGIN(tid)
+        for (int p = tid; p < n; p += OG_WG) lb[p] = lowband[p];
+        OG_LANES_END
+    }
+    for (int k = 0; k < recombine; k++) {
+        if (need_lowband) og_wg_haar1(lb, n >> k, 1 << k);
+        fill = CELT_BIT_INTERLEAVE[fill & 0xF] | CELT_BIT_INTERLEAVE[fill >> 4] << 2;
+    }
+    B >>= recombine;
+    n_b <<= recombine;
+    while ((n_b & 1) == 0 && tf_change < 0) {
+        if (need_lowband) og_wg_haar1(lb, n_b, B);
+        fill |= fill << B;
+        B <<= 1;
+        n_b >>= 1;
+        time_divide++;
+        tf_change++;
+    }
+    const int B0 = B, n_b0 = n_b;
+    if (B0 > 1 && need_lowband) og_wg_hadamard_reorder(lb, L.v.b.tmp, n_b >> recombine, B0 << recombine, long_blocks, 0);
+
+    int cm = 0;
+    for (int l = 0; l < nl; l++) {                      // leaves in decode order (the LCG seed is sequential)
+        const OgCeltLeaf lf = lv[l];
+        if (((lf.meta & OG_L_CH_Y) != 0) != (chy != 0)) continue;
+        const int Bl = 1 << (lf.meta & OG_L_LOGB_MASK), sh = lf.cmshift;
+        if (lf.k > 0) {
+            cm |= (int)L.leaf_cm[bd.leaf0 + l] << sh;
+            continue;
+        }
+        // the leaf's share of the quant_band fill: the recursion only shifts it (side halves) or clears it (theta)
+        const int fl = (lf.meta & OG_L_FILL_DEAD) ? 0 : (fill >> sh) & ((1 << Bl) - 1);
+        if (!fl) continue;                              // x stays zero (celt/decoder.rs:1640-1643)
+        float *xl = x + lf.off;
+        const int nn = lf.n;
+        const uint32_t s0 = c.seed;
+        const uint32_t *la = c.T->lcg_a, *lc = c.T->lcg_c;
+        if (!(lf.meta & OG_L_HAS_LOWBAND)) {            // noise (celt/decoder.rs:1644-1651)
+            OG_LANES_BEGIN(tid)
+            for (int p = tid; p < nn; p += OG_WG) {
+                uint32_t s = la[p + 1] * s0 + lc[p + 1];
+                xl[p] = (float)((int32_t)s >> 20);
+            }
+            OG_LANES_END
+            cm |= ((1 << Bl) - 1) << sh;
+        } else {                                        // fold the lower band in (celt/decoder.rs:1652-1659)
+            const float *lbl = lb + lf.off;
+            OG_LANES_BEGIN(tid)
+            for (int p = tid; p < nn; p += OG_WG) {
+                uint32_t s = la[p + 1] * s0 + lc[p + 1];
+                xl[p] = lbl[p] + ((s & 0x8000) ? 1.f / 256 : -1.f / 256);
+            }
+            OG_LANES_END
+            cm |= fl << sh;
+        }
+        c.seed = la[nn] * s0 + lc[nn];
+        og_wg_renormalize(xl, nn, lf.gain, L.red);
+    }
+
+    if (B0 > 1) og_wg_hadamard_reorder(x, L.v.b.tmp, n_b >> recombine, B0 << recombine, long_blocks, 1);
+    n_b = n_b0;
+    B = B0;
+    for (int k = 0; k < time_divide; k++) {
+        B >>= 1;
+        n_b <<= 1;
+        cm |= cm >> B;
+        og_wg_haar1(x, n_b, B);
+    }
+    for (int k = 0; k < recombine; k++) {
+        cm = CELT_BIT_DEINTERLEAVE[cm];
+        og_wg_haar1(x, n0 >> k, 1 << k);
+    }
+    B <<= recombine;
+    if (lowband_out) {
+        const float s = sqrtf((float)n0);
+        OG_LANES_BEGIN(tid)
+        for (int p = tid; p < n0; p += OG_WG) lowband_out[p] = s * x[p];
+        OG_LANES_END
+    }
+    return cm & ((1 << B) - 1);
+}
+
+// celt/decoder.rs:2037-2220 with the range-decoder half removed (the host ran it)
+OG_DEV void og_celt_bands(OgBandCtx &c)
+{
+    const OgCeltHdr *h = c.h;
+    OgCeltLds &L = *c.L;
+    const int lm = c.lm, M = 1 << lm, start = h->start, end = h->end;
+    const int C = (h->flags & OG_F_STEREO) ? 2 : 1;
+    const int B = (h->flags & OG_F_TRANSIENT) ? M : 1;
+    const int norm_offset = M * CELT_EBANDS[start];
+    for (int i = start; i < end; i++) {
+        const OgCeltBand bd = h->band[i];
+        const int boff = M * CELT_EBANDS[i], n = M * CELT_BAND_WIDTH[i];
+        const bool last = (bd.flags & OG_B_LAST) != 0;
+        int x_cm, y_cm;
+        if (bd.lowband != 0xFF) {
+            x_cm = y_cm = 0;
+            for (int f = bd.fold_lo; f < bd.fold_hi; f++) { x_cm |= L.collapse[0][f]; y_cm |= L.collapse[C - 1][f]; }
+        } else {
+            x_cm = y_cm = (1 << B) - 1;
+        }
+        if (bd.flags & OG_B_MERGE_NORM) {               // dual -> intensity switch (celt/decoder.rs:2133-2138)
+            const int cnt = boff - norm_offset;
+            OG_LANES_BEGIN(tid)
+            for (int p = tid; p < cnt; p += OG_WG) L.u.norm[0][p] = 0.5f * (L.u.norm[0][p] + L.u.norm[1][p]);
+            OG_LANES_END
+        }
+        const float *lb0 = bd.lowband != 0xFF ? L.u.norm[0] + bd.lowband * M : nullptr;
+        const float *lb1 = bd.lowband != 0xFF ? L.u.norm[1] + bd.lowband * M : nullptr;
+        float *out0 = last ? nullptr : L.u.norm[0] + boff - norm_offset;
+        float *out1 = last ? nullptr : L.u.norm[1] + boff - norm_offset;
+        float *x = L.X[0] + boff, *y = L.X[1] + boff;
+        if (bd.flags & OG_B_DUAL) {
+            x_cm = og_quant_band(c, bd, 0, x, n, B, lb0, out0, x_cm);
+            y_cm = og_quant_band(c, bd, 1, y, n, B, lb1, out1, y_cm);
+        } else if (C == 2 && n == 1) {                  // decode_band_1 on both channels (celt/decoder.rs:1466-1495)
+            (void)og_quant_band(c, bd, 0, x, 1, B, nullptr, out0, 0);
+            (void)og_quant_band(c, bd, 1, y, 1, B, nullptr, nullptr, 0);
+            x_cm = y_cm = 1;
+        } else if (C == 2) {                            // joint stereo (celt/decoder.rs:1795-1862 + RFC 6716 bands.c)
+            const float mid = (1.f / 32768) * bd.imid, side = (1.f / 32768) * bd.iside;
+            int cm;
+            if (n == 2) {
+                const int sw = (bd.flags & OG_B_N2SWAP) != 0;
+                float *x2 = sw ? y : x, *y2 = sw ? x : y;
+                cm = og_quant_band(c, bd, sw, x2, n, B, lb0, out0, x_cm | y_cm);
+                const float sign = (bd.flags & OG_B_N2NEG) ? -1.f : 1.f;
+                OG_LANES_BEGIN(tid)
+                if (tid == 0) {
+                    y2[0] = -sign * x2[1];
+                    y2[1] = sign * x2[0];
+                    x[0] *= mid; x[1] *= mid; y[0] *= side; y[1] *= side;
+                    float t = x[0]; x[0] = t - y[0]; y[0] = t + y[0];
+                    t = x[1]; x[1] = t - y[1]; y[1] = t + y[1];
+                }
+                OG_LANES_END
+            } else {
+                const int fill = (bd.flags & OG_B_MIDFILL0) ? 0 : (x_cm | y_cm);
+                cm = og_quant_band(c, bd, 0, x, n, B, lb0, out0, fill);
+                cm |= og_quant_band(c, bd, 1, y, n, B, nullptr, nullptr, 0);
+                OG_LANES_BEGIN(tid)                     // stereo_merge (celt/decoder.rs:796-827)
+                if (tid == 0) {
+                    float xp = 0, sd = 0;
+                    for (int j = 0; j < n; j++) { xp += x[j] * y[j]; sd += y[j] * y[j]; }
+                    L.red[0] = xp; L.red[1] = sd;
+                }
+                OG_LANES_END
+                const float xp = L.red[0] * mid, e = mid * mid + L.red[1];
+                const float e0 = e - 2.f * xp, e1 = e + 2.f * xp;
+                if (e0 < 6e-4f || e1 < 6e-4f) {
+                    OG_LANES_BEGIN(tid)
+                    for (int p = tid; p < n; p += OG_WG) y[p] = x[p];
+                    OG_LANES_END
+                } else {
+                    const float g0 = 1.f / sqrtf(e0), g1 = 1.f / sqrtf(e1);
+                    OG_LANES_BEGIN(tid)
+                    for (int p = tid; p < n; p += OG_WG) {
+                        float v0 = mid * x[p], v1 = y[p];
+                        x[p] = g0 * (v0 - v1);
+                        y[p] = g1 * (v0 + v1);
+                    }
+                    OG_LANES_END
+                }
+            }
+            if (bd.flags & OG_B_INV) {
+                OG_LANES_BEGIN(tid)
+                for (int p = tid; p < n; p += OG_WG) y[p] = -y[p];
+                OG_LANES_END
+            }
+            x_cm = y_cm = cm;
+        } else {
+            x_cm = y_cm = og_quant_band(c, bd, 0, x, n, B, lb0, out0, x_cm | y_cm);
+        }
+        OG_LANES_BEGIN(tid)
+        if (tid == 0) { L.collapse[0][i] = (uint8_t)x_cm; L.collapse[C - 1][i] = (uint8_t)y_cm; }
+        OG_LANES_END
+    }
+}
+
+// RFC 6716 4.3.5 anti-collapse (bands.c); the reference only reserves its flag bit (celt/decoder.rs:1092)
+OG_DEV void og_anti_collapse(OgBandCtx &c)
+{
+    const OgCeltHdr *h = c.h;
+    OgCeltLds &L = *c.L;
+    const int lm = c.lm, C = (h->flags & OG_F_STEREO) ? 2 : 1;
+    const uint32_t *la = c.T->lcg_a, *lc = c.T->lcg_c;
+    for (int i = h->start; i < h->end; i++) {
+        const int n0 = CELT_BAND_WIDTH[i];
+        const int depth = h->pulses_depth[i];
+        const float thresh = 0.5f * exp2f(-0.125f * (float)depth);
+        const float sqrt_1 = 1.f / sqrtf((float)(n0 << lm));
+        for (int ch = 0; ch < C; ch++) {
+            float ediff = h->energy[ch][i] - h->prev_min[ch][i];
+            if (ediff < 0) ediff = 0;
+            float r = 2.f * exp2f(-ediff);
+            if (lm == 3) r *= 1.41421356f;
+            if (r > thresh) r = thresh;
+            r *= sqrt_1;
+            float *x = L.X[ch] + (CELT_EBANDS[i] << lm);
+            const int mask = L.collapse[ch][i];
+            bool renorm = false;
+            for (int k = 0; k < (1 << lm); k++) {
+                if (mask & (1 << k)) continue;
+                const uint32_t s0 = c.seed;
+                OG_LANES_BEGIN(tid)
+                for (int j = tid; j < n0; j += OG_WG) {
+                    uint32_t s = la[j + 1] * s0 + lc[j + 1];
+                    x[(j << lm) + k] = (s & 0x8000) ? r : -r;
+                }
+                OG_LANES_END
+                c.seed = la[n0] * s0 + lc[n0];
+                renorm = true;
+            }
+            if (renorm) og_wg_renormalize(x, n0 << lm, 1.f, L.red);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3: IMDCT as an N/4-point complex FFT (N/4 = 60 * 2^lm = 15 * 2^(lm+2): radix 4/2/3/5 Stockham
+// stages ping-ponging between two LDS buffers), RFC 6716 4.3.7.
+OG_DEV OgCf og_cmul(OgCf a, OgCf b) { OgCf r; r.r = a.r * b.r - a.i * b.i; r.i = a.r * b.i + a.i * b.r; return r; }
+
+// One Stockham stage of radix R over `ntr` transforms of size n; transform t of channel c starts at
+// c*480 + t*n.  Ns = product of the radices already done.
+OG_DEV void og_wg_fft_stage(const OgCf *src, OgCf *dst, int n, int nch, int blocks, int Ns, int R, const OgCf *W)
+{
+    const int per = n / R, total = nch * blocks * per, wstep = 480 / (Ns * R);
+    OG_LANES_BEGIN(tid)
+    for (int q = tid; q < total; q += OG_WG) {
+        const int tt = q / per, j = q - tt * per;
+        const int ch = tt / blocks, b = tt - ch * blocks;
+        const int base = ch * 480 + b * n;
+        const int k = j % Ns;
+        const int j0 = (j - k) * R + k;
+        OgCf v[5];
+        for (int r = 0; r < R; r++) {
+            v[r] = src[base + j + r * per];
+            if (r && k) v[r] = og_cmul(v[r], W[k * r * wstep]);
+        }
+        OgCf *o = dst + base + j0;
+        if (R == 2) {
+            o[0].r = v[0].r + v[1].r; o[0].i = v[0].i + v[1].i;
+            o[Ns].r = v[0].r - v[1].r; o[Ns].i = v[0].i - v[1].i;
+        } else if (R == 4) {
+            OgCf t0 = {v[0].r + v[2].r, v[0].i + v[2].i}, t1 = {v[0].r - v[2].r, v[0].i - v[2].i};
+            OgCf t2 = {v[1].r + v[3].r, v[1].i + v[3].i}, t3 = {v[1].i - v[3].i, v[3].r - v[1].r};   // -i (v1 - v3)
+            o[0].r = t0.r + t2.r; o[0].i = t0.i + t2.i;
+            o[Ns].r = t1.r + t3.r; o[Ns].i = t1.i + t3.i;
+            o[2 * Ns].r = t0.r - t2.r; o[2 * Ns].i = t0.i - t2.i;
+            o[3 * Ns].r = t1.r - t3.r; o[3 * Ns].i = t1.i - t3.i;
+        } else if (R == 3) {
+            const float s3 = 0.86602540378443864676f;
+            OgCf s = {v[1].r + v[2].r, v[1].i + v[2].i}, d = {v[1].r - v[2].r, v[1].i - v[2].i};
+            OgCf m = {v[0].r - 0.5f * s.r, v[0].i - 0.5f * s.i};
+            OgCf e = {s3 * d.i, -s3 * d.r};                                                          // -i s3 d
+            o[0].r = v[0].r + s.r; o[0].i = v[0].i + s.i;
+            o[Ns].r = m.r + e.r; o[Ns].i = m.i + e.i;
+            o[2 * Ns].r = m.r - e.r; o[2 * Ns].i = m.i - e.i;
+        } else {
+            const float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f;
+            const float s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;
+            OgCf s14 = {v[1].r + v[4].r, v[1].i + v[4].i}, d14 = {v[1].r - v[4].r, v[1].i - v[4].i};
+            OgCf s23 = {v[2].r + v[3].r, v[2].i + v[3].i}, d23 = {v[2].r - v[3].r, v[2].i - v[3].i};
+            OgCf p1 = {v[0].r + c1 * s14.r + c2 * s23.r, v[0].i + c1 * s14.i + c2 * s23.i};
+            OgCf p2 = {v[0].r + c2 * s14.r + c1 * s23.r, v[0].i + c2 * s14.i + c1 * s23.i};
+            OgCf q1 = {s1 * d14.r + s2 * d23.r, s1 * d14.i + s2 * d23.i};
+            OgCf q2 = {s2 * d14.r - s1 * d23.r, s2 * d14.i - s1 * d23.i};
+            o[0].r = v[0].r + s14.r + s23.r; o[0].i = v[0].i + s14.i + s23.i;
+            o[Ns].r = p1.r + q1.i; o[Ns].i = p1.i - q1.r;                                           // p1 - i q1
+            o[4 * Ns].r = p1.r - q1.i; o[4 * Ns].i = p1.i + q1.r;
+            o[2 * Ns].r = p2.r + q2.i; o[2 * Ns].i = p2.i - q2.r;
+            o[3 * Ns].r = p2.r - q2.i; o[3 * Ns].i = p2.i + q2.r;
+        }
+    }
+    OG_LANES_END
+}
+
+// RFC 6716 celt.c comb_filter, in place, for both channels; y points at sample 0 of channel 0 inside
+// L.v.out, channel stride OG_OUTLEN.  The recursion reaches back >= 13 samples, so `step` samples are
+// independent at a time.
+OG_DEV void og_wg_comb_filter(float *y0, int nch, int T0, int T1, int n, float g0, float g1, int tap0, int tap1,
+                              const float *window)
+{
+    if (g0 == 0.f && g1 == 0.f) return;
+    if (T0 < 15) T0 = 15;
+    if (T1 < 15) T1 = 15;
+    const float g00 = g0 * CELT_POSTFILTER_TAPS[tap0][0], g01 = g0 * CELT_POSTFILTER_TAPS[tap0][1], g02 = g0 * CELT_POSTFILTER_TAPS[tap0][2];
+    const float g10 = g1 * CELT_POSTFILTER_TAPS[tap1][0], g11 = g1 * CELT_POSTFILTER_TAPS[tap1][1], g12 = g1 * CELT_POSTFILTER_TAPS[tap1][2];
+    const int overlap = (g0 == g1 && T0 == T1 && tap0 == tap1) ? 0 : 120;
+    const int stop = g1 == 0.f ? overlap : n;          // with g1 == 0 only the cross-fade runs
+    const int lanes = OG_WG / 2;                       // lanes per channel
+    int step = (T0 < T1 ? T0 : T1) - 2;
+    if (step > lanes) step = lanes;
+    for (int i0 = 0; i0 < stop; i0 += step) {
+        const int i1 = i0 + step < stop ? i0 + step : stop;
+        OG_LANES_BEGIN(tid)
+        const int ch = tid / lanes, i = i0 + (tid - ch * lanes);
+        if (ch < nch && i < i1) {
+            float *y = y0 + ch * OG_OUTLEN;
+            if (i < overlap) {
+                const float f = window[i] * window[i];
+                y[i] = y[i] + ((1.f - f) * g00) * y[i - T0]
+                     + ((1.f - f) * g01) * (y[i - T0 + 1] + y[i - T0 - 1])
+                     + ((1.f - f) * g02) * (y[i - T0 + 2] + y[i - T0 - 2])
+                     + (f * g10) * y[i - T1]
+                     + (f * g11) * (y[i - T1 + 1] + y[i - T1 - 1])
+                     + (f * g12) * (y[i - T1 + 2] + y[i - T1 - 2]);
+            } else {
+                y[i] = y[i] + g10 * y[i - T1] + g11 * (y[i - T1 + 1] + y[i - T1 - 1]) + g12 * (y[i - T1 + 2] + y[i - T1 - 2]);
+            }
+        }
+        OG_LANES_END
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The whole frame.  Uniform arguments; every lane of the workgroup calls it.
+OG_DEV void og_celt_frame(const OgCeltHdr *h, const OgCeltLeaf *leaves_base, const OgCeltTables *T, OgCeltState *states,
+                          float *pcm_base, size_t pcm_stride, OgCeltLds &L, int16_t *dbg_pulses, float *dbg_norm,
+                          float *dbg_freq, uint8_t *dbg_collapse)
+{
+    const OgCeltLeaf *lv = leaves_base + h->leaf_begin;
+    const int lm = h->lm, M = 1 << lm, N = 120 << lm;
+    const int C = (h->flags & OG_F_STEREO) ? 2 : 1, CC = (h->flags & OG_F_OUT_STEREO) ? 2 : 1;
+    const bool transient = (h->flags & OG_F_TRANSIENT) != 0, silence = (h->flags & OG_F_SILENCE) != 0;
+    const int nleaves = h->nleaves < OG_MAXLEAF ? h->nleaves : OG_MAXLEAF;
+    OgCeltState *st = states + h->stream;
+    const bool reset = (h->flags & OG_F_RESET) != 0;
+
+    // ---- phase 0: clear coefficient buffers, stage the PVQ table, map leaves to bands
+    OG_LANES_BEGIN(tid)
+    for (int p = tid; p < 2 * 960; p += OG_WG) (&L.X[0][0])[p] = 0.f;
+    for (int p = tid; p < 2 * 800; p += OG_WG) (&L.u.norm[0][0])[p] = 0.f;
+    for (int p = tid; p < 1272; p += OG_WG) L.v.b.pvq_u[p] = T->pvq_u[p];
+    if (tid < 16) L.v.b.pvq_row[tid] = T->pvq_row[tid];
+    if (tid < 48) (&L.collapse[0][0])[tid] = 0;
+    OG_LANES_END
+
+    if (!silence) {
+        // ---- phase 1 (K1): one lane per PVQ leaf
+        OG_LANES_BEGIN(tid)
+        for (int l = tid; l < nleaves; l += OG_WG) {
+            const OgCeltLeaf lf = lv[l];
+            if (lf.k == 0 || (lf.meta & OG_L_N1)) continue;
+            const int band = lf.band, ch = (lf.meta & OG_L_CH_Y) ? 1 : 0;
+            const int pos = (CELT_EBANDS[band] << lm) + lf.off;
+            const int Bl = 1 << (lf.meta & OG_L_LOGB_MASK);
+            float *x = L.X[ch] + pos;
+            int cm;
+            const uint32_t yy = og_cwrsi(L.v.b.pvq_u, L.v.b.pvq_row, lf.n, lf.k, lf.index, x, Bl, &cm,
+                                         dbg_pulses ? dbg_pulses + ch * 960 + pos : nullptr);
+            const float g = lf.gain / sqrtf((float)yy);                      // celt/decoder.rs:766-786
+            for (int i = 0; i < lf.n; i++) x[i] *= g;
+            og_exp_rotation(x, lf.n, Bl, lf.k, h->spread);
+            L.leaf_cm[l] = (uint16_t)cm;
+        }
+        OG_LANES_END
+
+        // ---- phase 2 (K2): bands in order
+        OgBandCtx c;
+        c.h = h; c.lv = lv; c.T = T; c.L = &L; c.seed = h->seed; c.lm = lm;
+        og_celt_bands(c);
+        if (dbg_norm || dbg_collapse) {
+            OG_LANES_BEGIN(tid)
+            if (dbg_norm) for (int p = tid; p < 2 * 960; p += OG_WG) dbg_norm[p] = (&L.X[0][0])[p];
+            if (dbg_collapse && tid < 42) dbg_collapse[tid] = L.collapse[tid / 21][tid % 21];
+            OG_LANES_END
+        }
+        if (h->flags & OG_F_ANTICOLLAPSE) og_anti_collapse(c);
+    }
+
+    // ---- phase 4: denormalise (RFC 6716 4.3.6) + channel up/down-mix into MDCT bins
+    OG_LANES_BEGIN(tid)
+    for (int p = tid; p < 2 * 960; p += OG_WG) {
+        const int ch = p >= 960, j = p - ch * 960;
+        float v = 0.f;
+        if (!silence && ch < C) {
+            int b = -1;                                 // band of bin j
+            const int jb = j >> lm;
+            if (jb < 100) { b = 0; while (CELT_EBANDS[b + 1] <= jb) b++; }
+            if (b >= h->start && b < h->end) {
+                float lg = h->energy[ch][b] + CELT_EMEANS[b];
+                v = L.X[ch][j] * exp2f(lg < 32.f ? lg : 32.f);
+            }
+        }
+        L.X[ch][j] = v;
+    }
+    OG_LANES_END
+    if (CC == 2 && C == 1) {
+        OG_LANES_BEGIN(tid)
+        for (int p = tid; p < 960; p += OG_WG) L.X[1][p] = L.X[0][p];
+        OG_LANES_END
+    } else if (CC == 1 && C == 2) {
+        OG_LANES_BEGIN(tid)
+        for (int p = tid; p < 960; p += OG_WG) L.X[0][p] = 0.5f * L.X[0][p] + 0.5f * L.X[1][p];
+        OG_LANES_END
+    }
+    if (dbg_freq) {
+        OG_LANES_BEGIN(tid)
+        for (int p = tid; p < 2 * 960; p += OG_WG) dbg_freq[p] = (&L.X[0][0])[p];
+        OG_LANES_END
+    }
+
+    // ---- phase 5 (K3): IMDCT.  B blocks of NB bins, interleaved with stride B in X.
+    const int B = transient ? M : 1, NB = N / B, n4 = NB >> 1;
+    const OgCf *tw = T->tw + (n4 - 60);
+    OgCf *bufA = &L.u.A[0][0], *bufB = (OgCf *)&L.X[0][0];
+    OG_LANES_BEGIN(tid)
+    for (int q = tid; q < CC * (N >> 1); q += OG_WG) {                       // pre-twiddle
+        const int ch = q / (N >> 1), r = q - ch * (N >> 1), b = r / n4, i = r - b * n4;
+        const float x1 = L.X[ch][(2 * i) * B + b], x2 = L.X[ch][(NB - 1 - 2 * i) * B + b];
+        const OgCf w = tw[i];
+        OgCf z;
+        z.r = x1 * w.r + x2 * w.i;
+        z.i = x2 * w.r - x1 * w.i;
+        bufA[ch * 480 + b * n4 + i] = z;
+    }
+    OG_LANES_END
+    {
+        int radix[5], ns = 0;                           // 60 * 2^lm = 4 * 4^a * 2^b * 3 * 5
+        int rem = n4 / 15;
+        while (rem % 4 == 0) { radix[ns++] = 4; rem /= 4; }
+        if (rem == 2) radix[ns++] = 2;
+        radix[ns++] = 3;
+        radix[ns++] = 5;
+        int Ns = 1;
+        OgCf *src = bufA, *dst = bufB;
+        for (int s = 0; s < ns; s++) {
+            og_wg_fft_stage(src, dst, n4, CC, B, Ns, radix[s], T->fft_w);
+            Ns *= radix[s];
+            OgCf *t = src; src = dst; dst = t;
+        }
+        // `src` now holds the spectrum; load state + post-twiddle into the time buffer
+        OG_LANES_BEGIN(tid)
+        for (int q = tid; q < CC * 60; q += OG_WG) {                         // previous frame's tail
+            const int ch = q / 60, i = q - ch * 60;
+            L.v.out[ch][OG_HIST + i] = reset ? 0.f : st->overlap[ch][i];
+        }
+        for (int q = tid; q < CC * (N >> 1); q += OG_WG) {
+            const int ch = q / (N >> 1), r = q - ch * (N >> 1), b = r / n4, k = r - b * n4;
+            const OgCf Z = src[ch * 480 + b * n4 + k], w = tw[k];
+            const float vr = Z.r * w.r + Z.i * w.i, vi = Z.i * w.r - Z.r * w.i;
+            float *D = &L.v.out[ch][OG_HIST + NB * b + 60];
+            D[2 * k] = vi;
+            D[NB - 1 - 2 * k] = -vr;
+        }
+        OG_LANES_END
+    }
+    OG_LANES_BEGIN(tid)
+    for (int q = tid; q < CC * B * 60; q += OG_WG) {                         // TDAC mirror (RFC 6716 mdct.c)
+        const int ch = q / (B * 60), r = q - ch * (B * 60), b = r / 60, i = r - b * 60;
+        float *o = &L.v.out[ch][OG_HIST + NB * b];
+        const float x1 = o[119 - i], x2 = o[i];
+        const float w1 = T->window[i], w2 = T->window[119 - i];
+        o[i] = w2 * x2 - w1 * x1;
+        o[119 - i] = w1 * x2 + w2 * x1;
+    }
+    OG_LANES_END
+
+    // ---- phase 6: comb post-filter (RFC 6716 4.3.7.1); parameter sets [0] old, [1] current, [2] new
+    const float pg0 = 0.09375f * h->pf_gain_q[0], pg1 = 0.09375f * h->pf_gain_q[1], pg2 = 0.09375f * h->pf_gain_q[2];
+    const uint32_t pos0 = reset ? 0u : st->pos;
+    if (pg0 != 0.f || pg1 != 0.f || (lm != 0 && pg2 != 0.f)) {
+        int reach = 0;
+        for (int k = 0; k < 3; k++) { int t = h->pf_period[k] < 15 ? 15 : h->pf_period[k]; if (t > reach) reach = t; }
+        reach += 2;
+        if (reach > OG_HIST) reach = OG_HIST;
+        OG_LANES_BEGIN(tid)
+        for (int q = tid; q < CC * reach; q += OG_WG) {
+            const int ch = q / reach, d = q - ch * reach + 1;
+            L.v.out[ch][OG_HIST - d] = reset ? 0.f : st->hist[ch][(pos0 - (uint32_t)d) & 1023u];
+        }
+        OG_LANES_END
+        float *y0 = &L.v.out[0][OG_HIST];
+        og_wg_comb_filter(y0, CC, h->pf_period[0], h->pf_period[1], 120, pg0, pg1, h->pf_tapset[0], h->pf_tapset[1], T->window);
+        if (lm != 0)
+            og_wg_comb_filter(y0 + 120, CC, h->pf_period[1], h->pf_period[2], N - 120, pg1, pg2, h->pf_tapset[1],
+                              h->pf_tapset[2], T->window);
+    }
+
+    // ---- phase 7: de-emphasis t[j] = y[j] + 0.85 t[j-1] as a blocked scan (60 lanes x N/60 samples per channel),
+    //      then coalesced PCM + state write-back
+    const float coef = 0.85000610f;
+    const int Lc = N / 60;
+    float *tbuf = &L.X[0][0];                           // [2][960], free since the FFT finished... (bufB may hold
+                                                        // the spectrum when the stage count is odd; it was consumed above)
+    OG_LANES_BEGIN(tid)
+    if (tid < CC * 60) {
+        const int ch = tid / 60, l = tid - ch * 60;
+        const float *y = &L.v.out[ch][OG_HIST + l * Lc];
+        float m = 0.f, t = 0.f;
+        for (int j = 0; j < Lc; j++) { t = y[j] + m; m = coef * t; }
+        L.carry[ch][l] = m;                             // chunk's own contribution to the running memory
+    }
+    OG_LANES_END
+    float aL = 1.f;
+    for (int j = 0; j < Lc; j++) aL *= coef;            // coef^Lc
+    OG_LANES_BEGIN(tid)
+    if (tid < CC * 60) {
+        const int ch = tid / 60, l = tid - ch * 60;
+        float m = reset ? 0.f : st->deemph[ch];
+        for (int q = 0; q < l; q++) m = m * aL + L.carry[ch][q];
+        const float *y = &L.v.out[ch][OG_HIST + l * Lc];
+        float *t = tbuf + ch * 960 + l * Lc;
+        for (int j = 0; j < Lc; j++) { const float v = y[j] + m; m = coef * v; t[j] = v; }
+        if (l == 59) st->deemph[ch] = m;
+    }
+    OG_LANES_END
+    float *pcm = pcm_base + (size_t)h->stream * pcm_stride + (size_t)h->pcm_off * CC;
+    const bool accum = (h->flags & OG_F_ACCUM) != 0;
+    OG_LANES_BEGIN(tid)
+    for (int q = tid; q < N * CC; q += OG_WG) {
+        const int j = q / CC, ch = q - j * CC;
+        const float v = tbuf[ch * 960 + j] * (1.f / 32768.f);
+        pcm[q] = accum ? pcm[q] + v : v;
+    }
+    for (int q = tid; q < CC * N; q += OG_WG) {         // history ring (N <= 960 < 1024: no wrap onto itself)
+        const int ch = q / N, i = q - ch * N;
+        st->hist[ch][(pos0 + (uint32_t)i) & 1023u] = L.v.out[ch][OG_HIST + i];
+    }
+    for (int q = tid; q < CC * 60; q += OG_WG) {
+        const int ch = q / 60, i = q - ch * 60;
+        st->overlap[ch][i] = L.v.out[ch][OG_HIST + N + i];
+    }
+    if (reset)                                          // forget the ring's older samples
+        for (int q = tid; q < CC * (1024 - N); q += OG_WG) {
+            const int ch = q / (1024 - N), i = q - ch * (1024 - N);
+            st->hist[ch][N + i] = 0.f;
+        }
+    if (tid == 0) st->pos = pos0 + (uint32_t)N;
+    OG_LANES_END
+}

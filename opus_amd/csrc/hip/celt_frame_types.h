@@ -1,0 +1,22 @@
+// Constants and table layout shared by the CELT kernel and the host code that fills its tables.
+#pragma once
+#include <stdint.h>
+
+#ifndef OG_WG
+#define OG_WG 256                     // 4 wavefronts per frame
+#endif
+#define OG_HIST 1024                  // comb filter reaches back period + 2 <= 1024 samples
+#define OG_OUTLEN (OG_HIST + 960 + 60)
+#define OG_MAXLEAF 704                // 21 bands x 2 channels x 16 partitions, rounded up
+
+struct OgCf { float r, i; };
+
+struct OgCeltTables {                 // constant tables, built once per device by og_fill_celt_tables()
+    OgCf fft_w[480];                  // e^{-2 pi i t / 480}
+    OgCf tw[900];                     // IMDCT pre/post twiddles for block sizes 120/240/480/960 at 0/60/180/420
+    float window[120];                // RFC 6716 4.3.7 power-complementary window
+    uint32_t lcg_a[184], lcg_c[184];  // seed after j LCG steps = lcg_a[j] * seed + lcg_c[j]
+    uint32_t pvq_u[1272];             // U(N,K) rows (celt/decoder.rs:293-409)
+    uint16_t pvq_row[16];             // row offsets (celt/decoder.rs:410-413)
+};
+

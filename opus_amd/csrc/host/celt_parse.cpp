@@ -54,22 +54,6 @@ uint32_t isqrt32(uint32_t v)
 inline uint32_t U(int n, int k) { return CELT_PVQ_U[CELT_PVQ_U_ROW[std::min(n, k)] + std::max(n, k)]; }   // :412, :663
 inline uint32_t V(int n, int k) { return U(n, k) + U(n, k + 1); }                                          // :666
 
-// fill-map algebra: nibble j of a map = which bit of the quant_band root fill feeds bit j (0xF: none)
-constexpr uint32_t FM_ID = 0x76543210u;
-inline uint32_t fm_keep(uint32_t m, int lo, int hi)      // keep bits [lo,hi), clear the rest
-{
-    uint32_t r = 0;
-    for (int j = 0; j < 8; j++) r |= ((j >= lo && j < hi) ? ((m >> (4 * j)) & 0xF) : 0xFu) << (4 * j);
-    return r;
-}
-inline uint32_t fm_shr(uint32_t m, int s)
-{
-    uint32_t r = 0;
-    for (int j = 0; j < 8; j++) r |= (j + s < 8 ? ((m >> (4 * (j + s))) & 0xF) : 0xFu) << (4 * j);
-    return r;
-}
-inline uint32_t fm_dup(uint32_t m) { return (m << 4) | (m & 0xF); }      // fill = (fill&1) | (fill<<1), :1784
-
 struct Theta { int itheta, inv, imid, iside, delta, qalloc; };
 
 class FrameParser {
@@ -81,13 +65,14 @@ public:
     OgCeltHdr *hdr_;
     int band_ = 0, intensity_ = 0, tf_change_ = 0, remaining_ = 0;
 
-    void emit(int off, int n, int k, int B, uint32_t index, uint32_t fmap, float gain, int cmshift, int chy, bool lowband, bool n1)
+    void emit(int off, int n, int k, int B, uint32_t index, bool dead, float gain, int cmshift, int chy, bool lowband, bool n1)
     {
         OgCeltLeaf l;
-        l.index = index; l.fillmap = fmap; l.gain = gain;
+        l.index = index; l.gain = gain;
         l.off = uint8_t(off); l.n = uint8_t(n); l.k = uint8_t(k);
-        int logb = B == 1 ? 0 : B == 2 ? 1 : B == 4 ? 2 : 3;
-        l.meta = uint8_t(logb | (cmshift << OG_L_CMSHIFT_SHIFT) | (chy ? OG_L_CH_Y : 0) | (n1 ? OG_L_N1 : 0) | (lowband ? OG_L_HAS_LOWBAND : 0));
+        l.cmshift = uint8_t(cmshift); l.band = uint8_t(band_); l.reserved = 0;
+        const int logb = 31 - __builtin_clz(unsigned(B));
+        l.meta = uint8_t(logb | (dead ? OG_L_FILL_DEAD : 0) | (chy ? OG_L_CH_Y : 0) | (n1 ? OG_L_N1 : 0) | (lowband ? OG_L_HAS_LOWBAND : 0));
         leaves_.push_back(l);
         hdr_->band[band_].nleaves++;
     }
@@ -97,11 +82,11 @@ public:
         for (int c = 0; c < (stereo ? 2 : 1); c++) {
             uint32_t sign = 0;
             if (remaining_ >= 1 << BITRES) { sign = rd_.bits(1); remaining_ -= 1 << BITRES; }
-            emit(0, 1, 0, 1, sign, FM_ID, 1.f, 0, c, false, true);
+            emit(0, 1, 0, 1, sign, false, 1.f, 0, c, false, true);
         }
     }
 
-    Theta theta(int N, int &b, int B, int B0, int LM, bool stereo, uint32_t &fmap)   // celt/decoder.rs:1497-1593
+    Theta theta(int N, int &b, int B, int B0, int LM, bool stereo)   // celt/decoder.rs:1497-1593
     {
         Theta t{0, 0, 0, 0, 0, 0};
         int pulse_cap = CELT_LOG_N[band_] + LM * (1 << BITRES);
@@ -146,8 +131,8 @@ public:
         }
         t.qalloc = rd_.tell_frac() - tell;
         b -= t.qalloc;
-        if (t.itheta == 0) { t.imid = 32767; t.iside = 0; fmap = fm_keep(fmap, 0, B); t.delta = -16384; }
-        else if (t.itheta == 16384) { t.imid = 0; t.iside = 32767; fmap = fm_keep(fmap, B, 2 * B); t.delta = 16384; }
+        if (t.itheta == 0) { t.imid = 32767; t.iside = 0; t.delta = -16384; }          // side fill dies (:1567-1571)
+        else if (t.itheta == 16384) { t.imid = 0; t.iside = 32767; t.delta = 16384; }   // mid fill dies (:1572-1577)
         else {
             t.imid = bx_cos(t.itheta);
             t.iside = bx_cos(16384 - t.itheta);
@@ -157,16 +142,16 @@ public:
     }
 
     // celt/decoder.rs:1772-1790 + :1863-1975 (split) + :1601-1663 (leaf)
-    void partition(int off, int N, int b, int B, int LM, float gain, uint32_t fmap, int cmshift, int chy, bool lowband)
+    void partition(int off, int N, int b, int B, int LM, float gain, bool dead, int cmshift, int chy, bool lowband)
     {
         const uint8_t *cache = CELT_CACHE_BITS + CELT_CACHE_INDEX[(LM + 1) * 21 + band_];
         if (LM != -1 && b > cache[cache[0]] + 12 && N > 2) {
             int B0 = B;
             N >>= 1;
             LM -= 1;
-            if (B == 1) fmap = fm_dup(fmap);
             B = (B + 1) >> 1;
-            Theta t = theta(N, b, B, B0, LM, false, fmap);
+            Theta t = theta(N, b, B, B0, LM, false);
+            const bool mid_dead = dead || t.itheta == 16384, side_dead = dead || t.itheta == 0;
             float mid = (1.f / 32768) * t.imid, side = (1.f / 32768) * t.iside;
             int delta = t.delta;
             if (B0 > 1 && (t.itheta & 0x3fff)) {
@@ -177,17 +162,16 @@ public:
             int sbits = b - mbits;
             remaining_ -= t.qalloc;
             int rebalance = remaining_;
-            uint32_t fside = fm_shr(fmap, B);
             if (mbits >= sbits) {
-                partition(off, N, mbits, B, LM, gain * mid, fmap, cmshift, chy, lowband);
+                partition(off, N, mbits, B, LM, gain * mid, mid_dead, cmshift, chy, lowband);
                 rebalance = mbits - (rebalance - remaining_);
                 if (rebalance > 3 << BITRES && t.itheta != 0) sbits += rebalance - (3 << BITRES);
-                partition(off + N, N, sbits, B, LM, gain * side, fside, cmshift + (B0 >> 1), chy, lowband);
+                partition(off + N, N, sbits, B, LM, gain * side, side_dead, cmshift + (B0 >> 1), chy, lowband);
             } else {
-                partition(off + N, N, sbits, B, LM, gain * side, fside, cmshift + (B0 >> 1), chy, lowband);
+                partition(off + N, N, sbits, B, LM, gain * side, side_dead, cmshift + (B0 >> 1), chy, lowband);
                 rebalance = sbits - (rebalance - remaining_);
                 if (rebalance > 3 << BITRES && t.itheta != 16384) mbits += rebalance - (3 << BITRES);
-                partition(off, N, mbits, B, LM, gain * mid, fmap, cmshift, chy, lowband);
+                partition(off, N, mbits, B, LM, gain * mid, mid_dead, cmshift, chy, lowband);
             }
             return;
         }
@@ -209,9 +193,9 @@ public:
         if (q != 0) {
             int K = q < 8 ? q : (8 + (q & 7)) << ((q >> 3) - 1);                 // :1627-1631
             uint32_t idx = rd_.uint(V(N, K));                                    // :670
-            emit(off, N, K, B, idx, fmap, gain, cmshift, chy, lowband, false);
+            emit(off, N, K, B, idx, dead, gain, cmshift, chy, lowband, false);
         } else {
-            emit(off, N, 0, B, 0, fmap, gain, cmshift, chy, lowband, false);     // fill path runs on the device
+            emit(off, N, 0, B, 0, dead, gain, cmshift, chy, lowband, false);     // fill path runs on the device
         }
     }
 
@@ -223,7 +207,7 @@ public:
         B >>= recombine;
         N_B <<= recombine;
         while ((N_B & 1) == 0 && tf < 0) { B <<= 1; N_B >>= 1; tf++; }
-        partition(0, N, b, B, LM, gain, FM_ID, 0, chy, lowband);
+        partition(0, N, b, B, LM, gain, false, 0, chy, lowband);
     }
 
     void quant_band_stereo(int N, int b, int B, int LM, bool lowband)       // celt/decoder.rs:1795-1862 + RFC bands.c
@@ -231,8 +215,7 @@ public:
         OgCeltBand &bd = hdr_->band[band_];
         if (N == 1) { band_n1(true); return; }
         bd.flags |= OG_B_JOINT;
-        uint32_t fmap = FM_ID;
-        Theta t = theta(N, b, B, B, LM, true, fmap);
+        Theta t = theta(N, b, B, B, LM, true);
         bd.imid = uint16_t(t.imid);
         bd.iside = uint16_t(t.iside);
         if (t.inv) bd.flags |= OG_B_INV;

@@ -1,0 +1,32 @@
+// Host-side construction of the CELT kernels' constant tables (uploaded once per device).
+#include <cmath>
+#include "celt_tables.hpp"
+#include "../rfc6716_tables.h"
+
+void og_fill_celt_tables(OgCeltTables *t)
+{
+    const double PI = 3.14159265358979323846;
+    for (int k = 0; k < 480; k++) {
+        double a = -2.0 * PI * k / 480.0;
+        t->fft_w[k].r = (float)std::cos(a);
+        t->fft_w[k].i = (float)std::sin(a);
+    }
+    for (int n4 = 60; n4 <= 480; n4 *= 2) {            // block size n2 = 2*n4, transform length N = 4*n4
+        for (int i = 0; i < n4; i++) {
+            double th = 2.0 * PI * (i + 0.125) / (4.0 * n4);
+            t->tw[n4 - 60 + i].r = (float)std::cos(th);
+            t->tw[n4 - 60 + i].i = (float)std::sin(th);
+        }
+    }
+    for (int i = 0; i < 120; i++) {                    // RFC 6716 4.3.7: sin(pi/2 sin^2(pi (i+1/2) / 2L)), L = 120
+        double s = std::sin(0.5 * PI * (i + 0.5) / 120);
+        t->window[i] = (float)std::sin(0.5 * PI * s * s);
+    }
+    t->lcg_a[0] = 1; t->lcg_c[0] = 0;                  // celt/decoder.rs:1595-1599 composed j times
+    for (int j = 0; j + 1 < 184; j++) {
+        t->lcg_a[j + 1] = 1664525u * t->lcg_a[j];
+        t->lcg_c[j + 1] = 1664525u * t->lcg_c[j] + 1013904223u;
+    }
+    for (int i = 0; i < 1272; i++) t->pvq_u[i] = CELT_PVQ_U[i];
+    for (int i = 0; i < 16; i++) t->pvq_row[i] = i < 15 ? CELT_PVQ_U_ROW[i] : 0;
+}

@@ -1,0 +1,433 @@
+// C ABI, layers 1 and 2 (include/opusgpu.h): the batch engine and the one-stream decoder on top of it.
+//
+// One opusgpu_batch owns, for `nstreams` independent streams on one GPU: a host parser per stream (what
+// `struct Dec` keeps in the reference, src/decoder.rs:16-30, minus sample buffers), per-stream
+// synthesis state in HBM, pinned side-info staging and one HIP stream.  batch_send is the host half of
+// Dec::send_packet (decoder.rs:48-127), batch_decode the device half.
+#include <hip/hip_runtime_api.h>
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <new>
+#include <thread>
+#include <vector>
+#include "stream_parser.hpp"
+#include "../hip/device_util.hpp"
+
+extern "C" int opusgpu_launch_silk(const OgSilkFrame *frames, uint32_t nframes, void *state, float *pcm,
+                                   size_t pcm_stride_floats, int channels, void *stream);
+extern "C" size_t opusgpu_sizeof_silk_state(void);
+
+namespace {
+
+template <class T>
+struct DeviceBuf {                       // grow-only device array
+    T *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t n)
+    {
+        if (n <= cap) return OPUSGPU_OK;
+        size_t want = std::max(n, cap * 2);
+        if (p) OG_HIP(hipFree(p));
+        p = nullptr; cap = 0;
+        OG_HIP(hipMalloc((void **)&p, want * sizeof(T)));
+        cap = want;
+        return OPUSGPU_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+template <class T>
+struct PinnedBuf {                       // grow-only pinned host array (H2D source)
+    T *p = nullptr;
+    size_t cap = 0, n = 0;
+    int reserve(size_t want)
+    {
+        if (want <= cap) return OPUSGPU_OK;
+        size_t c = std::max(want, cap * 2);
+        T *q = nullptr;
+        OG_HIP(hipHostMalloc((void **)&q, c * sizeof(T), hipHostMallocDefault));
+        if (p) { std::memcpy(q, p, n * sizeof(T)); (void)hipHostFree(p); }
+        p = q; cap = c;
+        return OPUSGPU_OK;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = n = 0; }
+};
+
+struct ParsedPacket {                    // one thread-local parse result
+    int rc = 0;                          // number of frames or error
+    uint32_t stream = 0;
+    OgFrameInfo fi[48];
+    size_t celt0 = 0, leaf0 = 0, silk0 = 0;   // offsets into the worker's local arrays
+    size_t ncelt = 0, nleaf = 0, nsilk = 0;
+};
+
+struct Worker {
+    std::vector<OgCeltHdr> celt;
+    std::vector<OgCeltLeaf> leaves;
+    std::vector<OgSilkFrame> silk;
+};
+
+int worker_count()
+{
+    int n = 0;
+    if (const char *e = std::getenv("OPUSGPU_THREADS")) n = std::atoi(e);
+    if (n <= 0) n = int(std::min(16u, std::max(1u, std::thread::hardware_concurrency())));
+    return std::min(n, 64);
+}
+
+}  // namespace
+
+struct opusgpu_batch {
+    int device = 0, channels = 2;
+    uint32_t nstreams = 0;
+    hipStream_t stream = nullptr;
+    std::vector<og::StreamParser> parsers;
+    std::vector<uint32_t> nsamples;
+    std::vector<uint8_t> seen;
+
+    // side-info of the last batch_send, frames ordered by round (frame index inside the packet)
+    PinnedBuf<OgCeltHdr> h_celt;
+    PinnedBuf<OgCeltLeaf> h_leaves;
+    PinnedBuf<OgSilkFrame> h_silk;
+    std::vector<uint32_t> celt_round_off, silk_round_off;   // [rounds + 1]
+
+    DeviceBuf<OgCeltHdr> d_celt;
+    DeviceBuf<OgCeltLeaf> d_leaves;
+    DeviceBuf<OgSilkFrame> d_silk;
+    OgCeltState *d_celt_state = nullptr;
+    void *d_silk_state = nullptr;
+    float *d_pcm = nullptr;
+    size_t pcm_stride = 0;
+    bool pending = false;
+
+    ~opusgpu_batch()
+    {
+        (void)hipSetDevice(device);
+        if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
+        h_celt.release(); h_leaves.release(); h_silk.release();
+        d_celt.release(); d_leaves.release(); d_silk.release();
+        if (d_celt_state) (void)hipFree(d_celt_state);
+        if (d_silk_state) (void)hipFree(d_silk_state);
+        if (d_pcm) (void)hipFree(d_pcm);
+    }
+};
+
+extern "C" {
+
+int opusgpu_batch_create(opusgpu_batch **out, uint32_t nstreams, int channels, int device)
+{
+    if (!out || nstreams == 0) return OPUSGPU_BAD_ARG;
+    if (channels > 2) return OPUSGPU_UNSUPPORTED;       // decoder.rs:170-171
+    if (channels < 1) return OPUSGPU_CONFIG_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    OG_HIP(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return OPUSGPU_BAD_ARG;
+    OG_HIP(hipSetDevice(device));
+    int rc = opusgpu_init(device);
+    if (rc) return rc;
+    opusgpu_batch *b = new (std::nothrow) opusgpu_batch;
+    if (!b) return OPUSGPU_BAD_ARG;
+    b->device = device; b->channels = channels; b->nstreams = nstreams;
+    b->parsers.reserve(nstreams);
+    for (uint32_t s = 0; s < nstreams; s++) b->parsers.emplace_back(channels);
+    b->nsamples.assign(nstreams, 0);
+    b->seen.assign(nstreams, 0);
+    b->pcm_stride = size_t(OPUSGPU_MAX_FRAME) * channels;
+    hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc((void **)&b->d_celt_state, size_t(nstreams) * sizeof(OgCeltState));
+    if (e == hipSuccess) e = hipMemsetAsync(b->d_celt_state, 0, size_t(nstreams) * sizeof(OgCeltState), b->stream);
+    if (e == hipSuccess) e = hipMalloc(&b->d_silk_state, size_t(nstreams) * opusgpu_sizeof_silk_state());
+    if (e == hipSuccess) e = hipMemsetAsync(b->d_silk_state, 0, size_t(nstreams) * opusgpu_sizeof_silk_state(), b->stream);
+    if (e == hipSuccess) e = hipMalloc((void **)&b->d_pcm, size_t(nstreams) * b->pcm_stride * sizeof(float));
+    if (e == hipSuccess) e = hipMemsetAsync(b->d_pcm, 0, size_t(nstreams) * b->pcm_stride * sizeof(float), b->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+    if (e != hipSuccess) { delete b; return og::device_fail(e, "batch_create"); }
+    *out = b;
+    return OPUSGPU_OK;
+}
+
+void opusgpu_batch_destroy(opusgpu_batch *b) { delete b; }
+
+int opusgpu_batch_send(opusgpu_batch *b, const uint8_t *const *pkts, const uint32_t *lens, const uint32_t *stream_ids,
+                       uint32_t n, int32_t *errors)
+{
+    if (!b || (n && (!pkts || !lens))) return OPUSGPU_BAD_ARG;
+    std::fill(b->seen.begin(), b->seen.end(), 0);
+    for (uint32_t i = 0; i < n; i++) {
+        uint32_t s = stream_ids ? stream_ids[i] : i;
+        if (s >= b->nstreams || b->seen[s]) return OPUSGPU_BAD_ARG;
+        b->seen[s] = 1;
+    }
+    std::fill(b->nsamples.begin(), b->nsamples.end(), 0);
+
+    // ---- parse: static partition of the packets over the workers, one stream per task
+    const int nw = std::max(1, std::min<int>(worker_count(), int(n)));
+    std::vector<Worker> workers(nw);
+    std::vector<ParsedPacket> parsed(n);
+    auto run = [&](int w) {
+        Worker &W = workers[w];
+        const uint32_t lo = uint32_t(uint64_t(n) * w / nw), hi = uint32_t(uint64_t(n) * (w + 1) / nw);
+        for (uint32_t i = lo; i < hi; i++) {
+            ParsedPacket &pp = parsed[i];
+            pp.stream = stream_ids ? stream_ids[i] : i;
+            pp.celt0 = W.celt.size(); pp.leaf0 = W.leaves.size(); pp.silk0 = W.silk.size();
+            pp.rc = b->parsers[pp.stream].parse(pkts[i], lens[i], pp.fi, W.celt, W.leaves, W.silk);
+            if (pp.rc < 0) {                            // a bad packet never poisons the batch
+                W.celt.resize(pp.celt0); W.leaves.resize(pp.leaf0); W.silk.resize(pp.silk0);
+            }
+            pp.ncelt = W.celt.size() - pp.celt0; pp.nleaf = W.leaves.size() - pp.leaf0; pp.nsilk = W.silk.size() - pp.silk0;
+        }
+    };
+    if (nw == 1) run(0);
+    else {
+        std::vector<std::thread> th;
+        for (int w = 0; w < nw; w++) th.emplace_back(run, w);
+        for (auto &t : th) t.join();
+    }
+
+    // ---- merge: leaves concatenated per worker, frames regrouped by round
+    std::vector<size_t> leaf_base(nw + 1, 0);
+    size_t tot_celt = 0, tot_silk = 0;
+    for (int w = 0; w < nw; w++) {
+        leaf_base[w + 1] = leaf_base[w] + workers[w].leaves.size();
+        tot_celt += workers[w].celt.size();
+        tot_silk += workers[w].silk.size();
+    }
+    OG_HIP(hipSetDevice(b->device));
+    int rc;
+    if ((rc = b->h_leaves.reserve(leaf_base[nw] + 1))) return rc;
+    if ((rc = b->h_celt.reserve(tot_celt + 1))) return rc;
+    if ((rc = b->h_silk.reserve(tot_silk + 1))) return rc;
+    for (int w = 0; w < nw; w++)
+        if (!workers[w].leaves.empty())
+            std::memcpy(b->h_leaves.p + leaf_base[w], workers[w].leaves.data(), workers[w].leaves.size() * sizeof(OgCeltLeaf));
+    b->h_leaves.n = leaf_base[nw];
+
+    uint32_t rounds = 0;
+    for (uint32_t i = 0; i < n; i++) if (parsed[i].rc > 0) rounds = std::max(rounds, uint32_t(parsed[i].rc));
+    std::vector<uint32_t> ccount(rounds + 1, 0), scount(rounds + 1, 0);
+    for (uint32_t i = 0; i < n; i++) {
+        const ParsedPacket &pp = parsed[i];
+        for (int f = 0; f < pp.rc; f++) { ccount[f] += pp.fi[f].has_celt; scount[f] += pp.fi[f].nsilk; }
+    }
+    b->celt_round_off.assign(rounds + 1, 0);
+    b->silk_round_off.assign(rounds + 1, 0);
+    for (uint32_t r = 0; r < rounds; r++) {
+        b->celt_round_off[r + 1] = b->celt_round_off[r] + ccount[r];
+        b->silk_round_off[r + 1] = b->silk_round_off[r] + scount[r];
+    }
+    std::vector<uint32_t> cfill(b->celt_round_off.begin(), b->celt_round_off.end()), sfill(b->silk_round_off.begin(), b->silk_round_off.end());
+    for (int w = 0; w < nw; w++) {
+        const uint32_t lo = uint32_t(uint64_t(n) * w / nw), hi = uint32_t(uint64_t(n) * (w + 1) / nw);
+        for (uint32_t i = lo; i < hi; i++) {
+            const ParsedPacket &pp = parsed[i];
+            if (errors) errors[i] = pp.rc < 0 ? pp.rc : OPUSGPU_OK;
+            uint32_t pcm_off = 0;
+            for (int f = 0; f < pp.rc; f++) {
+                const OgFrameInfo &fi = pp.fi[f];
+                uint32_t sub = 0;                       // SILK frames of one Opus frame are consecutive 20 ms pieces
+                for (uint32_t k = 0; k < fi.nsilk; k++) {
+                    OgSilkFrame sf = workers[w].silk[fi.silk_index + k];
+                    sf.stream = pp.stream;
+                    sf.pcm_off = pcm_off + sub;
+                    sub += uint32_t(sf.f_size) * (48000u / (sf.bandwidth == 0 ? 8000u : sf.bandwidth == 1 ? 12000u : 16000u));
+                    b->h_silk.p[sfill[f]++] = sf;
+                }
+                if (fi.has_celt) {
+                    OgCeltHdr hd = workers[w].celt[fi.celt_index];
+                    hd.stream = pp.stream;
+                    hd.pcm_off = pcm_off;
+                    hd.leaf_begin = uint32_t(hd.leaf_begin + leaf_base[w]);
+                    b->h_celt.p[cfill[f]++] = hd;
+                }
+                pcm_off += fi.frame_size;
+            }
+            b->nsamples[pp.stream] = pcm_off;
+        }
+    }
+    b->h_celt.n = tot_celt;
+    b->h_silk.n = tot_silk;
+    b->pending = true;
+    return OPUSGPU_OK;
+}
+
+int opusgpu_batch_decode(opusgpu_batch *b)
+{
+    if (!b) return OPUSGPU_BAD_ARG;
+    if (!b->pending) return OPUSGPU_OK;
+    OG_HIP(hipSetDevice(b->device));
+    int rc;
+    if ((rc = b->d_celt.reserve(b->h_celt.n + 1)) || (rc = b->d_leaves.reserve(b->h_leaves.n + 1)) ||
+        (rc = b->d_silk.reserve(b->h_silk.n + 1)))
+        return rc;
+    if (b->h_celt.n) OG_HIP(hipMemcpyAsync(b->d_celt.p, b->h_celt.p, b->h_celt.n * sizeof(OgCeltHdr), hipMemcpyHostToDevice, b->stream));
+    if (b->h_leaves.n) OG_HIP(hipMemcpyAsync(b->d_leaves.p, b->h_leaves.p, b->h_leaves.n * sizeof(OgCeltLeaf), hipMemcpyHostToDevice, b->stream));
+    if (b->h_silk.n) OG_HIP(hipMemcpyAsync(b->d_silk.p, b->h_silk.p, b->h_silk.n * sizeof(OgSilkFrame), hipMemcpyHostToDevice, b->stream));
+    const size_t rounds = b->celt_round_off.empty() ? 0 : b->celt_round_off.size() - 1;
+    for (size_t r = 0; r < rounds; r++) {               // frame r of every packet; a stream's frames stay in order
+        const uint32_t s0 = b->silk_round_off[r], sn = b->silk_round_off[r + 1] - s0;
+        if (sn && (rc = opusgpu_launch_silk(b->d_silk.p + s0, sn, b->d_silk_state, b->d_pcm, b->pcm_stride, b->channels, b->stream)))
+            return rc;
+        const uint32_t c0 = b->celt_round_off[r], cn = b->celt_round_off[r + 1] - c0;
+        if (cn && (rc = opusgpu_launch_celt(b->d_celt.p + c0, b->d_leaves.p, cn, 1, b->d_celt_state, b->d_pcm, b->pcm_stride,
+                                            nullptr, b->stream)))
+            return rc;
+    }
+    b->pending = false;
+    return OPUSGPU_OK;
+}
+
+int opusgpu_batch_sync(opusgpu_batch *b)
+{
+    if (!b) return OPUSGPU_BAD_ARG;
+    OG_HIP(hipSetDevice(b->device));
+    OG_HIP(hipStreamSynchronize(b->stream));
+    return OPUSGPU_OK;
+}
+
+int opusgpu_batch_pcm(opusgpu_batch *b, const float **d_pcm, size_t *stride_floats, const uint32_t **nsamples)
+{
+    if (!b) return OPUSGPU_BAD_ARG;
+    if (d_pcm) *d_pcm = b->d_pcm;
+    if (stride_floats) *stride_floats = b->pcm_stride;
+    if (nsamples) *nsamples = b->nsamples.data();
+    return OPUSGPU_OK;
+}
+
+int opusgpu_batch_read(opusgpu_batch *b, uint32_t stream, float *pcm, size_t cap_floats, size_t *nsamples)
+{
+    if (!b || stream >= b->nstreams || !pcm) return OPUSGPU_BAD_ARG;
+    const size_t n = b->nsamples[stream], fl = n * b->channels;
+    if (fl > cap_floats) return OPUSGPU_BAD_ARG;
+    OG_HIP(hipSetDevice(b->device));
+    if (fl) OG_HIP(hipMemcpyAsync(pcm, b->d_pcm + size_t(stream) * b->pcm_stride, fl * sizeof(float), hipMemcpyDeviceToHost, b->stream));
+    OG_HIP(hipStreamSynchronize(b->stream));
+    if (nsamples) *nsamples = n;
+    return OPUSGPU_OK;
+}
+
+int opusgpu_batch_flush(opusgpu_batch *b, uint32_t stream)
+{
+    if (!b || stream >= b->nstreams) return OPUSGPU_BAD_ARG;
+    b->parsers[stream].reset();                         // next frames carry the RESET flags; device state follows
+    b->nsamples[stream] = 0;
+    return OPUSGPU_OK;
+}
+
+int opusgpu_batch_sideinfo(opusgpu_batch *b, const OgCeltHdr **celt, uint32_t *ncelt, const OgCeltLeaf **leaves,
+                           uint32_t *nleaves, const OgSilkFrame **silk, uint32_t *nsilk)
+{
+    if (!b) return OPUSGPU_BAD_ARG;
+    if (celt) *celt = b->h_celt.p;
+    if (ncelt) *ncelt = uint32_t(b->h_celt.n);
+    if (leaves) *leaves = b->h_leaves.p;
+    if (nleaves) *nleaves = uint32_t(b->h_leaves.n);
+    if (silk) *silk = b->h_silk.p;
+    if (nsilk) *nsilk = uint32_t(b->h_silk.n);
+    return OPUSGPU_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------
+// Layer 1: the reference's one-stream Decoder (src/decoder.rs:16-188) = a batch of one + an output queue.
+struct opusgpu_decoder {
+    int device = 0, channels = 2;
+    bool configured = false;
+    std::vector<uint8_t> extradata;
+    opusgpu_batch *batch = nullptr;
+    std::deque<std::vector<float>> queue;
+    ~opusgpu_decoder() { delete batch; }
+};
+
+extern "C" {
+
+int opusgpu_decoder_create(opusgpu_decoder **out, int device)
+{
+    if (!out) return OPUSGPU_BAD_ARG;
+    *out = new (std::nothrow) opusgpu_decoder;
+    if (!*out) return OPUSGPU_BAD_ARG;
+    (*out)->device = device;
+    return OPUSGPU_OK;
+}
+
+void opusgpu_decoder_destroy(opusgpu_decoder *d) { delete d; }
+
+int opusgpu_decoder_set_extradata(opusgpu_decoder *d, const uint8_t *extra, size_t len)
+{
+    if (!d || (len && !extra)) return OPUSGPU_BAD_ARG;
+    d->extradata.assign(extra, extra + len);            // decoder.rs:45-47
+    return OPUSGPU_OK;
+}
+
+int opusgpu_decoder_configure(opusgpu_decoder *d)
+{
+    if (!d) return OPUSGPU_BAD_ARG;
+    int channels = 2;                                   // decoder.rs:136-145
+    const std::vector<uint8_t> &e = d->extradata;
+    if (!e.empty()) {
+        if (e.size() < 19 || std::memcmp(e.data(), "OpusHead", 8) != 0) return OPUSGPU_CONFIG_INVALID;
+        channels = e[9];
+        const int mapping_family = e[18];
+        if (channels < 1) return OPUSGPU_CONFIG_INVALID;
+        if (channels > 2 || mapping_family != 0) {
+            // decoder.rs:151-171: explicit stream maps / >2 channels end in unimplemented!(); mono/stereo with a
+            // family-0 header is everything the reference can configure
+            if (channels > 2) return OPUSGPU_UNSUPPORTED;
+            if (e.size() < size_t(21 + channels)) return OPUSGPU_CONFIG_INCOMPLETE;   // decoder.rs:167
+        }
+    }
+    delete d->batch;
+    d->batch = nullptr;
+    d->queue.clear();
+    d->channels = channels;
+    int rc = opusgpu_batch_create(&d->batch, 1, channels, d->device);
+    d->configured = rc == OPUSGPU_OK;
+    return rc;
+}
+
+int opusgpu_decoder_send_packet(opusgpu_decoder *d, const uint8_t *pkt, size_t len)
+{
+    if (!d) return OPUSGPU_BAD_ARG;
+    if (!d->configured) return OPUSGPU_CONFIG_INCOMPLETE;   // the reference unwraps None here (decoder.rs:49-50)
+    if (len > 0xFFFFFFFFu) return OPUSGPU_INVALID_DATA;
+    const uint8_t *pk[1] = {pkt};
+    uint32_t ln[1] = {uint32_t(len)};
+    int32_t err = 0;
+    int rc = opusgpu_batch_send(d->batch, pk, ln, nullptr, 1, &err);
+    if (rc) return rc;
+    if (err) return err;
+    if ((rc = opusgpu_batch_decode(d->batch))) return rc;
+    std::vector<float> out(size_t(OPUSGPU_MAX_FRAME) * d->channels);
+    size_t n = 0;
+    if ((rc = opusgpu_batch_read(d->batch, 0, out.data(), out.size(), &n))) return rc;
+    out.resize(n * d->channels);
+    d->queue.push_back(std::move(out));
+    return OPUSGPU_OK;
+}
+
+int opusgpu_decoder_receive_frame(opusgpu_decoder *d, float *pcm, size_t cap_floats, size_t *nsamples, int *channels)
+{
+    if (!d || !pcm) return OPUSGPU_BAD_ARG;
+    if (d->queue.empty()) return OPUSGPU_MORE_DATA_NEEDED;
+    std::vector<float> &f = d->queue.front();
+    if (f.size() > cap_floats) return OPUSGPU_BAD_ARG;
+    std::memcpy(pcm, f.data(), f.size() * sizeof(float));
+    if (nsamples) *nsamples = f.size() / d->channels;
+    if (channels) *channels = d->channels;
+    d->queue.pop_front();
+    return OPUSGPU_OK;
+}
+
+int opusgpu_decoder_flush(opusgpu_decoder *d)
+{
+    if (!d) return OPUSGPU_BAD_ARG;
+    d->queue.clear();
+    if (d->batch) return opusgpu_batch_flush(d->batch, 0);
+    return OPUSGPU_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,146 @@
+"""Host-side mirror of the reference decoder interface (lu-zero/opus src/decoder.rs) over the C ABI."""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi as A
+
+
+class OpusError(Exception):
+    """av_codec::error::Error as the reference uses it (InvalidData, ConfigurationInvalid, ...)."""
+
+    def __init__(self, code, where=""):
+        lib = A.load()
+        msg = lib.opusgpu_strerror(code).decode()
+        if code == A.DEVICE:
+            msg += ": " + lib.opusgpu_last_error().decode()
+        super().__init__(f"{where}: {msg}" if where else msg)
+        self.code = code
+
+
+def _chk(rc, where):
+    if rc < 0:
+        raise OpusError(rc, where)
+    return rc
+
+
+def parse_packet(pkt):
+    """Packet::from_slice (packet.rs:202-317) -> dict."""
+    p = A.Packet()
+    b = bytes(pkt)
+    _chk(A.load().opusgpu_packet_parse(b, len(b), C.byref(p)), "packet_parse")
+    return dict(mode=p.mode, bandwidth=p.bandwidth, frame_size=p.frame_size, stereo=p.stereo, code=p.code,
+                nframes=p.nframes, padding=p.padding, frames=[(p.off[i], p.len[i]) for i in range(p.nframes)])
+
+
+class Decoder:
+    """One stream: set_extradata -> configure -> (send_packet -> receive_frame)* -> flush (decoder.rs:42-188)."""
+
+    def __init__(self, device=0):
+        self._lib = A.load()
+        self._h = C.c_void_p()
+        _chk(self._lib.opusgpu_decoder_create(C.byref(self._h), device), "decoder_create")
+        self._buf = np.zeros(5760 * 2, np.float32)
+
+    def set_extradata(self, extra):
+        b = bytes(extra)
+        _chk(self._lib.opusgpu_decoder_set_extradata(self._h, b, len(b)), "set_extradata")
+
+    def configure(self):
+        _chk(self._lib.opusgpu_decoder_configure(self._h), "configure")
+
+    def send_packet(self, pkt):
+        b = bytes(pkt)
+        _chk(self._lib.opusgpu_decoder_send_packet(self._h, b, len(b)), "send_packet")
+
+    def receive_frame(self):
+        n = C.c_size_t()
+        ch = C.c_int()
+        _chk(self._lib.opusgpu_decoder_receive_frame(self._h, self._buf.ctypes.data, self._buf.size, C.byref(n), C.byref(ch)),
+             "receive_frame")
+        return self._buf[: n.value * ch.value].reshape(n.value, ch.value).copy()
+
+    def flush(self):
+        _chk(self._lib.opusgpu_decoder_flush(self._h), "flush")
+
+    def close(self):
+        if self._h:
+            self._lib.opusgpu_decoder_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class BatchDecoder:
+    """`nstreams` independent decoders on one GPU; one packet per stream per send()."""
+
+    def __init__(self, nstreams, channels=2, device=0):
+        self._lib = A.load()
+        self.nstreams, self.channels = nstreams, channels
+        self._h = C.c_void_p()
+        _chk(self._lib.opusgpu_batch_create(C.byref(self._h), nstreams, channels, device), "batch_create")
+
+    def send(self, packets, stream_ids=None):
+        """packets: list of bytes; returns per-packet error codes (0 = ok)."""
+        n = len(packets)
+        keep = [bytes(p) for p in packets]
+        arr = (C.c_char_p * n)(*keep)
+        lens = (C.c_uint32 * n)(*[len(p) for p in keep])
+        ids = (C.c_uint32 * n)(*stream_ids) if stream_ids is not None else None
+        errs = (C.c_int32 * n)()
+        _chk(self._lib.opusgpu_batch_send(self._h, arr, lens, ids, n, errs), "batch_send")
+        return list(errs)
+
+    def decode(self, sync=True):
+        _chk(self._lib.opusgpu_batch_decode(self._h), "batch_decode")
+        if sync:
+            _chk(self._lib.opusgpu_batch_sync(self._h), "batch_sync")
+
+    def sync(self):
+        _chk(self._lib.opusgpu_batch_sync(self._h), "batch_sync")
+
+    def read(self, stream):
+        buf = np.zeros(5760 * self.channels, np.float32)
+        n = C.c_size_t()
+        _chk(self._lib.opusgpu_batch_read(self._h, stream, buf.ctypes.data, buf.size, C.byref(n)), "batch_read")
+        return buf[: n.value * self.channels].reshape(n.value, self.channels).copy()
+
+    def device_pcm(self):
+        """-> (device pointer, row stride in floats, nsamples per stream as numpy array)"""
+        p = C.c_void_p()
+        stride = C.c_size_t()
+        ns = C.POINTER(C.c_uint32)()
+        _chk(self._lib.opusgpu_batch_pcm(self._h, C.byref(p), C.byref(stride), C.byref(ns)), "batch_pcm")
+        return p.value, stride.value, np.ctypeslib.as_array(ns, shape=(self.nstreams,)).copy()
+
+    def sideinfo(self):
+        """Side-info of the last send(): (celt hdr array, leaf array, silk frame array) as ctypes arrays (copies)."""
+        ce, lv, sk = C.POINTER(A.CeltHdr)(), C.POINTER(A.CeltLeaf)(), C.POINTER(A.SilkFrame)()
+        nc, nl, ns = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        _chk(self._lib.opusgpu_batch_sideinfo(self._h, C.byref(ce), C.byref(nc), C.byref(lv), C.byref(nl), C.byref(sk), C.byref(ns)),
+             "batch_sideinfo")
+
+        def take(ptr, n, T):
+            out = (T * n.value)()
+            if n.value:
+                C.memmove(out, ptr, n.value * C.sizeof(T))
+            return out
+        return take(ce, nc, A.CeltHdr), take(lv, nl, A.CeltLeaf), take(sk, ns, A.SilkFrame)
+
+    def flush(self, stream):
+        _chk(self._lib.opusgpu_batch_flush(self._h, stream), "batch_flush")
+
+    def close(self):
+        if self._h:
+            self._lib.opusgpu_batch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

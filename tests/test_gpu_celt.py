@@ -1,0 +1,161 @@
+"""GPU parity: the HIP CELT path, called through the C ABI, against the CPU oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import orc
+from gpu_util import HostParser, check_pcm
+from opus_amd import BatchDecoder, Decoder, _abi as A, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _decode_single(vid, npackets, channels=2):
+    extra, pk = orc.load_vectors(ids=[vid], max_packets=npackets)[vid]
+    if channels == 1:
+        extra = extra[:9] + b"\x01" + extra[10:]
+    d = Decoder(0)
+    d.set_extradata(extra)
+    d.configure()
+    ref = orc.Decoder(channels)
+    worst = 0.0
+    for i, p in enumerate(pk):
+        d.send_packet(p)
+        worst = max(worst, check_pcm(ref.decode(p), d.receive_frame(), f"vector {vid} packet {i}"))
+    return worst
+
+
+@pytest.mark.parametrize("vid,n", [(11, 200), (1, 400), (7, 4186)])
+def test_single_stream_vectors(vid, n):
+    """reference call order set_extradata -> configure -> send_packet -> receive_frame (decoder.rs:217-231)"""
+    _decode_single(vid, n)
+
+
+def test_single_stream_mono_output():
+    _decode_single(7, 1500, channels=1)
+    _decode_single(1, 100, channels=1)
+
+
+def test_batch_mixed_vectors():
+    """48 streams on different CELT vectors / offsets, one packet per stream per call"""
+    V = orc.load_vectors(ids=[1, 7, 11])
+    ns, steps = 48, 30
+    dec = BatchDecoder(ns, 2, 0)
+    refs = [orc.Decoder(2) for _ in range(ns)]
+    src = [V[(1, 7, 11)[s % 3]][1] for s in range(ns)]
+    start = [(37 * s) % 300 for s in range(ns)]
+    for t in range(steps):
+        pk = [src[s][start[s] + t] for s in range(ns)]
+        assert not any(dec.send(pk))
+        dec.decode()
+        for s in range(ns):
+            check_pcm(refs[s].decode(pk[s]), dec.read(s), f"stream {s} step {t}")
+
+
+def test_batch_subset_and_bad_packet():
+    """a bad packet reports its own error and leaves the other streams alone; absent streams produce nothing"""
+    V = orc.load_vectors(ids=[11], max_packets=8)[11][1]
+    dec = BatchDecoder(4, 2, 0)
+    refs = [orc.Decoder(2) for _ in range(4)]
+    errs = dec.send([V[0], b"", V[0]], stream_ids=[0, 1, 3])
+    assert errs == [0, A.INVALID_DATA, 0]
+    dec.decode()
+    check_pcm(refs[0].decode(V[0]), dec.read(0))
+    check_pcm(refs[3].decode(V[0]), dec.read(3))
+    assert dec.read(1).shape[0] == 0 and dec.read(2).shape[0] == 0
+    assert not any(dec.send([V[1], V[0]], stream_ids=[0, 1]))
+    dec.decode()
+    check_pcm(refs[0].decode(V[1]), dec.read(0))
+    check_pcm(refs[1].decode(V[0]), dec.read(1))
+
+
+def test_flush_resets_stream():
+    V = orc.load_vectors(ids=[11], max_packets=6)[11][1]
+    dec = BatchDecoder(1, 2, 0)
+    for p in V[:4]:
+        dec.send([p]); dec.decode()
+    dec.flush(0)
+    ref = orc.Decoder(2)
+    for p in V[:3]:
+        dec.send([p]); dec.decode()
+        check_pcm(ref.decode(p), dec.read(0), "after flush")
+
+
+@pytest.mark.parametrize("payload", [160, 320])
+def test_synthetic_c2(payload):
+    """BASELINE config 2 shape (CELT FB stereo 20 ms, random payloads) on 64 streams x 12 frames"""
+    ns, nf = 64, 12
+    pk = synth.celt_fb_stereo_packets(range(ns), nf, payload)
+    dec = BatchDecoder(ns, 2, 0)
+    refs = [orc.Decoder(2) for _ in range(ns)]
+    for f in range(nf):
+        assert not any(dec.send([pk[s, f].tobytes() for s in range(ns)]))
+        dec.decode()
+        for s in range(ns):
+            check_pcm(refs[s].decode(pk[s, f].tobytes()), dec.read(s), f"stream {s} frame {f}")
+
+
+def test_stage_dumps_bit_exact_pulses():
+    """raw launch (layer 3b) with stage dumps: PVQ pulse vectors and collapse masks bit-exact, normalised
+    coefficients and MDCT bins within f32 rounding of the oracle's"""
+    import torch
+    lib = A.load()
+    assert lib.opusgpu_init(0) == 0
+    cases = []
+    _, pk7 = orc.load_vectors(ids=[7])[7]
+    cases += [bytes(p) for p in pk7[::23]]
+    syn = synth.celt_fb_stereo_packets(range(6), 20, 200)
+    cases += [syn[s, f].tobytes() for s in range(6) for f in range(20)]
+    hp = HostParser(2)
+    ref = orc.Decoder(2, trace=True)
+    dev = torch.device("cuda:0")
+    state = torch.zeros(C.sizeof(A.CeltState), dtype=torch.uint8, device=dev)
+    pcm = torch.zeros(5760 * 2, dtype=torch.float32, device=dev)
+    for i, p in enumerate(cases):
+        n, nc, nl, _ = hp.parse(p)
+        assert n == 1 and nc == 1
+        refpcm = ref.decode(p)
+        t = ref.trace
+        hp.celt[0].stream = 0
+        hp.celt[0].pcm_off = 0
+        hdr = torch.frombuffer(bytearray(bytes(hp.celt)[: C.sizeof(A.CeltHdr)]), dtype=torch.uint8).to(dev)
+        leaves = torch.frombuffer(bytearray(bytes(hp.leaves)[: max(nl, 1) * 16]), dtype=torch.uint8).to(dev)
+        pulses = torch.zeros((2, 960), dtype=torch.int16, device=dev)
+        norm = torch.zeros((2, 960), dtype=torch.float32, device=dev)
+        freq = torch.zeros((2, 960), dtype=torch.float32, device=dev)
+        coll = torch.zeros((2, 21), dtype=torch.uint8, device=dev)
+        dbg = A.CeltDebug(pulses.data_ptr(), norm.data_ptr(), freq.data_ptr(), coll.data_ptr())
+        rc = lib.opusgpu_launch_celt(hdr.data_ptr(), leaves.data_ptr(), 1, 1, state.data_ptr(), pcm.data_ptr(), 5760 * 2,
+                                     C.byref(dbg), None)
+        assert rc == 0, lib.opusgpu_last_error()
+        torch.cuda.synchronize()
+        Cn = t.C
+        assert np.array_equal(pulses.cpu().numpy()[:Cn], np.ctypeslib.as_array(t.pulses)[:Cn]), f"case {i}: pulses"
+        assert np.array_equal(coll.cpu().numpy()[:Cn], np.ctypeslib.as_array(t.collapse)[:Cn]), f"case {i}: collapse masks"
+        tx = np.ctypeslib.as_array(t.X)[:Cn]
+        assert np.abs(norm.cpu().numpy()[:Cn] - tx).max() <= 1e-5, f"case {i}: normalised coefficients"
+        tf = np.ctypeslib.as_array(t.freq)
+        assert np.abs(freq.cpu().numpy() - tf).max() <= 1e-5 * max(1.0, np.abs(tf).max()), f"case {i}: MDCT bins"
+        check_pcm(refpcm, pcm.cpu().numpy()[: refpcm.size].reshape(refpcm.shape), f"case {i}: pcm")
+
+
+def test_full_size_properties():
+    """BASELINE size (4096 streams): duplicate streams decode bit-identically (stream independence, no cross-talk),
+    a sample of streams matches the oracle, and the rest are finite"""
+    import torch
+    ns, nf = 4096, 3
+    half = synth.celt_fb_stereo_packets(range(ns // 2), nf, 160)
+    dec = BatchDecoder(ns, 2, 0)
+    sample = list(range(0, ns // 2, 128))
+    refs = {s: orc.Decoder(2) for s in sample}
+    for f in range(nf):
+        pk = [half[s % (ns // 2), f].tobytes() for s in range(ns)]
+        assert not any(dec.send(pk))
+        dec.decode()
+        ptr, stride, nsamp = dec.device_pcm()
+        assert (nsamp == 960).all()
+        for s in sample:
+            a, b = dec.read(s), dec.read(s + ns // 2)
+            assert np.array_equal(a, b)
+            check_pcm(refs[s].decode(pk[s]), a, f"stream {s} frame {f}")
