@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""bench.py -- decoded audio-seconds per second on BASELINE.json config 2:
+synthetic CELT-only fullband 48 kHz stereo 20 ms frames, 4096 streams per MI355X (weak scaling over GPUs).
+
+A step = one pass of the hot path over one batch: frame t of each of the 4096 streams (one fused CELT kernel
+launch through the C ABI, layer 3b).  Inputs (side-info records, pre-parsed by the host layer) are resident in HBM
+before the timed region; PCM and decoder state stay in HBM.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+STREAMS_PER_GPU = 4096
+PAYLOAD = 160                       # bytes per 20 ms frame = 64 kb/s
+FRAME_S = 0.02
+HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+# SURVEY.md 8(d) algorithmic bytes per C2 frame: 1024 side-info + 7680 PCM + 1920 overlap r/w + ~700 energy/seed
+# = 11324, plus 7712 of post-filter history when the comb filter is active in the frame
+ALG_BYTES_BASE, ALG_BYTES_PF = 11324, 7712
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--streams", type=int, default=STREAMS_PER_GPU, help="streams per GPU (BASELINE: 4096)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(packets, budget_s=12.0):
+    """The CPU oracle (restatement of lu-zero/opus + RFC 6716 synthesis tail; the Rust crate cannot be built here),
+    one stream per thread on the host cores, on a bounded sample of the same packets."""
+    from concurrent.futures import ThreadPoolExecutor
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orc
+    cores = min(16, os.cpu_count() or 1)          # the GPU box grants 16 CPUs per GPU
+    nstreams, nframes = packets.shape[0], packets.shape[1]
+    sample_streams = min(nstreams, cores * 4)
+    orc.lib()
+
+    def work(s):
+        d = orc.Decoder(2)
+        t_end = time.perf_counter() + budget_s
+        n = 0
+        for f in range(nframes):
+            d.decode(packets[s, f].tobytes())
+            n += 1
+            if time.perf_counter() > t_end:
+                break
+        return n
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        done = list(ex.map(work, range(sample_streams)))
+    dt = time.perf_counter() - t0
+    frames = sum(done)
+    return {"value": round(frames * FRAME_S / dt, 2), "unit": "audio-s/s", "cores": cores, "kind": "port",
+            "sample": f"{sample_streams} of the same synthetic streams x {max(done)} frames ({frames} frames) on the CPU oracle "
+                      f"(oracle/liborc.so, scalar C, -O2), one stream per thread"}
+
+
+def main():
+    a = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from opus_amd import BatchDecoder, _abi as A, synth
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    lib = A.load()
+
+    S, K, W = a.streams, a.steps, a.warmup
+    nframes = K + W
+    ids = np.arange(S, dtype=np.uint64) + np.uint64(rank * S)     # streams shard across ranks, no collective
+    packets = synth.celt_fb_stereo_packets(ids, nframes, PAYLOAD)
+
+    # ---- host half (untimed here; its rate is reported separately): packets -> side-info, copied to HBM
+    parser = BatchDecoder(S, 2, local_rank)
+    hdr_dev, leaf_dev, alg_bytes, nleaves = [], [], [], []
+    t_parse = 0.0
+    for f in range(nframes):
+        pk = [packets[s, f].tobytes() for s in range(S)]
+        t0 = time.perf_counter()
+        errs = parser.send(pk)
+        t_parse += time.perf_counter() - t0
+        assert not any(errs)
+        celt, leaves, _ = parser.sideinfo()
+        assert len(celt) == S
+        hb = np.frombuffer(celt, dtype=np.uint8).reshape(S, C.sizeof(A.CeltHdr))
+        gq = hb[:, A.CeltHdr.pf_gain_q.offset:A.CeltHdr.pf_gain_q.offset + 3]
+        pf_on = (gq != 0).any(axis=1).sum()
+        alg_bytes.append(int(S * ALG_BYTES_BASE + pf_on * ALG_BYTES_PF))
+        nleaves.append(len(leaves))
+        hdr_dev.append(torch.from_numpy(hb.copy()).to(dev))
+        leaf_dev.append(torch.from_numpy(np.frombuffer(leaves, dtype=np.uint8).copy()).to(dev))
+    parser.close()
+
+    state = torch.zeros(S * C.sizeof(A.CeltState), dtype=torch.uint8, device=dev)
+    stride = 960 * 2
+    pcm = torch.zeros(S * stride, dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream(dev)
+    sp = C.c_void_p(stream.cuda_stream)
+
+    def step(f):
+        rc = lib.opusgpu_launch_celt(hdr_dev[f].data_ptr(), leaf_dev[f].data_ptr(), S, 1, state.data_ptr(), pcm.data_ptr(),
+                                     stride, None, sp)
+        if rc:
+            raise RuntimeError(lib.opusgpu_last_error().decode())
+
+    for f in range(W):
+        step(f)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for k in range(K):
+        ev[k][0].record(stream)
+        step(W + k)
+        ev[k][1].record(stream)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert bool(torch.isfinite(pcm).all())
+
+    kernel_ms = [e0.elapsed_time(e1) for e0, e1 in ev]
+    avg_kernel_s = sum(kernel_ms) / K / 1e3
+    avg_alg = sum(alg_bytes[W:]) / K
+    achieved = avg_alg / avg_kernel_s / 1e9
+    traffic = None
+    tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")      # HBM bytes per launch from a rocprofv3 --pmc pass
+    if os.path.exists(tp):
+        try:
+            traffic = json.load(open(tp)).get("og_celt_kernel_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    if rank == 0:
+        out = {
+            "metric": "decoded audio-sec/sec (48 kHz stereo CELT 20 ms, 4096 streams)",
+            "value": round(world * S * K * FRAME_S / elapsed, 1),
+            "unit": "audio-s/s",
+            "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": round(elapsed / K * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: synthetic CELT-only FB 48 kHz stereo 20 ms frames (TOC 0xFC + "
+                                   f"{PAYLOAD} random payload bytes), {S} streams per GPU, one frame per stream per step",
+                       "streams_per_gpu": S, "frame_ms": 20, "payload_bytes": PAYLOAD,
+                       "parallelism": f"streams sharded over {world} GPU(s), no collective"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "kernel": "og_celt_kernel", "avg_launch_us": round(avg_kernel_s * 1e6, 2),
+                         "algorithmic_bytes_per_launch": int(avg_alg)},
+            "host_parse": {"value": round(S * nframes * FRAME_S / t_parse, 1), "unit": "audio-s/s",
+                           "note": "packets -> side-info on the host threads (untimed in `value`)",
+                           "mean_leaves_per_frame": round(sum(nleaves) / (S * nframes), 1)},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(packets)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

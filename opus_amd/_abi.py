@@ -114,6 +114,12 @@ def load(path=None):
     if not os.path.exists(p):
         raise RuntimeError(f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    try:
+        # torch bundles its own libamdhip64.so.7; whichever HIP runtime is loaded first serves the whole process.
+        # Loading torch's first keeps one runtime when a caller also holds torch device tensors (tests, bench.py).
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(p)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)
