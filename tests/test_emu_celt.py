@@ -1,0 +1,54 @@
+"""CPU CI of the CELT kernel logic: tests/emu builds the kernel body (opus_amd/csrc/hip/celt_frame.h) with g++, lanes
+run one after the other (hip/wg.h), and the result is compared with the oracle.  A fixture for boxes without a GPU;
+the parity tests proper are tests/test_gpu_*.py, which run the hipcc-built kernel through the C ABI."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import orc
+from gpu_util import HostParser, check_pcm
+from opus_amd import _abi as A, build, synth
+
+
+@pytest.fixture(scope="module")
+def emu():
+    lib = C.CDLL(build.build_emu())
+    lib.emu_launch_celt.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    return lib
+
+
+def _run(emu, packets, channels):
+    hp = HostParser(channels)
+    ref = orc.Decoder(channels, trace=True)
+    st = A.CeltState()
+    pcm = np.zeros(5760 * channels, np.float32)
+    for i, p in enumerate(packets):
+        n, nc, nl, _ = hp.parse(p)
+        assert n > 0 and nc == n
+        r = ref.decode(p)
+        off = 0
+        for f in range(n):
+            hp.celt[f].stream = 0
+            hp.celt[f].pcm_off = off
+            off += hp.fi[f].frame_size
+        pulses = np.zeros((n, 2, 960), np.int16)
+        dbg = A.CeltDebug(pulses.ctypes.data, None, None, None)
+        emu.emu_launch_celt(hp.celt, hp.leaves, n, 1, C.byref(st), pcm.ctypes.data, 5760 * channels, C.byref(dbg))
+        check_pcm(r, pcm[: off * channels].reshape(off, channels), f"packet {i}")
+        t = ref.trace
+        assert np.array_equal(pulses[n - 1][: t.C], np.ctypeslib.as_array(t.pulses)[: t.C]), f"packet {i}: PVQ pulses"
+
+
+@pytest.mark.parametrize("vid,n,ch", [(11, 120, 2), (1, 300, 2), (7, 4186, 2), (7, 1200, 1)])
+def test_emu_vectors(emu, vid, n, ch):
+    _, pk = orc.load_vectors(ids=[vid], max_packets=n)[vid]
+    _run(emu, pk, ch)
+
+
+@pytest.mark.parametrize("payload", [160, 320])
+def test_emu_synthetic(emu, payload):
+    pk = synth.celt_fb_stereo_packets(range(6), 25, payload)
+    for s in range(6):
+        _run(emu, [pk[s, f].tobytes() for f in range(25)], 2)

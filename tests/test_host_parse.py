@@ -1,0 +1,139 @@
+"""Host layer (C++ parser behind the C ABI) against the CPU oracle: framing, side-info records, final range.
+No GPU: these call only the opusgpu_parse_* / opusgpu_packet_parse entry points."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import orc
+from gpu_util import HostParser
+from opus_amd import _abi as A, parse_packet, synth
+
+EB = [0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 20, 24, 28, 34, 40, 48, 60, 78, 100]
+
+
+def test_abi_exports_every_declared_symbol():
+    lib = A.load()
+    for name in A.PROTOTYPES:
+        assert hasattr(lib, name), name
+    # include/opusgpu.h and the ctypes mirror agree on the record layouts
+    assert lib.opusgpu_sizeof_celt_hdr() == C.sizeof(A.CeltHdr)
+    assert lib.opusgpu_sizeof_celt_leaf() == C.sizeof(A.CeltLeaf) == 16
+    assert lib.opusgpu_sizeof_celt_state() == C.sizeof(A.CeltState)
+    assert lib.opusgpu_sizeof_silk_frame() == C.sizeof(A.SilkFrame)
+    assert lib.opusgpu_strerror(A.INVALID_DATA) == b"invalid data"
+
+
+def test_header_declares_what_the_mirror_binds():
+    import os
+    import re
+    hdr = open(os.path.join(A.ROOT, "include", "opusgpu.h")).read()
+    declared = set(re.findall(r"\b(opusgpu_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == set(A.PROTOTYPES), declared ^ set(A.PROTOTYPES)
+
+
+def _toc(config, stereo, code):
+    return bytes([(config << 3) | (stereo << 2) | code])
+
+
+def test_packet_framing_codes():
+    # code 0
+    p = parse_packet(_toc(31, 1, 0) + bytes(10))
+    assert (p["mode"], p["bandwidth"], p["frame_size"], p["stereo"], p["frames"]) == (2, 4, 960, 1, [(1, 10)])
+    # code 1: two equal halves (the reference yields one chunk, packet.rs:133: RFC 6716 3.2.3 is authoritative)
+    p = parse_packet(_toc(9, 0, 1) + bytes(8))
+    assert p["frames"] == [(1, 4), (5, 4)] and p["mode"] == 0 and p["bandwidth"] == 2 and p["frame_size"] == 960
+    with pytest.raises(Exception):
+        parse_packet(_toc(9, 0, 1) + bytes(7))
+    # code 2: first length coded, 1-byte and 2-byte forms
+    p = parse_packet(_toc(13, 0, 2) + bytes([3]) + bytes(9))
+    assert p["frames"] == [(2, 3), (5, 6)] and p["mode"] == 1 and p["frame_size"] == 960
+    p = parse_packet(_toc(13, 0, 2) + bytes([252, 1]) + bytes(300))
+    assert p["frames"] == [(3, 256), (259, 44)]
+    # code 3 CBR with padding
+    p = parse_packet(_toc(16, 0, 3) + bytes([0x40 | 3, 2]) + bytes(9) + bytes(2))
+    assert p["frames"] == [(3, 3), (6, 3), (9, 3)] and p["padding"] == 2 and p["frame_size"] == 120
+    # code 3 VBR: count-1 coded lengths, last frame = remainder (the reference drops it, packet.rs:177-188)
+    p = parse_packet(_toc(16, 0, 3) + bytes([0x80 | 3, 2, 4]) + bytes(2 + 4 + 5))
+    assert p["frames"] == [(4, 2), (6, 4), (10, 5)]
+
+
+@pytest.mark.parametrize("pkt", [b"", _toc(16, 0, 3), _toc(16, 0, 3) + bytes([0]), _toc(3, 0, 3) + bytes([3]) + bytes(12),
+                                 _toc(16, 0, 2) + bytes([200]) + bytes(5), _toc(31, 0, 0) + bytes(1276)])
+def test_packet_framing_rejects_malformed(pkt):
+    """the reference panics on an empty packet (packet.rs:215-225); here every malformed packet is InvalidData"""
+    lib = A.load()
+    p = A.Packet()
+    assert lib.opusgpu_packet_parse(pkt, len(pkt), C.byref(p)) == A.INVALID_DATA
+
+
+def test_framing_matches_oracle_on_all_vectors():
+    L = orc.lib()
+    for vid, (_, pk) in orc.load_vectors().items():
+        for p in pk[:400]:
+            a = parse_packet(p)
+            o = orc.Packet()
+            assert L.orc_packet_parse(bytes(p), len(p), C.byref(o)) == 0
+            assert (a["mode"], a["bandwidth"], a["frame_size"], a["stereo"], a["code"], a["nframes"]) == (
+                o.mode, o.bandwidth, o.frame_size, o.stereo, o.code, o.nframes)
+            assert a["frames"] == [(o.off[i], o.len[i]) for i in range(o.nframes)]
+
+
+def _compare_frame(hd, leaves, fi, t):
+    assert (hd.lm, hd.start, hd.end) == (t.lm, t.start, t.end)
+    assert bool(hd.flags & A.F_TRANSIENT) == bool(t.transient) and bool(hd.flags & A.F_SILENCE) == bool(t.silence)
+    assert bool(hd.flags & A.F_ANTICOLLAPSE) == bool(t.anticollapse_on)
+    assert (hd.spread, hd.intensity, hd.seed, fi.final_range) == (t.spread, t.intensity, t.seed_in, t.seed_out)
+    assert (hd.pf_period[2], hd.pf_tapset[2], hd.pf_gain_q[2]) == (t.pf_period, t.pf_tapset, t.pf_gain_q + 1 if t.pf_on else 0)
+    for c in range(t.C):
+        assert np.array_equal(np.array(hd.energy[c][:]), np.array(t.energy[c][:]))       # bit-exact f32
+    M = 1 << t.lm
+    for i in range(t.start, t.end):
+        assert hd.band[i].tf_change == t.tf_change[i]
+        lb = t.band_lowband[i]
+        assert hd.band[i].lowband == (0xFF if lb < 0 else lb >> t.lm)
+    assert hd.nleaves == t.nleaves
+    for j in range(t.nleaves):
+        ol, l = t.leaf[j], leaves[hd.leaf_begin + j]
+        assert (l.n, l.k, l.index, bool(l.meta & A.L_CH_Y), l.off, 1 << (l.meta & A.L_LOGB_MASK), l.band,
+                bool(l.meta & A.L_N1)) == (ol.n, ol.k, ol.idx, bool(ol.ch), ol.off - M * EB[ol.band], ol.blocks, ol.band,
+                                           ol.kind == orc_LEAF_N1)
+        assert np.float32(l.gain) == np.float32(ol.gain)
+
+
+orc_LEAF_N1 = 4
+
+
+@pytest.mark.parametrize("vid,step", [(1, 3), (7, 2), (11, 1)])
+def test_celt_sideinfo_matches_oracle_trace(vid, step):
+    """every parsed symbol of the CELT frame (energies, tf, allocation-derived leaves: N, K, PVQ index, gain) and the
+    range decoder's final state equal the oracle's, on the reference's own CELT vectors"""
+    _, pk = orc.load_vectors(ids=[vid])[vid]
+    hp = HostParser(2)
+    d = orc.Decoder(2, trace=True)
+    for i, p in enumerate(pk):
+        n, nc, nl, _ = hp.parse(p)
+        d.decode(p)
+        assert n > 0 and nc == n
+        if i % step == 0:
+            _compare_frame(hp.celt[n - 1], hp.leaves, hp.fi[n - 1], d.trace)      # the trace holds the packet's last frame
+
+
+def test_celt_sideinfo_synthetic_c2():
+    pk = synth.celt_fb_stereo_packets(range(8), 30, 160)
+    for s in range(8):
+        hp = HostParser(2)
+        d = orc.Decoder(2, trace=True)
+        for f in range(30):
+            p = pk[s, f].tobytes()
+            n, nc, nl, _ = hp.parse(p)
+            d.decode(p)
+            assert n == 1
+            _compare_frame(hp.celt[0], hp.leaves, hp.fi[0], d.trace)
+
+
+def test_synth_generator_is_deterministic_per_stream():
+    a = synth.celt_fb_stereo_packets([5, 9], 3, 160)
+    b = synth.celt_fb_stereo_packets([9], 3, 160)
+    assert np.array_equal(a[1], b[0]) and not np.array_equal(a[0], a[1])
+    assert (a[:, :, 0] == 0xFC).all() and a.shape == (2, 3, 161)
