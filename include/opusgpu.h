@@ -145,6 +145,7 @@ typedef struct {               /* optional stage dumps for parity tests; any poi
     float *norm;               /* [nframes][2][960]  normalised coefficients after band decoding */
     float *freq;               /* [nframes][2][960]  denormalised MDCT coefficients */
     uint8_t *collapse;         /* [nframes][2][21]   collapse masks */
+    uint64_t *cycles;          /* [nframes][64]      shader-clock stamps: stages at 0-8, band starts at 16+i (profiling aid) */
 } OgCeltDebug;
 
 /* One-time per-device set-up of the constant tables (twiddles, window, PVQ U table). Called lazily by

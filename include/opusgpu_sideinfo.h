@@ -31,17 +31,23 @@ enum {                       /* OgCeltBand.flags */
     OG_B_DUAL = 16,          /* dual stereo: X and Y coded independently (celt/decoder.rs:2155-2193) */
     OG_B_MIDFILL0 = 32,      /* compute_theta cleared the mid's fill (itheta == 16384, celt/decoder.rs:1573) */
     OG_B_MERGE_NORM = 64,    /* dual -> intensity switch at this band: norm = (norm+norm2)/2 (:2133-2138) */
-    OG_B_LAST = 128          /* last coded band: no lowband_out (celt/decoder.rs:2143-2147) */
+    OG_B_LAST = 128,         /* last coded band: no lowband_out (celt/decoder.rs:2143-2147) */
+    OG_B_FOLD_X = 256,       /* an X-group fill leaf has a folding source: the lowband copy must be prepared */
+    OG_B_FOLD_Y = 512        /* same for the Y group (dual stereo only) */
 };
 
-typedef struct {             /* one band of one frame, 12 bytes */
+typedef struct {             /* one band of one frame, 16 bytes */
     uint16_t imid, iside;    /* Q15 cos/sin of theta (celt/decoder.rs:1564-1582) */
-    uint8_t flags;
-    uint8_t nleaves;         /* leaves of this band, in decode order */
+    uint16_t flags;
+    uint16_t leaf0;          /* the band's first leaf, relative to OgCeltHdr.leaf_begin.  The band's leaves are grouped:
+                                the nx leaves that write the X buffer, then the ny that write Y; inside each group the
+                                fill leaves (K == 0) come first.  Decode order is kept inside each run, which is all the
+                                noise generator's sequence needs (celt/decoder.rs:1595-1599; side leaves never draw). */
+    uint8_t nx, ny;          /* leaves writing X / Y */
+    uint8_t fx, fy;          /* of those, fill-path leaves (K == 0, N > 1) at the front of the group */
     uint8_t lowband;         /* effective_lowband / M, 0xFF = none (celt/decoder.rs:2088-2129) */
     int8_t tf_change;        /* celt/decoder.rs:994-1033 */
     uint8_t fold_lo, fold_hi;/* bands [fold_lo, fold_hi) whose collapse masks form the fill (:2097-2120) */
-    uint16_t leaf0;          /* index of the band's first leaf, relative to OgCeltHdr.leaf_begin */
 } OgCeltBand;
 
 enum {                       /* OgCeltLeaf.meta */

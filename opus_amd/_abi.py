@@ -13,9 +13,9 @@ L_LOGB_MASK, L_FILL_DEAD, L_CH_Y, L_N1, L_HAS_LOWBAND = 7, 8, 32, 64, 128
 
 
 class CeltBand(C.Structure):
-    _fields_ = [("imid", C.c_uint16), ("iside", C.c_uint16), ("flags", C.c_uint8), ("nleaves", C.c_uint8),
-                ("lowband", C.c_uint8), ("tf_change", C.c_int8), ("fold_lo", C.c_uint8), ("fold_hi", C.c_uint8),
-                ("leaf0", C.c_uint16)]
+    _fields_ = [("imid", C.c_uint16), ("iside", C.c_uint16), ("flags", C.c_uint16), ("leaf0", C.c_uint16),
+                ("nx", C.c_uint8), ("ny", C.c_uint8), ("fx", C.c_uint8), ("fy", C.c_uint8),
+                ("lowband", C.c_uint8), ("tf_change", C.c_int8), ("fold_lo", C.c_uint8), ("fold_hi", C.c_uint8)]
 
 
 class CeltLeaf(C.Structure):
@@ -61,7 +61,7 @@ class CeltState(C.Structure):
 
 
 class CeltDebug(C.Structure):
-    _fields_ = [("pulses", C.c_void_p), ("norm", C.c_void_p), ("freq", C.c_void_p), ("collapse", C.c_void_p)]
+    _fields_ = [("pulses", C.c_void_p), ("norm", C.c_void_p), ("freq", C.c_void_p), ("collapse", C.c_void_p), ("cycles", C.c_void_p)]
 
 
 # every symbol include/opusgpu.h declares: name -> (restype, argtypes or None)

@@ -32,26 +32,14 @@ struct OgCeltLds {
             float tmp[176];           // Hadamard reorder bounce buffer
         } b;
     } v;
-    uint16_t leaf_cm[OG_MAXLEAF];
+    OgCeltConst k;                    // LDS copy of the small constant tables
+    uint32_t band_cm[2][24];          // OR of the PVQ leaves' collapse masks per (buffer, band), filled by K1
+    OgCeltHdr hdr;                    // the frame's side-info, staged once (uniform control code reads it from LDS)
+    OgCeltLeaf leaves[OG_LDS_LEAVES];
     uint8_t collapse[2][24];
     float red[4];
     float carry[2][64];
 };
-
-#if !defined(OG_NO_TABLES)
-#ifndef RFC_TBL
-#if defined(__HIP__)
-#define RFC_TBL static __device__ const
-#else
-#define RFC_TBL static const
-#endif
-#endif
-#include "../rfc6716_tables.h"
-RFC_TBL float CELT_EMEANS[21] = {   /* RFC 6716 4.3.2 mean band energy (log2 units); not in the reference */
-    6.437500f, 6.250000f, 5.750000f, 5.312500f, 5.062500f, 4.812500f, 4.500000f, 4.375000f, 4.875000f,
-    4.687500f, 4.562500f, 4.437500f, 4.875000f, 4.625000f, 4.312500f, 4.500000f, 4.375000f, 4.625000f,
-    4.750000f, 4.437500f, 3.750000f};
-#endif
 
 OG_DEV uint32_t og_lcg(uint32_t s) { return 1664525u * s + 1013904223u; }   // celt/decoder.rs:1595-1599
 
@@ -70,6 +58,7 @@ OG_DEV uint32_t og_cwrsi(const uint32_t *U, const uint16_t *row, int n, int k, u
 {
     uint32_t yy = 0, p, q;
     int s, k0, val, cm = 0, pos = 0;
+    bool all_zero = false;
     const int nb = n / blocks;
     int bl = nb, bi = 0;
 #define OG_PUT(v)                                                                                                   \
@@ -97,13 +86,29 @@ OG_DEV uint32_t og_cwrsi(const uint32_t *U, const uint16_t *row, int n, int k, u
             i -= p;
             val = (k0 - k + s) ^ s;
             OG_PUT(val)
-        } else {                                        // lots of dimensions
-            p = og_u(U, row, k, n);
-            q = og_u(U, row, k + 1, n);
-            if (p <= i && i < q) {
-                i -= p;
-                OG_PUT(0)
-            } else {
+        } else {                                        // lots of dimensions: mostly zeros
+            if (k == 0) { all_zero = true; break; }     // every pulse placed: the rest of x stays zero
+            // Rows k and k+1 of U are contiguous in n, so a run of zeros is decoded with the table reads of four
+            // steps in flight instead of one LDS round trip per coefficient.
+            const uint32_t *Rk = U + row[k], *Rk1 = U + row[k + 1];
+            bool zero = true;
+            while (n > 2 && k < n) {
+                const uint32_t p0 = Rk[n], q0 = Rk1[n], p1 = Rk[n - 1], q1 = Rk1[n - 1];
+                const uint32_t p2 = Rk[n - 2], q2 = Rk1[n - 2], p3 = Rk[n - 3], q3 = Rk1[n - 3];
+                if (!(p0 <= i && i < q0)) { zero = false; break; }
+                i -= p0; OG_PUT(0) n--;
+                if (!(n > 2 && k < n)) break;
+                if (!(p1 <= i && i < q1)) { zero = false; break; }
+                i -= p1; OG_PUT(0) n--;
+                if (!(n > 2 && k < n)) break;
+                if (!(p2 <= i && i < q2)) { zero = false; break; }
+                i -= p2; OG_PUT(0) n--;
+                if (!(n > 2 && k < n)) break;
+                if (!(p3 <= i && i < q3)) { zero = false; break; }
+                i -= p3; OG_PUT(0) n--;
+            }
+            if (!zero) {                                // a pulse sits at this position
+                q = Rk1[n];
                 s = -(int)(i >= q);
                 i -= q & (uint32_t)s;
                 k0 = k;
@@ -111,37 +116,86 @@ OG_DEV uint32_t og_cwrsi(const uint32_t *U, const uint16_t *row, int n, int k, u
                 i -= p;
                 val = (k0 - k + s) ^ s;
                 OG_PUT(val)
+                n--;
             }
+            continue;
         }
         n--;
     }
-    p = 2 * (uint32_t)k + 1;                            // n == 2
-    s = -(int)(i >= p);
-    i -= p & (uint32_t)s;
-    k0 = k;
-    k = (int)((i + 1) >> 1);
-    if (k) i -= 2 * (uint32_t)k - 1;
-    val = (k0 - k + s) ^ s;
-    OG_PUT(val)
-    s = -(int)i;                                        // n == 1
-    val = (k + s) ^ s;
-    OG_PUT(val)
+    if (!all_zero) {
+        p = 2 * (uint32_t)k + 1;                        // n == 2
+        s = -(int)(i >= p);
+        i -= p & (uint32_t)s;
+        k0 = k;
+        k = (int)((i + 1) >> 1);
+        if (k) i -= 2 * (uint32_t)k - 1;
+        val = (k0 - k + s) ^ s;
+        OG_PUT(val)
+        s = -(int)i;                                    // n == 1
+        val = (k + s) ^ s;
+        OG_PUT(val)
+    }
 #undef OG_PUT
     *cm_out = blocks <= 1 ? 1 : cm;
     return yy;
 }
 
-OG_DEV void og_exp_rotation1(float *x, int len, int stride, float c, float s)   // RFC 6716 vq.c; celt/decoder.rs:676-692
+// RFC 6716 vq.c exp_rotation1 (celt/decoder.rs:676-692).  The reference loops walk x[i], x[i+stride] in place; the
+// `stride` residue classes are independent first-order recurrences, so each runs with its carry in a register
+// (same arithmetic, same order within a class).  Eight steps are loaded, rotated and stored at a time so that the
+// LDS latency is paid per block, not per coefficient.
+OG_DEV void og_rot_fwd(float *x, int i, int stride, int cnt, float c, float s)      // steps at i, i+stride, ...
 {
-    for (int i = 0; i < len - stride; i++) {
-        float x1 = x[i], x2 = x[i + stride];
-        x[i + stride] = c * x2 + s * x1;
-        x[i] = c * x1 - s * x2;
+    float t = x[i];
+    while (cnt >= 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = x[i + (j + 1) * stride];
+#pragma unroll
+        for (int j = 0; j < 8; j++) { const float x2 = v[j]; v[j] = c * t - s * x2; t = c * x2 + s * t; }
+#pragma unroll
+        for (int j = 0; j < 8; j++) x[i + j * stride] = v[j];
+        i += 8 * stride;
+        cnt -= 8;
     }
-    for (int i = len - 2 * stride - 1; i >= 0; i--) {
-        float x1 = x[i], x2 = x[i + stride];
-        x[i + stride] = c * x2 + s * x1;
-        x[i] = c * x1 - s * x2;
+    for (; cnt > 0; cnt--, i += stride) {
+        const float x2 = x[i + stride];
+        x[i] = c * t - s * x2;
+        t = c * x2 + s * t;
+    }
+    x[i] = t;
+}
+
+OG_DEV void og_rot_bwd(float *x, int i, int stride, int cnt, float c, float s)      // steps at i, i-stride, ...
+{
+    float u = x[i + stride];
+    while (cnt >= 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = x[i - j * stride];
+#pragma unroll
+        for (int j = 0; j < 8; j++) { const float x1 = v[j]; v[j] = c * u + s * x1; u = c * x1 - s * u; }
+#pragma unroll
+        for (int j = 0; j < 8; j++) x[i - j * stride + stride] = v[j];
+        i -= 8 * stride;
+        cnt -= 8;
+    }
+    for (; cnt > 0; cnt--, i -= stride) {
+        const float x1 = x[i];
+        x[i + stride] = c * u + s * x1;
+        u = c * x1 - s * u;
+    }
+    x[i + stride] = u;
+}
+
+OG_DEV void og_exp_rotation1(float *x, int len, int stride, float c, float s)
+{
+    for (int r = 0; r < stride && r < len - stride; r++)                 // forward: i = 0 .. len-stride-1
+        og_rot_fwd(x, r, stride, (len - stride - r + stride - 1) / stride, c, s);
+    const int top = len - 2 * stride - 1;                                // backward: i = top .. 0
+    for (int r = 0; r < stride && r <= top; r++) {
+        const int i = top - ((top - r) % stride);                        // largest i <= top with i = r (mod stride)
+        og_rot_bwd(x, i, stride, (i - r) / stride + 1, c, s);
     }
 }
 
@@ -164,6 +218,46 @@ OG_DEV void og_exp_rotation(float *x, int len, int stride, int k, int spread)   
 }
 
 // ------------------------------------------------------------------------------------------------
+// Reductions evaluated in uniform code: every lane gets the same value.  On the GPU each wavefront reduces the
+// (<= 176-element) vector on its own (lane-strided partials + xor butterfly), so no LDS scratch and no barrier.
+#if defined(__HIP__)
+#define OG_BARRIER __syncthreads();
+OG_DEV float og_wave_sum(float v)
+{
+    for (int m = 32; m; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+OG_DEV float og_uniform_sumsq(const float *x, int n)
+{
+    float e = 0.f;
+    for (int i = (int)(threadIdx.x & 63); i < n; i += 64) e += x[i] * x[i];
+    return og_wave_sum(e);
+}
+OG_DEV void og_uniform_dot2(const float *x, const float *y, int n, float *xy, float *yy)
+{
+    float a = 0.f, b = 0.f;
+    for (int i = (int)(threadIdx.x & 63); i < n; i += 64) { a += x[i] * y[i]; b += y[i] * y[i]; }
+    *xy = og_wave_sum(a);
+    *yy = og_wave_sum(b);
+}
+#else
+#define OG_BARRIER
+OG_DEV float og_uniform_sumsq(const float *x, int n)
+{
+    float e = 0.f;
+    for (int i = 0; i < n; i++) e += x[i] * x[i];
+    return e;
+}
+OG_DEV void og_uniform_dot2(const float *x, const float *y, int n, float *xy, float *yy)
+{
+    float a = 0.f, b = 0.f;
+    for (int i = 0; i < n; i++) { a += x[i] * y[i]; b += y[i] * y[i]; }
+    *xy = a;
+    *yy = b;
+}
+#endif
+
+// ------------------------------------------------------------------------------------------------
 // K2 building blocks: workgroup-collective vector operations on LDS (each ends in a barrier).
 OG_DEV void og_wg_haar1(float *x, int n0, int stride)   // celt/decoder.rs:453-466
 {
@@ -180,10 +274,10 @@ OG_DEV void og_wg_haar1(float *x, int n0, int stride)   // celt/decoder.rs:453-4
 }
 
 // celt/decoder.rs:472-538.  inverse = 0: deinterleave (frequency order -> block order), 1: interleave.
-OG_DEV void og_wg_hadamard_reorder(float *x, float *tmp, int n0, int stride, int hadamard, int inverse)
+OG_DEV void og_wg_hadamard_reorder(float *x, float *tmp, int n0, int stride, int hadamard, int inverse, const uint8_t *ordery)
 {
     const int sh = __builtin_ctz((unsigned)stride), n = n0 * stride;
-    const uint8_t *ord = CELT_HADAMARD_ORDERY + stride - 2;
+    const uint8_t *ord = ordery + stride - 2;
     OG_LANES_BEGIN(tid)
     for (int p = tid; p < n; p += OG_WG) {
         int i = p & (stride - 1), j = p >> sh;
@@ -197,30 +291,34 @@ OG_DEV void og_wg_hadamard_reorder(float *x, float *tmp, int n0, int stride, int
     OG_LANES_END
 }
 
-// x *= gain / ||x||  (celt/decoder.rs:788-794); the sum runs in the oracle's order on one lane
-OG_DEV void og_wg_renormalize(float *x, int n, float gain, float *red)
+// x *= gain / ||x||  (celt/decoder.rs:788-794)
+OG_DEV void og_wg_renormalize(float *x, int n, float gain)
 {
+    const float g = gain / sqrtf(1e-15f + og_uniform_sumsq(x, n));
+    OG_BARRIER                                          // every wave has read x before anyone scales it
     OG_LANES_BEGIN(tid)
-    if (tid == 0) {
-        float e = 1e-15f;
-        for (int i = 0; i < n; i++) e += x[i] * x[i];
-        red[0] = gain / sqrtf(e);
-    }
-    OG_LANES_END
-    OG_LANES_BEGIN(tid)
-    const float g = red[0];
     for (int p = tid; p < n; p += OG_WG) x[p] *= g;
     OG_LANES_END
 }
 
+#if defined(__HIP__)
+#define OG_STAMP_TO(buf, k) { if ((buf) && threadIdx.x == 0) (buf)[k] = (uint64_t)__builtin_readcyclecounter(); }
+#else
+#define OG_STAMP_TO(buf, k) {}
+#endif
+#define OG_STAMP(k) OG_STAMP_TO(dbg.cycles, k)
+
 struct OgBandCtx {
-    const OgCeltHdr *h;
-    const OgCeltLeaf *lv;             // the frame's leaves
+    const OgCeltHdr *h;               // staged in LDS
+    const OgCeltLeaf *lv;             // the frame's leaves in HBM (only those beyond OG_LDS_LEAVES are read from there)
     const OgCeltTables *T;
     OgCeltLds *L;
     uint32_t seed;                    // uniform across the workgroup
-    int lm;
+    int lm, band;
+    uint64_t *cycles;                 // profiling stamps (may be null)
 };
+
+OG_DEV OgCeltLeaf og_leaf(const OgBandCtx &c, int idx) { return idx < OG_LDS_LEAVES ? c.L->leaves[idx] : c.lv[idx]; }
 
 // One quant_band call (celt/decoder.rs:1665-1768 pre, :1601-1663 leaves, :1994-2032 post) on channel
 // buffer x, for the leaves of band `bd` whose OG_L_CH_Y flag equals chy.  PVQ leaves were expanded by K1.
@@ -228,14 +326,11 @@ OG_DEV int og_quant_band(OgBandCtx &c, const OgCeltBand &bd, int chy, float *x, 
                          float *lowband_out, int fill)
 {
     OgCeltLds &L = *c.L;
-    const OgCeltLeaf *lv = c.lv + bd.leaf0;
-    const int nl = bd.nleaves;
+    const int g0 = bd.leaf0 + (chy ? bd.nx : 0), nfill = chy ? bd.fy : bd.fx;     // this buffer's leaf group
     if (n == 1) {                                       // celt/decoder.rs:1466-1495
+        const float v = og_leaf(c, g0).index ? -1.f : 1.f;
         OG_LANES_BEGIN(tid)
         if (tid == 0) {
-            float v = 1.f;
-            for (int l = 0; l < nl; l++)
-                if (((lv[l].meta & OG_L_CH_Y) != 0) == (chy != 0)) v = lv[l].index ? -1.f : 1.f;
             x[0] = v;
             if (lowband_out) lowband_out[0] = v;
         }
@@ -244,10 +339,7 @@ OG_DEV int og_quant_band(OgBandCtx &c, const OgCeltBand &bd, int chy, float *x, 
     }
     const int n0 = n, long_blocks = B == 1;
     int n_b = n / B, tf_change = bd.tf_change, recombine = tf_change > 0 ? tf_change : 0, time_divide = 0;
-    bool need_lowband = false;
-    if (lowband)
-        for (int l = 0; l < nl; l++)
-            if (((lv[l].meta & OG_L_CH_Y) != 0) == (chy != 0) && lv[l].k == 0 && (lv[l].meta & OG_L_HAS_LOWBAND)) need_lowband = true;
+    const bool need_lowband = lowband && (bd.flags & (chy ? OG_B_FOLD_Y : OG_B_FOLD_X));
     float *lb = L.v.b.scratch;
     if (need_lowband) {
         OG_LANES_BEGIN(tid)
@@ -256,7 +348,7 @@ OG_DEV int og_quant_band(OgBandCtx &c, const OgCeltBand &bd, int chy, float *x, 
     }
     for (int k = 0; k < recombine; k++) {
         if (need_lowband) og_wg_haar1(lb, n >> k, 1 << k);
-        fill = CELT_BIT_INTERLEAVE[fill & 0xF] | CELT_BIT_INTERLEAVE[fill >> 4] << 2;
+        fill = L.k.bit_interleave[fill & 0xF] | L.k.bit_interleave[fill >> 4] << 2;
     }
     B >>= recombine;
     n_b <<= recombine;
@@ -269,17 +361,12 @@ OG_DEV int og_quant_band(OgBandCtx &c, const OgCeltBand &bd, int chy, float *x, 
         tf_change++;
     }
     const int B0 = B, n_b0 = n_b;
-    if (B0 > 1 && need_lowband) og_wg_hadamard_reorder(lb, L.v.b.tmp, n_b >> recombine, B0 << recombine, long_blocks, 0);
+    if (B0 > 1 && need_lowband) og_wg_hadamard_reorder(lb, L.v.b.tmp, n_b >> recombine, B0 << recombine, long_blocks, 0, L.k.hadamard);
 
-    int cm = 0;
-    for (int l = 0; l < nl; l++) {                      // leaves in decode order (the LCG seed is sequential)
-        const OgCeltLeaf lf = lv[l];
-        if (((lf.meta & OG_L_CH_Y) != 0) != (chy != 0)) continue;
+    int cm = (int)L.band_cm[chy ? 1 : 0][c.band];       // PVQ leaves: expanded (and masks collected) by K1
+    for (int l = 0; l < nfill; l++) {                   // fill leaves in decode order (the LCG seed is sequential)
+        const OgCeltLeaf lf = og_leaf(c, g0 + l);
         const int Bl = 1 << (lf.meta & OG_L_LOGB_MASK), sh = lf.cmshift;
-        if (lf.k > 0) {
-            cm |= (int)L.leaf_cm[bd.leaf0 + l] << sh;
-            continue;
-        }
         // the leaf's share of the quant_band fill: the recursion only shifts it (side halves) or clears it (theta)
         const int fl = (lf.meta & OG_L_FILL_DEAD) ? 0 : (fill >> sh) & ((1 << Bl) - 1);
         if (!fl) continue;                              // x stays zero (celt/decoder.rs:1640-1643)
@@ -306,10 +393,10 @@ OG_DEV int og_quant_band(OgBandCtx &c, const OgCeltBand &bd, int chy, float *x, 
             cm |= fl << sh;
         }
         c.seed = la[nn] * s0 + lc[nn];
-        og_wg_renormalize(xl, nn, lf.gain, L.red);
+        og_wg_renormalize(xl, nn, lf.gain);
     }
 
-    if (B0 > 1) og_wg_hadamard_reorder(x, L.v.b.tmp, n_b >> recombine, B0 << recombine, long_blocks, 1);
+    if (B0 > 1) og_wg_hadamard_reorder(x, L.v.b.tmp, n_b >> recombine, B0 << recombine, long_blocks, 1, L.k.hadamard);
     n_b = n_b0;
     B = B0;
     for (int k = 0; k < time_divide; k++) {
@@ -319,7 +406,7 @@ OG_DEV int og_quant_band(OgBandCtx &c, const OgCeltBand &bd, int chy, float *x, 
         og_wg_haar1(x, n_b, B);
     }
     for (int k = 0; k < recombine; k++) {
-        cm = CELT_BIT_DEINTERLEAVE[cm];
+        cm = L.k.bit_deinterleave[cm];
         og_wg_haar1(x, n0 >> k, 1 << k);
     }
     B <<= recombine;
@@ -340,10 +427,12 @@ OG_DEV void og_celt_bands(OgBandCtx &c)
     const int lm = c.lm, M = 1 << lm, start = h->start, end = h->end;
     const int C = (h->flags & OG_F_STEREO) ? 2 : 1;
     const int B = (h->flags & OG_F_TRANSIENT) ? M : 1;
-    const int norm_offset = M * CELT_EBANDS[start];
+    const int norm_offset = M * L.k.ebands[start];
     for (int i = start; i < end; i++) {
         const OgCeltBand bd = h->band[i];
-        const int boff = M * CELT_EBANDS[i], n = M * CELT_BAND_WIDTH[i];
+        c.band = i;
+        OG_STAMP_TO(c.cycles, 16 + i)
+        const int boff = M * L.k.ebands[i], n = M * L.k.width[i];
         const bool last = (bd.flags & OG_B_LAST) != 0;
         int x_cm, y_cm;
         if (bd.lowband != 0xFF) {
@@ -373,6 +462,7 @@ OG_DEV void og_celt_bands(OgBandCtx &c)
         } else if (C == 2) {                            // joint stereo (celt/decoder.rs:1795-1862 + RFC 6716 bands.c)
             const float mid = (1.f / 32768) * bd.imid, side = (1.f / 32768) * bd.iside;
             int cm;
+            const float inv = (bd.flags & OG_B_INV) ? -1.f : 1.f;
             if (n == 2) {
                 const int sw = (bd.flags & OG_B_N2SWAP) != 0;
                 float *x2 = sw ? y : x, *y2 = sw ? x : y;
@@ -383,51 +473,43 @@ OG_DEV void og_celt_bands(OgBandCtx &c)
                     y2[0] = -sign * x2[1];
                     y2[1] = sign * x2[0];
                     x[0] *= mid; x[1] *= mid; y[0] *= side; y[1] *= side;
-                    float t = x[0]; x[0] = t - y[0]; y[0] = t + y[0];
-                    t = x[1]; x[1] = t - y[1]; y[1] = t + y[1];
+                    float t = x[0]; x[0] = t - y[0]; y[0] = inv * (t + y[0]);
+                    t = x[1]; x[1] = t - y[1]; y[1] = inv * (t + y[1]);
                 }
                 OG_LANES_END
             } else {
                 const int fill = (bd.flags & OG_B_MIDFILL0) ? 0 : (x_cm | y_cm);
                 cm = og_quant_band(c, bd, 0, x, n, B, lb0, out0, fill);
                 cm |= og_quant_band(c, bd, 1, y, n, B, nullptr, nullptr, 0);
-                OG_LANES_BEGIN(tid)                     // stereo_merge (celt/decoder.rs:796-827)
-                if (tid == 0) {
-                    float xp = 0, sd = 0;
-                    for (int j = 0; j < n; j++) { xp += x[j] * y[j]; sd += y[j] * y[j]; }
-                    L.red[0] = xp; L.red[1] = sd;
-                }
-                OG_LANES_END
-                const float xp = L.red[0] * mid, e = mid * mid + L.red[1];
-                const float e0 = e - 2.f * xp, e1 = e + 2.f * xp;
-                if (e0 < 6e-4f || e1 < 6e-4f) {
-                    OG_LANES_BEGIN(tid)
-                    for (int p = tid; p < n; p += OG_WG) y[p] = x[p];
-                    OG_LANES_END
-                } else {
-                    const float g0 = 1.f / sqrtf(e0), g1 = 1.f / sqrtf(e1);
-                    OG_LANES_BEGIN(tid)
-                    for (int p = tid; p < n; p += OG_WG) {
+                float xp, sd;                           // stereo_merge (celt/decoder.rs:796-827)
+                og_uniform_dot2(x, y, n, &xp, &sd);
+                xp *= mid;
+                const float e = mid * mid + sd, e0 = e - 2.f * xp, e1 = e + 2.f * xp;
+                const bool degenerate = e0 < 6e-4f || e1 < 6e-4f;
+                const float g0 = degenerate ? 0.f : 1.f / sqrtf(e0), g1 = degenerate ? 0.f : 1.f / sqrtf(e1);
+                OG_BARRIER
+                OG_LANES_BEGIN(tid)
+                for (int p = tid; p < n; p += OG_WG) {
+                    if (degenerate) {
+                        y[p] = inv * x[p];
+                    } else {
                         float v0 = mid * x[p], v1 = y[p];
                         x[p] = g0 * (v0 - v1);
-                        y[p] = g1 * (v0 + v1);
+                        y[p] = inv * (g1 * (v0 + v1));
                     }
-                    OG_LANES_END
                 }
-            }
-            if (bd.flags & OG_B_INV) {
-                OG_LANES_BEGIN(tid)
-                for (int p = tid; p < n; p += OG_WG) y[p] = -y[p];
                 OG_LANES_END
             }
             x_cm = y_cm = cm;
         } else {
             x_cm = y_cm = og_quant_band(c, bd, 0, x, n, B, lb0, out0, x_cm | y_cm);
         }
-        OG_LANES_BEGIN(tid)
-        if (tid == 0) { L.collapse[0][i] = (uint8_t)x_cm; L.collapse[C - 1][i] = (uint8_t)y_cm; }
-        OG_LANES_END
+        // every lane stores the same two bytes: no barrier of its own needed (later bands read them after
+        // at least one more barrier; earlier entries are never rewritten)
+        L.collapse[0][i] = (uint8_t)x_cm;
+        L.collapse[C - 1][i] = (uint8_t)y_cm;
     }
+    OG_BARRIER
 }
 
 // RFC 6716 4.3.5 anti-collapse (bands.c); the reference only reserves its flag bit (celt/decoder.rs:1092)
@@ -438,7 +520,7 @@ OG_DEV void og_anti_collapse(OgBandCtx &c)
     const int lm = c.lm, C = (h->flags & OG_F_STEREO) ? 2 : 1;
     const uint32_t *la = c.T->lcg_a, *lc = c.T->lcg_c;
     for (int i = h->start; i < h->end; i++) {
-        const int n0 = CELT_BAND_WIDTH[i];
+        const int n0 = L.k.width[i];
         const int depth = h->pulses_depth[i];
         const float thresh = 0.5f * exp2f(-0.125f * (float)depth);
         const float sqrt_1 = 1.f / sqrtf((float)(n0 << lm));
@@ -449,7 +531,7 @@ OG_DEV void og_anti_collapse(OgBandCtx &c)
             if (lm == 3) r *= 1.41421356f;
             if (r > thresh) r = thresh;
             r *= sqrt_1;
-            float *x = L.X[ch] + (CELT_EBANDS[i] << lm);
+            float *x = L.X[ch] + (L.k.ebands[i] << lm);
             const int mask = L.collapse[ch][i];
             bool renorm = false;
             for (int k = 0; k < (1 << lm); k++) {
@@ -464,7 +546,7 @@ OG_DEV void og_anti_collapse(OgBandCtx &c)
                 c.seed = la[n0] * s0 + lc[n0];
                 renorm = true;
             }
-            if (renorm) og_wg_renormalize(x, n0 << lm, 1.f, L.red);
+            if (renorm) og_wg_renormalize(x, n0 << lm, 1.f);
         }
     }
 }
@@ -474,22 +556,30 @@ OG_DEV void og_anti_collapse(OgBandCtx &c)
 // stages ping-ponging between two LDS buffers), RFC 6716 4.3.7.
 OG_DEV OgCf og_cmul(OgCf a, OgCf b) { OgCf r; r.r = a.r * b.r - a.i * b.i; r.i = a.r * b.i + a.i * b.r; return r; }
 
-// One Stockham stage of radix R over `ntr` transforms of size n; transform t of channel c starts at
-// c*480 + t*n.  Ns = product of the radices already done.
-OG_DEV void og_wg_fft_stage(const OgCf *src, OgCf *dst, int n, int nch, int blocks, int Ns, int R, const OgCf *W)
+// floor(q / d) for the small non-negative integers used as work-item indices (q < 4096, d <= 480): exact
+OG_DEV int og_div(int q, float inv_d) { return (int)(((float)q + 0.5f) * inv_d); }
+
+// One Stockham stage of radix R over nch*blocks transforms of size n; transform b of channel ch starts at
+// ch*480 + b*n.  Ns = product of the radices already done: a power of two for R = 2, 3, 4 (stage order 4,4,2,3,5)
+// and n/5 for the final R = 5 stage, so the position inside the sub-transform never needs a division.
+template <int R>
+OG_DEV void og_wg_fft_stage(const OgCf *src, OgCf *dst, int n, int nch, int blocks, int Ns, const OgCf *W)
 {
     const int per = n / R, total = nch * blocks * per, wstep = 480 / (Ns * R);
+    const float inv_per = 1.f / (float)per;
+    const int bsh = __builtin_ctz((unsigned)blocks);
     OG_LANES_BEGIN(tid)
     for (int q = tid; q < total; q += OG_WG) {
-        const int tt = q / per, j = q - tt * per;
-        const int ch = tt / blocks, b = tt - ch * blocks;
+        const int tt = og_div(q, inv_per), j = q - tt * per;
+        const int ch = tt >> bsh, b = tt & (blocks - 1);
         const int base = ch * 480 + b * n;
-        const int k = j % Ns;
+        const int k = R == 5 ? j : (j & (Ns - 1));
         const int j0 = (j - k) * R + k;
-        OgCf v[5];
+        OgCf v[R];
+#pragma unroll
         for (int r = 0; r < R; r++) {
             v[r] = src[base + j + r * per];
-            if (r && k) v[r] = og_cmul(v[r], W[k * r * wstep]);
+            if (r) v[r] = og_cmul(v[r], W[k * r * wstep]);
         }
         OgCf *o = dst + base + j0;
         if (R == 2) {
@@ -497,14 +587,14 @@ OG_DEV void og_wg_fft_stage(const OgCf *src, OgCf *dst, int n, int nch, int bloc
             o[Ns].r = v[0].r - v[1].r; o[Ns].i = v[0].i - v[1].i;
         } else if (R == 4) {
             OgCf t0 = {v[0].r + v[2].r, v[0].i + v[2].i}, t1 = {v[0].r - v[2].r, v[0].i - v[2].i};
-            OgCf t2 = {v[1].r + v[3].r, v[1].i + v[3].i}, t3 = {v[1].i - v[3].i, v[3].r - v[1].r};   // -i (v1 - v3)
+            OgCf t2 = {v[1].r + v[3 % R].r, v[1].i + v[3 % R].i}, t3 = {v[1].i - v[3 % R].i, v[3 % R].r - v[1].r};   // -i (v1 - v3)
             o[0].r = t0.r + t2.r; o[0].i = t0.i + t2.i;
             o[Ns].r = t1.r + t3.r; o[Ns].i = t1.i + t3.i;
             o[2 * Ns].r = t0.r - t2.r; o[2 * Ns].i = t0.i - t2.i;
             o[3 * Ns].r = t1.r - t3.r; o[3 * Ns].i = t1.i - t3.i;
         } else if (R == 3) {
             const float s3 = 0.86602540378443864676f;
-            OgCf s = {v[1].r + v[2].r, v[1].i + v[2].i}, d = {v[1].r - v[2].r, v[1].i - v[2].i};
+            OgCf s = {v[1].r + v[2 % R].r, v[1].i + v[2 % R].i}, d = {v[1].r - v[2 % R].r, v[1].i - v[2 % R].i};
             OgCf m = {v[0].r - 0.5f * s.r, v[0].i - 0.5f * s.i};
             OgCf e = {s3 * d.i, -s3 * d.r};                                                          // -i s3 d
             o[0].r = v[0].r + s.r; o[0].i = v[0].i + s.i;
@@ -513,8 +603,8 @@ OG_DEV void og_wg_fft_stage(const OgCf *src, OgCf *dst, int n, int nch, int bloc
         } else {
             const float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f;
             const float s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;
-            OgCf s14 = {v[1].r + v[4].r, v[1].i + v[4].i}, d14 = {v[1].r - v[4].r, v[1].i - v[4].i};
-            OgCf s23 = {v[2].r + v[3].r, v[2].i + v[3].i}, d23 = {v[2].r - v[3].r, v[2].i - v[3].i};
+            OgCf s14 = {v[1].r + v[4 % R].r, v[1].i + v[4 % R].i}, d14 = {v[1].r - v[4 % R].r, v[1].i - v[4 % R].i};
+            OgCf s23 = {v[2 % R].r + v[3 % R].r, v[2 % R].i + v[3 % R].i}, d23 = {v[2 % R].r - v[3 % R].r, v[2 % R].i - v[3 % R].i};
             OgCf p1 = {v[0].r + c1 * s14.r + c2 * s23.r, v[0].i + c1 * s14.i + c2 * s23.i};
             OgCf p2 = {v[0].r + c2 * s14.r + c1 * s23.r, v[0].i + c2 * s14.i + c1 * s23.i};
             OgCf q1 = {s1 * d14.r + s2 * d23.r, s1 * d14.i + s2 * d23.i};
@@ -533,13 +623,13 @@ OG_DEV void og_wg_fft_stage(const OgCf *src, OgCf *dst, int n, int nch, int bloc
 // L.v.out, channel stride OG_OUTLEN.  The recursion reaches back >= 13 samples, so `step` samples are
 // independent at a time.
 OG_DEV void og_wg_comb_filter(float *y0, int nch, int T0, int T1, int n, float g0, float g1, int tap0, int tap1,
-                              const float *window)
+                              const float *window, const float (*taps)[4])
 {
     if (g0 == 0.f && g1 == 0.f) return;
     if (T0 < 15) T0 = 15;
     if (T1 < 15) T1 = 15;
-    const float g00 = g0 * CELT_POSTFILTER_TAPS[tap0][0], g01 = g0 * CELT_POSTFILTER_TAPS[tap0][1], g02 = g0 * CELT_POSTFILTER_TAPS[tap0][2];
-    const float g10 = g1 * CELT_POSTFILTER_TAPS[tap1][0], g11 = g1 * CELT_POSTFILTER_TAPS[tap1][1], g12 = g1 * CELT_POSTFILTER_TAPS[tap1][2];
+    const float g00 = g0 * taps[tap0][0], g01 = g0 * taps[tap0][1], g02 = g0 * taps[tap0][2];
+    const float g10 = g1 * taps[tap1][0], g11 = g1 * taps[tap1][1], g12 = g1 * taps[tap1][2];
     const int overlap = (g0 == g1 && T0 == T1 && tap0 == tap1) ? 0 : 120;
     const int stop = g1 == 0.f ? overlap : n;          // with g1 == 0 only the cross-fade runs
     const int lanes = OG_WG / 2;                       // lanes per channel
@@ -569,35 +659,52 @@ OG_DEV void og_wg_comb_filter(float *y0, int nch, int T0, int T1, int n, float g
 
 // ------------------------------------------------------------------------------------------------
 // The whole frame.  Uniform arguments; every lane of the workgroup calls it.
-OG_DEV void og_celt_frame(const OgCeltHdr *h, const OgCeltLeaf *leaves_base, const OgCeltTables *T, OgCeltState *states,
-                          float *pcm_base, size_t pcm_stride, OgCeltLds &L, int16_t *dbg_pulses, float *dbg_norm,
-                          float *dbg_freq, uint8_t *dbg_collapse)
+// `dbg` pointers are already offset to this frame (any may be null).
+OG_DEV void og_celt_frame(const OgCeltHdr *hg, const OgCeltLeaf *leaves_base, const OgCeltTables *T, OgCeltState *states,
+                          float *pcm_base, size_t pcm_stride, OgCeltLds &L, const OgCeltDebug &dbg)
 {
-    const OgCeltLeaf *lv = leaves_base + h->leaf_begin;
-    const int lm = h->lm, M = 1 << lm, N = 120 << lm;
-    const int C = (h->flags & OG_F_STEREO) ? 2 : 1, CC = (h->flags & OG_F_OUT_STEREO) ? 2 : 1;
-    const bool transient = (h->flags & OG_F_TRANSIENT) != 0, silence = (h->flags & OG_F_SILENCE) != 0;
-    const int nleaves = h->nleaves < OG_MAXLEAF ? h->nleaves : OG_MAXLEAF;
-    OgCeltState *st = states + h->stream;
-    const bool reset = (h->flags & OG_F_RESET) != 0;
+    int16_t *dbg_pulses = dbg.pulses;
+    float *dbg_norm = dbg.norm, *dbg_freq = dbg.freq;
+    uint8_t *dbg_collapse = dbg.collapse;
+    OG_STAMP(0)
+    const OgCeltLeaf *lv = leaves_base + hg->leaf_begin;
+    const int nleaves = hg->nleaves < OG_MAXLEAF ? hg->nleaves : OG_MAXLEAF;
 
-    // ---- phase 0: clear coefficient buffers, stage the PVQ table, map leaves to bands
+    // ---- phase 0: stage the side-info and the PVQ table in LDS, clear the coefficient buffers
     OG_LANES_BEGIN(tid)
+    {
+        const uint32_t *src = (const uint32_t *)hg;
+        uint32_t *dst = (uint32_t *)&L.hdr;
+        for (int p = tid; p < (int)(sizeof(OgCeltHdr) / 4); p += OG_WG) dst[p] = src[p];
+        const uint32_t *ls = (const uint32_t *)lv;      // leaves are 4 words
+        uint32_t *ld = (uint32_t *)L.leaves;
+        const int nst = 4 * (nleaves < OG_LDS_LEAVES ? nleaves : OG_LDS_LEAVES);
+        for (int p = tid; p < nst; p += OG_WG) ld[p] = ls[p];
+    }
+    for (int p = tid; p < (int)(sizeof(OgCeltConst) / 4); p += OG_WG) ((uint32_t *)&L.k)[p] = ((const uint32_t *)&T->k)[p];
     for (int p = tid; p < 2 * 960; p += OG_WG) (&L.X[0][0])[p] = 0.f;
     for (int p = tid; p < 2 * 800; p += OG_WG) (&L.u.norm[0][0])[p] = 0.f;
     for (int p = tid; p < 1272; p += OG_WG) L.v.b.pvq_u[p] = T->pvq_u[p];
     if (tid < 16) L.v.b.pvq_row[tid] = T->pvq_row[tid];
-    if (tid < 48) (&L.collapse[0][0])[tid] = 0;
+    if (tid < 48) { (&L.collapse[0][0])[tid] = 0; (&L.band_cm[0][0])[tid] = 0; }
     OG_LANES_END
+    const OgCeltHdr *h = &L.hdr;
+    const int lm = h->lm, M = 1 << lm, N = 120 << lm;
+    const int C = (h->flags & OG_F_STEREO) ? 2 : 1, CC = (h->flags & OG_F_OUT_STEREO) ? 2 : 1;
+    const bool transient = (h->flags & OG_F_TRANSIENT) != 0, silence = (h->flags & OG_F_SILENCE) != 0;
+    OgCeltState *st = states + h->stream;
+    const bool reset = (h->flags & OG_F_RESET) != 0;
 
+    OG_STAMP(1)
     if (!silence) {
         // ---- phase 1 (K1): one lane per PVQ leaf
+        // leaves are dealt round-robin to the wavefronts: each wave then serialises fewer divergent leaves
         OG_LANES_BEGIN(tid)
-        for (int l = tid; l < nleaves; l += OG_WG) {
-            const OgCeltLeaf lf = lv[l];
+        for (int l = (tid >> 6) + (tid & 63) * (OG_WG / 64); l < nleaves; l += OG_WG) {
+            const OgCeltLeaf lf = l < OG_LDS_LEAVES ? L.leaves[l] : lv[l];
             if (lf.k == 0 || (lf.meta & OG_L_N1)) continue;
             const int band = lf.band, ch = (lf.meta & OG_L_CH_Y) ? 1 : 0;
-            const int pos = (CELT_EBANDS[band] << lm) + lf.off;
+            const int pos = (L.k.ebands[band] << lm) + lf.off;
             const int Bl = 1 << (lf.meta & OG_L_LOGB_MASK);
             float *x = L.X[ch] + pos;
             int cm;
@@ -606,13 +713,14 @@ OG_DEV void og_celt_frame(const OgCeltHdr *h, const OgCeltLeaf *leaves_base, con
             const float g = lf.gain / sqrtf((float)yy);                      // celt/decoder.rs:766-786
             for (int i = 0; i < lf.n; i++) x[i] *= g;
             og_exp_rotation(x, lf.n, Bl, lf.k, h->spread);
-            L.leaf_cm[l] = (uint16_t)cm;
+            OG_ATOMIC_OR(&L.band_cm[ch][band], (uint32_t)cm << lf.cmshift);
         }
         OG_LANES_END
 
+        OG_STAMP(2)
         // ---- phase 2 (K2): bands in order
         OgBandCtx c;
-        c.h = h; c.lv = lv; c.T = T; c.L = &L; c.seed = h->seed; c.lm = lm;
+        c.h = h; c.lv = lv; c.T = T; c.L = &L; c.seed = h->seed; c.lm = lm; c.cycles = dbg.cycles;
         og_celt_bands(c);
         if (dbg_norm || dbg_collapse) {
             OG_LANES_BEGIN(tid)
@@ -620,26 +728,32 @@ OG_DEV void og_celt_frame(const OgCeltHdr *h, const OgCeltLeaf *leaves_base, con
             if (dbg_collapse && tid < 42) dbg_collapse[tid] = L.collapse[tid / 21][tid % 21];
             OG_LANES_END
         }
+        OG_STAMP(3)
         if (h->flags & OG_F_ANTICOLLAPSE) og_anti_collapse(c);
     }
+    OG_STAMP(4)
 
     // ---- phase 4: denormalise (RFC 6716 4.3.6) + channel up/down-mix into MDCT bins
-    OG_LANES_BEGIN(tid)
-    for (int p = tid; p < 2 * 960; p += OG_WG) {
-        const int ch = p >= 960, j = p - ch * 960;
-        float v = 0.f;
-        if (!silence && ch < C) {
-            int b = -1;                                 // band of bin j
-            const int jb = j >> lm;
-            if (jb < 100) { b = 0; while (CELT_EBANDS[b + 1] <= jb) b++; }
-            if (b >= h->start && b < h->end) {
-                float lg = h->energy[ch][b] + CELT_EMEANS[b];
-                v = L.X[ch][j] * exp2f(lg < 32.f ? lg : 32.f);
+    if (silence) {
+        OG_LANES_BEGIN(tid)
+        for (int p = tid; p < 2 * 960; p += OG_WG) (&L.X[0][0])[p] = 0.f;
+        OG_LANES_END
+    } else {
+        // bins outside [start, end) were never written and are still zero; one pass per band, no barrier between
+        // bands (disjoint bins)
+        for (int b = h->start; b < h->end; b++) {
+            const int lo = L.k.ebands[b] << lm, cnt = (int)L.k.width[b] << lm;
+            const float lg0 = h->energy[0][b] + L.k.emeans[b], lg1 = h->energy[C - 1][b] + L.k.emeans[b];
+            const float g0 = exp2f(lg0 < 32.f ? lg0 : 32.f), g1 = exp2f(lg1 < 32.f ? lg1 : 32.f);
+            OG_LANES_BEGIN_NOSYNC(tid)
+            for (int p = tid; p < C * cnt; p += OG_WG) {
+                const int ch = p >= cnt, j = lo + p - ch * cnt;
+                L.X[ch][j] *= ch ? g1 : g0;
             }
+            OG_LANES_END_NOSYNC
         }
-        L.X[ch][j] = v;
+        OG_BARRIER
     }
-    OG_LANES_END
     if (CC == 2 && C == 1) {
         OG_LANES_BEGIN(tid)
         for (int p = tid; p < 960; p += OG_WG) L.X[1][p] = L.X[0][p];
@@ -655,13 +769,15 @@ OG_DEV void og_celt_frame(const OgCeltHdr *h, const OgCeltLeaf *leaves_base, con
         OG_LANES_END
     }
 
+    OG_STAMP(5)
     // ---- phase 5 (K3): IMDCT.  B blocks of NB bins, interleaved with stride B in X.
     const int B = transient ? M : 1, NB = N / B, n4 = NB >> 1;
     const OgCf *tw = T->tw + (n4 - 60);
+    const float inv_n4 = 1.f / (float)n4;
     OgCf *bufA = &L.u.A[0][0], *bufB = (OgCf *)&L.X[0][0];
     OG_LANES_BEGIN(tid)
     for (int q = tid; q < CC * (N >> 1); q += OG_WG) {                       // pre-twiddle
-        const int ch = q / (N >> 1), r = q - ch * (N >> 1), b = r / n4, i = r - b * n4;
+        const int ch = q >= (N >> 1), r = q - ch * (N >> 1), b = og_div(r, inv_n4), i = r - b * n4;
         const float x1 = L.X[ch][(2 * i) * B + b], x2 = L.X[ch][(NB - 1 - 2 * i) * B + b];
         const OgCf w = tw[i];
         OgCf z;
@@ -680,7 +796,12 @@ OG_DEV void og_celt_frame(const OgCeltHdr *h, const OgCeltLeaf *leaves_base, con
         int Ns = 1;
         OgCf *src = bufA, *dst = bufB;
         for (int s = 0; s < ns; s++) {
-            og_wg_fft_stage(src, dst, n4, CC, B, Ns, radix[s], T->fft_w);
+            switch (radix[s]) {
+            case 4: og_wg_fft_stage<4>(src, dst, n4, CC, B, Ns, T->fft_w); break;
+            case 2: og_wg_fft_stage<2>(src, dst, n4, CC, B, Ns, T->fft_w); break;
+            case 3: og_wg_fft_stage<3>(src, dst, n4, CC, B, Ns, T->fft_w); break;
+            default: og_wg_fft_stage<5>(src, dst, n4, CC, B, Ns, T->fft_w); break;
+            }
             Ns *= radix[s];
             OgCf *t = src; src = dst; dst = t;
         }
@@ -691,7 +812,7 @@ OG_DEV void og_celt_frame(const OgCeltHdr *h, const OgCeltLeaf *leaves_base, con
             L.v.out[ch][OG_HIST + i] = reset ? 0.f : st->overlap[ch][i];
         }
         for (int q = tid; q < CC * (N >> 1); q += OG_WG) {
-            const int ch = q / (N >> 1), r = q - ch * (N >> 1), b = r / n4, k = r - b * n4;
+            const int ch = q >= (N >> 1), r = q - ch * (N >> 1), b = og_div(r, inv_n4), k = r - b * n4;
             const OgCf Z = src[ch * 480 + b * n4 + k], w = tw[k];
             const float vr = Z.r * w.r + Z.i * w.i, vi = Z.i * w.r - Z.r * w.i;
             float *D = &L.v.out[ch][OG_HIST + NB * b + 60];
@@ -702,7 +823,7 @@ OG_DEV void og_celt_frame(const OgCeltHdr *h, const OgCeltLeaf *leaves_base, con
     }
     OG_LANES_BEGIN(tid)
     for (int q = tid; q < CC * B * 60; q += OG_WG) {                         // TDAC mirror (RFC 6716 mdct.c)
-        const int ch = q / (B * 60), r = q - ch * (B * 60), b = r / 60, i = r - b * 60;
+        const int ch = q >= B * 60, r = q - ch * (B * 60), b = og_div(r, 1.f / 60.f), i = r - b * 60;
         float *o = &L.v.out[ch][OG_HIST + NB * b];
         const float x1 = o[119 - i], x2 = o[i];
         const float w1 = T->window[i], w2 = T->window[119 - i];
@@ -711,6 +832,7 @@ OG_DEV void og_celt_frame(const OgCeltHdr *h, const OgCeltLeaf *leaves_base, con
     }
     OG_LANES_END
 
+    OG_STAMP(6)
     // ---- phase 6: comb post-filter (RFC 6716 4.3.7.1); parameter sets [0] old, [1] current, [2] new
     const float pg0 = 0.09375f * h->pf_gain_q[0], pg1 = 0.09375f * h->pf_gain_q[1], pg2 = 0.09375f * h->pf_gain_q[2];
     const uint32_t pos0 = reset ? 0u : st->pos;
@@ -726,12 +848,13 @@ OG_DEV void og_celt_frame(const OgCeltHdr *h, const OgCeltLeaf *leaves_base, con
         }
         OG_LANES_END
         float *y0 = &L.v.out[0][OG_HIST];
-        og_wg_comb_filter(y0, CC, h->pf_period[0], h->pf_period[1], 120, pg0, pg1, h->pf_tapset[0], h->pf_tapset[1], T->window);
+        og_wg_comb_filter(y0, CC, h->pf_period[0], h->pf_period[1], 120, pg0, pg1, h->pf_tapset[0], h->pf_tapset[1], T->window, L.k.pf_taps);
         if (lm != 0)
             og_wg_comb_filter(y0 + 120, CC, h->pf_period[1], h->pf_period[2], N - 120, pg1, pg2, h->pf_tapset[1],
-                              h->pf_tapset[2], T->window);
+                              h->pf_tapset[2], T->window, L.k.pf_taps);
     }
 
+    OG_STAMP(7)
     // ---- phase 7: de-emphasis t[j] = y[j] + 0.85 t[j-1] as a blocked scan (60 lanes x N/60 samples per channel),
     //      then coalesced PCM + state write-back
     const float coef = 0.85000610f;
@@ -783,4 +906,5 @@ OG_DEV void og_celt_frame(const OgCeltHdr *h, const OgCeltLeaf *leaves_base, con
         }
     if (tid == 0) st->pos = pos0 + (uint32_t)N;
     OG_LANES_END
+    OG_STAMP(8)
 }

@@ -8,8 +8,18 @@
 #define OG_HIST 1024                  // comb filter reaches back period + 2 <= 1024 samples
 #define OG_OUTLEN (OG_HIST + 960 + 60)
 #define OG_MAXLEAF 704                // 21 bands x 2 channels x 16 partitions, rounded up
+#define OG_LDS_LEAVES 224             // leaves staged in LDS per frame (C2 frames carry 65-160); the rest stay in HBM
 
 struct OgCf { float r, i; };
+
+struct OgCeltConst {                  // small RFC 6716 tables the band walk indexes with uniform indices: kept in LDS
+    float emeans[24];                 // 4.3.2 mean band energies (log2)
+    float pf_taps[3][4];              // celt/decoder.rs:90-94
+    uint8_t ebands[24];               // celt/decoder.rs:281-283 band edges (units of 2.5 ms bins)
+    uint8_t width[24];
+    uint8_t bit_interleave[16], bit_deinterleave[16];   // celt/decoder.rs:1700-1706
+    uint8_t hadamard[32];             // celt/decoder.rs:468-470 ordery tables for strides 2,4,8,16
+};
 
 struct OgCeltTables {                 // constant tables, built once per device by og_fill_celt_tables()
     OgCf fft_w[480];                  // e^{-2 pi i t / 480}
@@ -18,5 +28,6 @@ struct OgCeltTables {                 // constant tables, built once per device 
     uint32_t lcg_a[184], lcg_c[184];  // seed after j LCG steps = lcg_a[j] * seed + lcg_c[j]
     uint32_t pvq_u[1272];             // U(N,K) rows (celt/decoder.rs:293-409)
     uint16_t pvq_row[16];             // row offsets (celt/decoder.rs:410-413)
+    OgCeltConst k;
 };
 

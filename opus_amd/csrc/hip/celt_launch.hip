@@ -6,7 +6,7 @@
 #include "../host/celt_tables.hpp"
 #include "device_util.hpp"
 
-__global__ __launch_bounds__(OG_WG) void og_celt_kernel(const OgCeltHdr *__restrict__ hdr, const OgCeltLeaf *__restrict__ leaves,
+__global__ __launch_bounds__(OG_WG, 4) void og_celt_kernel(const OgCeltHdr *__restrict__ hdr, const OgCeltLeaf *__restrict__ leaves,
                                                         uint32_t nframes, uint32_t frames_per_group,
                                                         const OgCeltTables *__restrict__ T, OgCeltState *state, float *pcm,
                                                         size_t pcm_stride, OgCeltDebug dbg)
@@ -16,9 +16,13 @@ __global__ __launch_bounds__(OG_WG) void og_celt_kernel(const OgCeltHdr *__restr
     for (uint32_t t = 0; t < frames_per_group; t++) {
         const uint32_t f = f0 + t;
         if (f >= nframes) break;
-        og_celt_frame(hdr + f, leaves, T, state, pcm, pcm_stride, L,
-                      dbg.pulses ? dbg.pulses + (size_t)f * 1920 : nullptr, dbg.norm ? dbg.norm + (size_t)f * 1920 : nullptr,
-                      dbg.freq ? dbg.freq + (size_t)f * 1920 : nullptr, dbg.collapse ? dbg.collapse + (size_t)f * 42 : nullptr);
+        OgCeltDebug d;
+        d.pulses = dbg.pulses ? dbg.pulses + (size_t)f * 1920 : nullptr;
+        d.norm = dbg.norm ? dbg.norm + (size_t)f * 1920 : nullptr;
+        d.freq = dbg.freq ? dbg.freq + (size_t)f * 1920 : nullptr;
+        d.collapse = dbg.collapse ? dbg.collapse + (size_t)f * 42 : nullptr;
+        d.cycles = dbg.cycles ? dbg.cycles + (size_t)f * 64 : nullptr;
+        og_celt_frame(hdr + f, leaves, T, state, pcm, pcm_stride, L, d);
         __syncthreads();                                // frame t's state stores before frame t+1's loads
     }
 }
@@ -79,7 +83,7 @@ int opusgpu_launch_celt(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, uint32_t
     const OgCeltTables *T;
     int rc = og::celt_tables_for_device(device, &T);
     if (rc) return rc;
-    OgCeltDebug dbg = {nullptr, nullptr, nullptr, nullptr};
+    OgCeltDebug dbg = {nullptr, nullptr, nullptr, nullptr, nullptr};
     if (debug) dbg = *debug;
     const uint32_t groups = (nframes + frames_per_group - 1) / frames_per_group;
     hipLaunchKernelGGL(og_celt_kernel, dim3(groups), dim3(OG_WG), 0, (hipStream_t)stream, hdr, leaves, nframes,

@@ -17,9 +17,15 @@
 #define OG_DEV __device__ __forceinline__
 #define OG_LANES_BEGIN(tid) { const int tid = (int)threadIdx.x; {
 #define OG_LANES_END } } __syncthreads();
+#define OG_ATOMIC_OR(p, v) atomicOr((p), (v))
+#define OG_LANES_BEGIN_NOSYNC(tid) { const int tid = (int)threadIdx.x; {
+#define OG_LANES_END_NOSYNC } }           /* regions that touch disjoint data; an explicit OG_BARRIER follows the batch */
 #else
 #include <math.h>
 #define OG_DEV static inline
 #define OG_LANES_BEGIN(tid) for (int tid = 0; tid < OG_WG; tid++) { {
 #define OG_LANES_END } }
+#define OG_ATOMIC_OR(p, v) (*(p) |= (v))
+#define OG_LANES_BEGIN_NOSYNC(tid) for (int tid = 0; tid < OG_WG; tid++) { {
+#define OG_LANES_END_NOSYNC } }
 #endif

@@ -74,7 +74,6 @@ public:
         const int logb = 31 - __builtin_clz(unsigned(B));
         l.meta = uint8_t(logb | (dead ? OG_L_FILL_DEAD : 0) | (chy ? OG_L_CH_Y : 0) | (n1 ? OG_L_N1 : 0) | (lowband ? OG_L_HAS_LOWBAND : 0));
         leaves_.push_back(l);
-        hdr_->band[band_].nleaves++;
     }
 
     void band_n1(bool stereo)                                  // celt/decoder.rs:1466-1495
@@ -551,6 +550,22 @@ int celt_parse_frame(CeltHostState &st, RangeDec &rd, int N, int start, int end,
                 fp.quant_band_stereo(n, b, B, LM, lowband);
             } else {
                 fp.quant_band(n, b, B, LM, 1.f, 0, lowband);
+            }
+            {   // group the band's leaves for the device walk: X then Y, fill leaves first, decode order inside runs
+                OgCeltLeaf *first = leaves.data() + hdr->leaf_begin + bd.leaf0, *last = leaves.data() + leaves.size();
+                auto key = [](const OgCeltLeaf &l) {
+                    const bool fillleaf = l.k == 0 && !(l.meta & OG_L_N1);
+                    return ((l.meta & OG_L_CH_Y) ? 2 : 0) + (fillleaf ? 0 : 1);
+                };
+                std::stable_sort(first, last, [&](const OgCeltLeaf &a, const OgCeltLeaf &c) { return key(a) < key(c); });
+                int cnt[4] = {0, 0, 0, 0};
+                for (OgCeltLeaf *l = first; l != last; ++l) {
+                    cnt[key(*l)]++;
+                    if (key(*l) == 0 && (l->meta & OG_L_HAS_LOWBAND)) bd.flags |= OG_B_FOLD_X;
+                    if (key(*l) == 2 && (l->meta & OG_L_HAS_LOWBAND)) bd.flags |= OG_B_FOLD_Y;
+                }
+                bd.fx = uint8_t(cnt[0]); bd.nx = uint8_t(cnt[0] + cnt[1]);
+                bd.fy = uint8_t(cnt[2]); bd.ny = uint8_t(cnt[2] + cnt[3]);
             }
             balance += pulses[i] + tellf;
             update_lowband = b > (n << BITRES);

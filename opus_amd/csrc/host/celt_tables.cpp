@@ -27,6 +27,15 @@ void og_fill_celt_tables(OgCeltTables *t)
         t->lcg_a[j + 1] = 1664525u * t->lcg_a[j];
         t->lcg_c[j + 1] = 1664525u * t->lcg_c[j] + 1013904223u;
     }
+    static const float emeans[21] = {   // RFC 6716 4.3.2 (quant_bands.c eMeans); not in the reference
+        6.437500f, 6.250000f, 5.750000f, 5.312500f, 5.062500f, 4.812500f, 4.500000f, 4.375000f, 4.875000f,
+        4.687500f, 4.562500f, 4.437500f, 4.875000f, 4.625000f, 4.312500f, 4.500000f, 4.375000f, 4.625000f,
+        4.750000f, 4.437500f, 3.750000f};
+    OgCeltConst &k = t->k;
+    for (int i = 0; i < 24; i++) { k.emeans[i] = i < 21 ? emeans[i] : 0.f; k.ebands[i] = i < 22 ? CELT_EBANDS[i] : 0; k.width[i] = i < 21 ? CELT_BAND_WIDTH[i] : 0; }
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 4; j++) k.pf_taps[i][j] = j < 3 ? CELT_POSTFILTER_TAPS[i][j] : 0.f;
+    for (int i = 0; i < 16; i++) { k.bit_interleave[i] = CELT_BIT_INTERLEAVE[i]; k.bit_deinterleave[i] = CELT_BIT_DEINTERLEAVE[i]; }
+    for (int i = 0; i < 32; i++) k.hadamard[i] = i < 30 ? CELT_HADAMARD_ORDERY[i] : 0;
     for (int i = 0; i < 1272; i++) t->pvq_u[i] = CELT_PVQ_U[i];
     for (int i = 0; i < 16; i++) t->pvq_row[i] = i < 15 ? CELT_PVQ_U_ROW[i] : 0;
 }

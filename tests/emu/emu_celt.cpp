@@ -16,11 +16,14 @@ extern "C" int emu_launch_celt(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, u
     (void)frames_per_group;
     for (uint32_t f = 0; f < nframes; f++) {
         std::memset(&L, 0xA5, sizeof L);               // LDS starts undefined on the device
-        og_celt_frame(hdr + f, leaves, &T, state, pcm, pcm_stride, L,
-                      dbg && dbg->pulses ? dbg->pulses + (size_t)f * 1920 : nullptr,
-                      dbg && dbg->norm ? dbg->norm + (size_t)f * 1920 : nullptr,
-                      dbg && dbg->freq ? dbg->freq + (size_t)f * 1920 : nullptr,
-                      dbg && dbg->collapse ? dbg->collapse + (size_t)f * 42 : nullptr);
+        OgCeltDebug d = {nullptr, nullptr, nullptr, nullptr, nullptr};
+        if (dbg) {
+            d.pulses = dbg->pulses ? dbg->pulses + (size_t)f * 1920 : nullptr;
+            d.norm = dbg->norm ? dbg->norm + (size_t)f * 1920 : nullptr;
+            d.freq = dbg->freq ? dbg->freq + (size_t)f * 1920 : nullptr;
+            d.collapse = dbg->collapse ? dbg->collapse + (size_t)f * 42 : nullptr;
+        }
+        og_celt_frame(hdr + f, leaves, &T, state, pcm, pcm_stride, L, d);
     }
     return 0;
 }

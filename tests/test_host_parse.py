@@ -93,12 +93,21 @@ def _compare_frame(hd, leaves, fi, t):
         lb = t.band_lowband[i]
         assert hd.band[i].lowband == (0xFF if lb < 0 else lb >> t.lm)
     assert hd.nleaves == t.nleaves
-    for j in range(t.nleaves):
-        ol, l = t.leaf[j], leaves[hd.leaf_begin + j]
+    # the host groups each band's leaves (X buffer then Y, fill leaves first, decode order inside each run)
+    want = sorted((t.leaf[j] for j in range(t.nleaves)),
+                  key=lambda ol: (ol.band, 2 * bool(ol.ch) + (0 if (ol.k == 0 and ol.kind != orc_LEAF_N1) else 1)))
+    for j, ol in enumerate(want):
+        l = leaves[hd.leaf_begin + j]
         assert (l.n, l.k, l.index, bool(l.meta & A.L_CH_Y), l.off, 1 << (l.meta & A.L_LOGB_MASK), l.band,
                 bool(l.meta & A.L_N1)) == (ol.n, ol.k, ol.idx, bool(ol.ch), ol.off - M * EB[ol.band], ol.blocks, ol.band,
                                            ol.kind == orc_LEAF_N1)
         assert np.float32(l.gain) == np.float32(ol.gain)
+    for i in range(t.start, t.end):
+        bd = hd.band[i]
+        grp = [l for l in want if l.band == i]
+        assert bd.nx + bd.ny == len(grp) and bd.nx == sum(1 for l in grp if not l.ch)
+        assert bd.fx == sum(1 for l in grp if not l.ch and l.k == 0 and l.kind != orc_LEAF_N1)
+        assert bd.fy == sum(1 for l in grp if l.ch and l.k == 0 and l.kind != orc_LEAF_N1)
 
 
 orc_LEAF_N1 = 4

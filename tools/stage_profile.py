@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Per-stage shader-clock profile of the fused CELT kernel on the C2 workload (diagnostic; uses OgCeltDebug.cycles)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from opus_amd import BatchDecoder, _abi as A, synth  # noqa: E402
+
+S = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+NF = 6
+lib = A.load()
+dev = torch.device("cuda:0")
+pk = synth.celt_fb_stereo_packets(range(S), NF, 160)
+parser = BatchDecoder(S, 2, 0)
+state = torch.zeros(S * C.sizeof(A.CeltState), dtype=torch.uint8, device=dev)
+pcm = torch.zeros(S * 1920, dtype=torch.float32, device=dev)
+names = ["init", "pvq", "bands", "anticollapse", "denorm", "imdct", "postfilter", "deemph+store"]
+tot = np.zeros(8)
+for f in range(NF):
+    assert not any(parser.send([pk[s, f].tobytes() for s in range(S)]))
+    celt, leaves, _ = parser.sideinfo()
+    hdr = torch.from_numpy(np.frombuffer(celt, dtype=np.uint8).copy()).to(dev)
+    lv = torch.from_numpy(np.frombuffer(leaves, dtype=np.uint8).copy()).to(dev)
+    cyc = torch.zeros((S, 64), dtype=torch.int64, device=dev)
+    dbg = A.CeltDebug(None, None, None, None, cyc.data_ptr())
+    rc = lib.opusgpu_launch_celt(hdr.data_ptr(), lv.data_ptr(), S, 1, state.data_ptr(), pcm.data_ptr(), 1920, C.byref(dbg), None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    c = cyc.cpu().numpy()
+    if f >= 1:
+        d = np.diff(c[:, :9], axis=1).astype(np.float64)
+        # stamps 2/3 are skipped on silent frames; ignore rows with non-monotonic stamps
+        ok = (d >= 0).all(axis=1)
+        tot += d[ok].mean(axis=0)
+        bb = np.concatenate([c[:, 16:37], c[:, 3:4]], axis=1)          # band starts + end of band phase
+        bd = np.diff(bb, axis=1).astype(np.float64)
+        okb = ok & (bd >= 0).all(axis=1)
+        band_tot = band_tot + bd[okb].mean(axis=0) if "band_tot" in dir() else bd[okb].mean(axis=0)
+        span = c[:, 8].max() - c[:, 0].min()
+for n, v in zip(names, tot / (NF - 1)):
+    print(f"{n:14s} {v:12.0f} clk  {100 * v / tot.sum() * (NF - 1):5.1f}%")
+print("mean per-frame total", tot.sum() / (NF - 1), "clk; launch span (last frame)", span, "clk")
+print("per-band mean clk:", " ".join(f"{v:.0f}" for v in band_tot / (NF - 1)))
