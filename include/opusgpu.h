@@ -160,6 +160,16 @@ int opusgpu_launch_celt(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, uint32_t
                         uint32_t frames_per_group, OgCeltState *state, float *pcm, size_t pcm_stride_floats,
                         const OgCeltDebug *debug /* host struct, may be NULL */, void *stream);
 
+/* SILK: K4 LTP + LPC synthesis with one lane per (stream, channel) over struct-of-arrays state (replaces
+ * silk/decoder.rs:1775-1898), then K5 + K6: stereo unmix / mono copy (silk/decoder.rs:2012-2061, :2104-2113) and the
+ * internal-rate -> 48 kHz resampler the reference lacks, writing interleaved PCM at OgSilkFrame.pcm_off.
+ * `state` = opusgpu_silk_state_bytes(nstreams) bytes of zero-initialised device memory, layout private to the
+ * kernels.  A stream may appear at most once per launch (its frames are sequential in time). */
+size_t opusgpu_silk_state_bytes(uint32_t nstreams);
+int opusgpu_launch_silk(const OgSilkFrame *frames, uint32_t nframes, void *state, uint32_t nstreams, float *pcm,
+                        size_t pcm_stride_floats, float *debug_internal /* [nframes][2][320] internal-rate L/R, or NULL */,
+                        void *stream);
+
 /* Bytes of OgCeltState[] / PCM a caller must provide are sizeof-derived; helpers for FFI users: */
 size_t opusgpu_sizeof_celt_state(void);
 size_t opusgpu_sizeof_celt_hdr(void);

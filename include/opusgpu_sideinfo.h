@@ -116,11 +116,19 @@ typedef struct {             /* one 10/20 ms SILK frame of one channel (mid or s
     int32_t excitation[320]; /* pre-division integer ex (silk/decoder.rs:1626-1634); f32 = ex / 2^23 */
 } OgSilkChan;
 
+enum {                       /* OgSilkFrame.flags */
+    OG_SF_STEREO = 1,        /* packet codes mid + side (silk/decoder.rs:1946) */
+    OG_SF_STEREO_OUT = 2,    /* stream has two output channels (silk/decoder.rs:1916) */
+    OG_SF_MID_ONLY = 4,      /* side not coded in this frame (silk/decoder.rs:2005-2009) */
+    OG_SF_RESAMPLER_RESET = 8/* clear the 48 kHz resampler history first (stream start / after a CELT-only packet) */
+};
+
 typedef struct {             /* one SILK frame (mid + side) of one stream */
-    uint8_t flags;           /* bit0 stereo packet, bit1 stereo out, bit2 mid-only, bit3 reset stereo state */
+    uint8_t flags;
     uint8_t bandwidth;       /* 0 NB 1 MB 2 WB */
     uint16_t f_size;         /* samples per frame at the internal rate */
     float w0, w1;            /* stereo weights (silk/decoder.rs:2000-2001) */
+    float prev_w0, prev_w1;  /* the previous frame's weights, interpolated from (silk/decoder.rs:2015-2026) */
     uint32_t stream;         /* state slot / PCM row */
     uint32_t pcm_off;        /* first 48 kHz output sample (per channel) inside the stream's PCM row */
     OgSilkChan ch[2];

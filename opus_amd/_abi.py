@@ -41,7 +41,7 @@ class SilkChan(C.Structure):
 
 class SilkFrame(C.Structure):
     _fields_ = [("flags", C.c_uint8), ("bandwidth", C.c_uint8), ("f_size", C.c_uint16), ("w0", C.c_float),
-                ("w1", C.c_float), ("stream", C.c_uint32), ("pcm_off", C.c_uint32), ("ch", SilkChan * 2)]
+                ("w1", C.c_float), ("prev_w0", C.c_float), ("prev_w1", C.c_float), ("stream", C.c_uint32), ("pcm_off", C.c_uint32), ("ch", SilkChan * 2)]
 
 
 class FrameInfo(C.Structure):
@@ -96,6 +96,8 @@ PROTOTYPES = {
     "opusgpu_packet_parse": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(Packet)]),
     "opusgpu_init": (C.c_int, [C.c_int]),
     "opusgpu_launch_celt": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, _P, _P, C.c_size_t, C.POINTER(CeltDebug), _P]),
+    "opusgpu_silk_state_bytes": (C.c_size_t, [C.c_uint32]),
+    "opusgpu_launch_silk": (C.c_int, [_P, C.c_uint32, _P, C.c_uint32, _P, C.c_size_t, _P, _P]),
     "opusgpu_sizeof_celt_state": (C.c_size_t, []),
     "opusgpu_sizeof_celt_hdr": (C.c_size_t, []),
     "opusgpu_sizeof_celt_leaf": (C.c_size_t, []),

@@ -8,7 +8,7 @@ CSRC = os.path.join(ROOT, "opus_amd", "csrc")
 OUT = os.path.join(ROOT, "opus_amd", "libopusgpu.so")
 
 HOST_SOURCES = ["host/packet.cpp", "host/celt_parse.cpp", "host/silk_parse.cpp", "host/stream_parser.cpp",
-                "host/capi_parse.cpp", "host/celt_tables.cpp", "host/engine.cpp"]
+                "host/capi_parse.cpp", "host/celt_tables.cpp", "host/silk_tables.cpp", "host/engine.cpp"]
 HIP_SOURCES = ["hip/celt_launch.hip", "hip/silk_launch.hip"]
 
 
@@ -59,6 +59,7 @@ def build_emu():
     out = os.path.join(ROOT, "tests", "emu", "libemu.so")
     srcs = [os.path.join(ROOT, "tests", "emu", f) for f in os.listdir(os.path.join(ROOT, "tests", "emu")) if f.endswith(".cpp")]
     srcs.append(os.path.join(CSRC, "host", "celt_tables.cpp"))
+    srcs.append(os.path.join(CSRC, "host", "silk_tables.cpp"))
     if not _newer(out, _all_inputs() + srcs):
         return out
     subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",

@@ -15,9 +15,6 @@
 #include "stream_parser.hpp"
 #include "../hip/device_util.hpp"
 
-extern "C" int opusgpu_launch_silk(const OgSilkFrame *frames, uint32_t nframes, void *state, float *pcm,
-                                   size_t pcm_stride_floats, int channels, void *stream);
-extern "C" size_t opusgpu_sizeof_silk_state(void);
 
 namespace {
 
@@ -139,8 +136,8 @@ int opusgpu_batch_create(opusgpu_batch **out, uint32_t nstreams, int channels, i
     hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc((void **)&b->d_celt_state, size_t(nstreams) * sizeof(OgCeltState));
     if (e == hipSuccess) e = hipMemsetAsync(b->d_celt_state, 0, size_t(nstreams) * sizeof(OgCeltState), b->stream);
-    if (e == hipSuccess) e = hipMalloc(&b->d_silk_state, size_t(nstreams) * opusgpu_sizeof_silk_state());
-    if (e == hipSuccess) e = hipMemsetAsync(b->d_silk_state, 0, size_t(nstreams) * opusgpu_sizeof_silk_state(), b->stream);
+    if (e == hipSuccess) e = hipMalloc(&b->d_silk_state, opusgpu_silk_state_bytes(nstreams));
+    if (e == hipSuccess) e = hipMemsetAsync(b->d_silk_state, 0, opusgpu_silk_state_bytes(nstreams), b->stream);
     if (e == hipSuccess) e = hipMalloc((void **)&b->d_pcm, size_t(nstreams) * b->pcm_stride * sizeof(float));
     if (e == hipSuccess) e = hipMemsetAsync(b->d_pcm, 0, size_t(nstreams) * b->pcm_stride * sizeof(float), b->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
@@ -206,12 +203,17 @@ int opusgpu_batch_send(opusgpu_batch *b, const uint8_t *const *pkts, const uint3
             std::memcpy(b->h_leaves.p + leaf_base[w], workers[w].leaves.data(), workers[w].leaves.size() * sizeof(OgCeltLeaf));
     b->h_leaves.n = leaf_base[nw];
 
+    // A stream's work must run in order: Opus frame f of a packet = rounds 3f .. 3f+2; its SILK frames (up to three
+    // 20 ms pieces) take rounds 3f+k, its CELT part (which adds onto the SILK output in hybrid mode) runs in 3f+2.
     uint32_t rounds = 0;
-    for (uint32_t i = 0; i < n; i++) if (parsed[i].rc > 0) rounds = std::max(rounds, uint32_t(parsed[i].rc));
+    for (uint32_t i = 0; i < n; i++) if (parsed[i].rc > 0) rounds = std::max(rounds, 3 * uint32_t(parsed[i].rc));
     std::vector<uint32_t> ccount(rounds + 1, 0), scount(rounds + 1, 0);
     for (uint32_t i = 0; i < n; i++) {
         const ParsedPacket &pp = parsed[i];
-        for (int f = 0; f < pp.rc; f++) { ccount[f] += pp.fi[f].has_celt; scount[f] += pp.fi[f].nsilk; }
+        for (int f = 0; f < pp.rc; f++) {
+            ccount[3 * f + 2] += pp.fi[f].has_celt;
+            for (uint32_t k = 0; k < pp.fi[f].nsilk; k++) scount[3 * f + k]++;
+        }
     }
     b->celt_round_off.assign(rounds + 1, 0);
     b->silk_round_off.assign(rounds + 1, 0);
@@ -233,15 +235,15 @@ int opusgpu_batch_send(opusgpu_batch *b, const uint8_t *const *pkts, const uint3
                     OgSilkFrame sf = workers[w].silk[fi.silk_index + k];
                     sf.stream = pp.stream;
                     sf.pcm_off = pcm_off + sub;
-                    sub += uint32_t(sf.f_size) * (48000u / (sf.bandwidth == 0 ? 8000u : sf.bandwidth == 1 ? 12000u : 16000u));
-                    b->h_silk.p[sfill[f]++] = sf;
+                    sub += uint32_t(sf.f_size) * (sf.bandwidth == 0 ? 6u : sf.bandwidth == 1 ? 4u : 3u);
+                    b->h_silk.p[sfill[3 * f + k]++] = sf;
                 }
                 if (fi.has_celt) {
                     OgCeltHdr hd = workers[w].celt[fi.celt_index];
                     hd.stream = pp.stream;
                     hd.pcm_off = pcm_off;
                     hd.leaf_begin = uint32_t(hd.leaf_begin + leaf_base[w]);
-                    b->h_celt.p[cfill[f]++] = hd;
+                    b->h_celt.p[cfill[3 * f + 2]++] = hd;
                 }
                 pcm_off += fi.frame_size;
             }
@@ -269,7 +271,7 @@ int opusgpu_batch_decode(opusgpu_batch *b)
     const size_t rounds = b->celt_round_off.empty() ? 0 : b->celt_round_off.size() - 1;
     for (size_t r = 0; r < rounds; r++) {               // frame r of every packet; a stream's frames stay in order
         const uint32_t s0 = b->silk_round_off[r], sn = b->silk_round_off[r + 1] - s0;
-        if (sn && (rc = opusgpu_launch_silk(b->d_silk.p + s0, sn, b->d_silk_state, b->d_pcm, b->pcm_stride, b->channels, b->stream)))
+        if (sn && (rc = opusgpu_launch_silk(b->d_silk.p + s0, sn, b->d_silk_state, b->nstreams, b->d_pcm, b->pcm_stride, nullptr, b->stream)))
             return rc;
         const uint32_t c0 = b->celt_round_off[r], cn = b->celt_round_off[r + 1] - c0;
         if (cn && (rc = opusgpu_launch_celt(b->d_celt.p + c0, b->d_leaves.p, cn, 1, b->d_celt_state, b->d_pcm, b->pcm_stride,

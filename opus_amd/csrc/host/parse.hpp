@@ -48,8 +48,10 @@ struct SilkChanHost {           // silk/decoder.rs:1296-1307 (the parse-side fie
 struct SilkHostState {
     int stereo_out = 1;
     SilkChanHost mid, side;
-    bool stereo_reset = true;   // prev0/prev1 = 0 (silk/decoder.rs:1938-1939)
-    bool resampler_reset = true; // device resampler history must be cleared (build's own stage)
+    float w0 = 0.f, w1 = 0.f;          // stereo prediction weights (silk/decoder.rs:23-24)
+    float prev_w0 = 0.f, prev_w1 = 0.f; // previous frame's weights (silk/decoder.rs:25-26, cleared by flush :1938-1939)
+    bool stereo_reset = true;
+    bool resampler_reset = true;        // device resampler history must be cleared (build's own stage)
     void flush();
 };
 // Parses the SILK part of one Opus frame (1-3 internal 20 ms frames); appends one OgSilkFrame each.

@@ -36,14 +36,14 @@ class HostParser:
         self.fi = (A.FrameInfo * 48)()
         self.celt = (A.CeltHdr * 48)()
         self.leaves = (A.CeltLeaf * max_leaves)()
-        self.silk = (A.SilkFrame * 4)()
+        self.silk = (A.SilkFrame * 16)()
         self.max_leaves = max_leaves
 
     def parse(self, pkt):
         nc, nl, ns = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
         b = bytes(pkt)
         n = self.lib.opusgpu_parser_parse(self.h, b, len(b), self.fi, self.celt, 48, C.byref(nc), self.leaves, self.max_leaves,
-                                          C.byref(nl), self.silk, 4, C.byref(ns))
+                                          C.byref(nl), self.silk, 16, C.byref(ns))
         return n, nc.value, nl.value, ns.value
 
     def __del__(self):

@@ -1,0 +1,113 @@
+"""CPU CI of the SILK kernel logic + the whole packet pipeline (host parser -> SILK kernels -> CELT kernel) in the
+g++ emulation build (tests/emu), against the oracle and the reference's golden PCM.  See test_emu_celt.py."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import orc
+from gpu_util import HostParser, check_pcm
+from opus_amd import _abi as A, build
+
+K = orc.kats()
+
+
+@pytest.fixture(scope="module")
+def emu():
+    lib = C.CDLL(build.build_emu())
+    lib.emu_silk_state_floats.restype = C.c_size_t
+    lib.emu_launch_silk.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.emu_launch_celt.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    return lib
+
+
+class EmuDecoder:
+    """host parser + emulated kernels for one stream, in the engine's order (SILK frames, then the CELT part)"""
+
+    def __init__(self, emu, channels):
+        self.emu, self.ch = emu, channels
+        self.hp = HostParser(channels)
+        self.sst = np.zeros(emu.emu_silk_state_floats(1), np.float32)
+        self.cst = A.CeltState()
+        self.pcm = np.zeros(5760 * channels, np.float32)
+        self.internal = np.zeros((2, 320), np.float32)
+
+    def decode(self, p):
+        hp = self.hp
+        n, nc, nl, ns = hp.parse(p)
+        if n < 0:
+            return n
+        off = 0
+        for f in range(n):
+            fi = hp.fi[f]
+            sub = 0
+            for k in range(fi.nsilk):
+                sf = hp.silk[fi.silk_index + k]
+                sf.stream, sf.pcm_off = 0, off + sub
+                sub += sf.f_size * (6, 4, 3)[sf.bandwidth]
+                self.emu.emu_launch_silk(C.byref(sf), 1, self.sst.ctypes.data, 1, self.pcm.ctypes.data, 5760 * self.ch,
+                                         self.internal.ctypes.data)
+            if fi.has_celt:
+                hd = hp.celt[fi.celt_index]
+                hd.stream, hd.pcm_off = 0, off
+                self.emu.emu_launch_celt(C.byref(hd), hp.leaves, 1, 1, C.byref(self.cst), self.pcm.ctypes.data, 5760 * self.ch, None)
+            off += fi.frame_size
+        return self.pcm[: off * self.ch].reshape(off, self.ch).copy()
+
+
+@pytest.mark.parametrize("name,nframes,fs", [("silk_midonly_to_stereo", 3, 160), ("silk_unmix", 1, 160)])
+def test_reference_silk_goldens(emu, name, nframes, fs):
+    """silk/tests.rs:22-514 and :516-845: exact f32 equality at the internal rate, through host parser + kernels"""
+    k = K[name]
+    d = EmuDecoder(emu, 2)
+    hp = d.hp
+    pkt = bytes(k["packet"])
+    n, _, _, ns = hp.parse(pkt)
+    assert n == 1 and ns == nframes
+    left, right = [], []
+    for j in range(ns):
+        sf = hp.silk[j]
+        sf.stream, sf.pcm_off = 0, 0
+        emu.emu_launch_silk(C.byref(sf), 1, d.sst.ctypes.data, 1, d.pcm.ctypes.data, 5760 * 2, d.internal.ctypes.data)
+        left.append(d.internal[0, :fs].copy())
+        right.append(d.internal[1, :fs].copy())
+    assert np.array_equal(np.concatenate(right), np.array(k["right"], np.float32))
+    assert np.array_equal(np.concatenate(left), np.array(k["left"], np.float32))
+
+
+@pytest.mark.parametrize("vid,channels", [(2, 2), (3, 1), (4, 2), (12, 2), (12, 1)])
+def test_emu_silk_vectors_bit_exact(emu, vid, channels):
+    """SILK-only vectors: the kernels keep the oracle's operation order, so 48 kHz PCM is bit-identical"""
+    _, pk = orc.load_vectors(ids=[vid])[vid]
+    d, ref = EmuDecoder(emu, channels), orc.Decoder(channels)
+    for i, p in enumerate(pk):
+        out, r = d.decode(p), ref.decode(p)
+        fi = d.hp.fi[0]
+        if fi.mode == 0:
+            assert np.array_equal(out, r), f"vector {vid} packet {i}"
+        else:
+            check_pcm(r, out, f"vector {vid} packet {i}")
+
+
+@pytest.mark.parametrize("vid,n", [(5, 700), (6, 700), (8, 1247), (9, 600), (10, 900)])
+def test_emu_hybrid_and_mode_switching(emu, vid, n):
+    _, pk = orc.load_vectors(ids=[vid], max_packets=n)[vid]
+    d, ref = EmuDecoder(emu, 2), orc.Decoder(2)
+    for i, p in enumerate(pk):
+        check_pcm(ref.decode(p), d.decode(p), f"vector {vid} packet {i}")
+
+
+def test_lbrr_is_unsupported_like_the_reference(emu):
+    """silk/decoder.rs:2070-2072: an LBRR flag is Error::Unsupported; the batch keeps going"""
+    # SILK NB 20 ms mono, first payload byte 0x40.. : VAD bit then LBRR bit set -> find one by brute force
+    hp = HostParser(2)
+    for b0 in range(256):
+        n, *_ = hp.parse(bytes([0x08, b0, 0, 0, 0, 0, 0, 0]))
+        if n == A.UNSUPPORTED:
+            break
+    else:
+        pytest.fail("no LBRR packet found")
+    L = orc.lib()
+    d = orc.Decoder(2)
+    with pytest.raises(ValueError):
+        d.decode(bytes([0x08, b0, 0, 0, 0, 0, 0, 0]))

@@ -1,0 +1,91 @@
+"""GPU parity over every mode: all 12 RFC 6716 vectors (SILK NB/MB/WB, hybrid SWB/FB, CELT, mode switching) through
+the one-stream C ABI, SILK goldens through the raw launch, and a mixed batch.  Oracle = oracle/liborc.so."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import orc
+from gpu_util import HostParser, check_pcm
+from opus_amd import BatchDecoder, Decoder, _abi as A
+
+pytestmark = pytest.mark.gpu
+K = orc.kats()
+
+
+@pytest.mark.parametrize("vid,n,exact", [(2, 1185, True), (3, 998, True), (4, 1265, True), (12, 1332, False), (5, 800, False),
+                                         (6, 800, False), (8, 1247, False), (9, 700, False), (10, 900, False)])
+def test_vectors_single_stream(vid, n, exact):
+    extra, pk = orc.load_vectors(ids=[vid], max_packets=n)[vid]
+    d = Decoder(0)
+    d.set_extradata(extra)
+    d.configure()
+    ref = orc.Decoder(2)
+    for i, p in enumerate(pk):
+        d.send_packet(p)
+        out, r = d.receive_frame(), ref.decode(p)
+        if exact:                       # SILK-only: same operation order as the oracle -> identical bits
+            assert np.array_equal(out, r), f"vector {vid} packet {i}: max diff {np.abs(out - r).max()}"
+        else:
+            check_pcm(r, out, f"vector {vid} packet {i}")
+
+
+@pytest.mark.parametrize("name,nframes,fs", [("silk_midonly_to_stereo", 3, 160), ("silk_unmix", 1, 160)])
+def test_reference_silk_goldens_on_gpu(name, nframes, fs):
+    """silk/tests.rs:22-514, :516-845: the reference's own golden PCM, exact f32 equality, from the HIP kernels"""
+    import torch
+    lib = A.load()
+    k = K[name]
+    hp = HostParser(2)
+    n, _, _, ns = hp.parse(bytes(k["packet"]))
+    assert n == 1 and ns == nframes
+    dev = torch.device("cuda:0")
+    state = torch.zeros(lib.opusgpu_silk_state_bytes(1), dtype=torch.uint8, device=dev)
+    pcm = torch.zeros(5760 * 2, dtype=torch.float32, device=dev)
+    left, right = [], []
+    for j in range(ns):
+        hp.silk[j].stream, hp.silk[j].pcm_off = 0, 0
+        rec = torch.frombuffer(bytearray(bytes(hp.silk[j])), dtype=torch.uint8).to(dev)
+        internal = torch.zeros((2, 320), dtype=torch.float32, device=dev)
+        rc = lib.opusgpu_launch_silk(rec.data_ptr(), 1, state.data_ptr(), 1, pcm.data_ptr(), 5760 * 2, internal.data_ptr(), None)
+        assert rc == 0, lib.opusgpu_last_error()
+        torch.cuda.synchronize()
+        x = internal.cpu().numpy()
+        left.append(x[0, :fs].copy())
+        right.append(x[1, :fs].copy())
+    assert np.array_equal(np.concatenate(right), np.array(k["right"], np.float32))
+    assert np.array_equal(np.concatenate(left), np.array(k["left"], np.float32))
+
+
+def test_batch_all_modes():
+    """BASELINE config 5 shape in small: the 12 vectors as independent streams of one batch, 60 packets each"""
+    V = orc.load_vectors()
+    ids = sorted(V)
+    ns, steps = 2 * len(ids), 60
+    dec = BatchDecoder(ns, 2, 0)
+    refs = [orc.Decoder(2) for _ in range(ns)]
+    start = [0 if s < len(ids) else 211 for s in range(ns)]
+    for t in range(steps):
+        pk = [V[ids[s % len(ids)]][1][start[s] + t] for s in range(ns)]
+        assert not any(dec.send(pk))
+        dec.decode()
+        for s in range(ns):
+            check_pcm(refs[s].decode(pk[s]), dec.read(s), f"stream {s} (vector {ids[s % len(ids)]}) step {t}")
+
+
+def test_silk_wb_mono_batch_c3_shape():
+    """BASELINE config 3 shape: SILK-only WB mono 20 ms packets of vectors 04/12 looped with per-stream offsets"""
+    V = orc.load_vectors(ids=[4, 12])
+    pool = [p for vid in (4, 12) for p in V[vid][1] if (p[0] >> 3) == 9 and not (p[0] & 4) and (p[0] & 3) == 0]
+    assert len(pool) > 100
+    ns, steps = 512, 8
+    dec = BatchDecoder(ns, 1, 0)
+    sample = list(range(0, ns, 37))
+    refs = {s: orc.Decoder(1) for s in sample}
+    for t in range(steps):
+        pk = [pool[(s * 7 + t) % len(pool)] for s in range(ns)]
+        assert not any(dec.send(pk))
+        dec.decode()
+        for s in sample:
+            out, r = dec.read(s), refs[s].decode(pk[s])
+            assert np.array_equal(out, r), f"stream {s} step {t}"
