@@ -75,7 +75,7 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
-    from opus_amd import BatchDecoder, _abi as A, synth
+    from opus_amd import BatchDecoder, _abi as A, sharding, synth
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -86,7 +86,7 @@ def main():
 
     S, K, W = a.streams, a.steps, a.warmup
     nframes = K + W
-    ids = np.arange(S, dtype=np.uint64) + np.uint64(rank * S)     # streams shard across ranks, no collective
+    ids = sharding.shard_stream_ids(rank, world, S)              # streams shard across ranks, no collective
     packets = synth.celt_fb_stereo_packets(ids, nframes, PAYLOAD)
 
     # ---- host half (untimed here; its rate is reported separately): packets -> side-info, copied to HBM
@@ -137,10 +137,7 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = sharding.max_over_ranks(elapsed, dev)
     assert bool(torch.isfinite(pcm).all())
 
     kernel_ms = [e0.elapsed_time(e1) for e0, e1 in ev]
@@ -158,7 +155,7 @@ def main():
     if rank == 0:
         out = {
             "metric": "decoded audio-sec/sec (48 kHz stereo CELT 20 ms, 4096 streams)",
-            "value": round(world * S * K * FRAME_S / elapsed, 1),
+            "value": round(sharding.aggregate_audio_seconds_per_second(world, S, K, FRAME_S, elapsed), 1),
             "unit": "audio-s/s",
             "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(elapsed / K * 1e3, 4),
