@@ -91,7 +91,7 @@ def main():
 
     # ---- host half (untimed here; its rate is reported separately): packets -> side-info, copied to HBM
     parser = BatchDecoder(S, 2, local_rank)
-    hdr_dev, leaf_dev, alg_bytes, nleaves = [], [], [], []
+    hdr_dev, leaf_dev, ref_dev, ref_classes, alg_bytes, nleaves = [], [], [], [], [], []
     t_parse = 0.0
     for f in range(nframes):
         pk = [packets[s, f].tobytes() for s in range(S)]
@@ -106,19 +106,27 @@ def main():
         pf_on = (gq != 0).any(axis=1).sum()
         alg_bytes.append(int(S * ALG_BYTES_BASE + pf_on * ALG_BYTES_PF))
         nleaves.append(len(leaves))
-        hdr_dev.append(torch.from_numpy(hb.copy()).to(dev))
-        leaf_dev.append(torch.from_numpy(np.frombuffer(leaves, dtype=np.uint8).copy()).to(dev))
+        lb = np.frombuffer(leaves, dtype=np.uint8)
+        refs = (A.LeafRef * max(len(leaves), 1))()
+        classes = (C.c_uint32 * 4)()
+        hbc = np.ascontiguousarray(hb)
+        nref = lib.opusgpu_sort_pvq_leaves(hbc.ctypes.data, S, lb.ctypes.data, refs, len(leaves), classes)
+        hdr_dev.append(torch.from_numpy(hbc.copy()).to(dev))
+        leaf_dev.append(torch.from_numpy(lb.copy()).to(dev))
+        ref_dev.append(torch.from_numpy(np.frombuffer(refs, dtype=np.uint8)[: max(nref, 1) * 8].copy()).to(dev))
+        ref_classes.append(classes)
     parser.close()
 
     state = torch.zeros(S * C.sizeof(A.CeltState), dtype=torch.uint8, device=dev)
+    work = torch.zeros(lib.opusgpu_celt_work_bytes(S), dtype=torch.uint8, device=dev)     # K1 -> K2 scratch (kept zero)
     stride = 960 * 2
     pcm = torch.zeros(S * stride, dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream(dev)
     sp = C.c_void_p(stream.cuda_stream)
 
     def step(f):
-        rc = lib.opusgpu_launch_celt(hdr_dev[f].data_ptr(), leaf_dev[f].data_ptr(), S, 1, state.data_ptr(), pcm.data_ptr(),
-                                     stride, None, sp)
+        rc = lib.opusgpu_launch_celt(hdr_dev[f].data_ptr(), leaf_dev[f].data_ptr(), S, 1, ref_dev[f].data_ptr(), ref_classes[f],
+                                     work.data_ptr(), state.data_ptr(), pcm.data_ptr(), stride, None, sp)
         if rc:
             raise RuntimeError(lib.opusgpu_last_error().decode())
 

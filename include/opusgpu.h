@@ -140,7 +140,7 @@ typedef struct {               /* per-stream CELT synthesis state in HBM (celt/d
     uint32_t pad_;
 } OgCeltState;
 
-typedef struct {               /* optional stage dumps for parity tests; any pointer may be NULL */
+typedef struct {               /* optional stage dumps for parity tests; any pointer may be NULL; zero-fill them first */
     int16_t *pulses;           /* [nframes][2][960]  PVQ pulse vectors at their coefficient positions */
     float *norm;               /* [nframes][2][960]  normalised coefficients after band decoding */
     float *freq;               /* [nframes][2][960]  denormalised MDCT coefficients */
@@ -152,13 +152,25 @@ typedef struct {               /* optional stage dumps for parity tests; any poi
  * the launches too; exposed so a caller can pay the allocation before graph capture. */
 int opusgpu_init(int device);
 
-/* CELT: PVQ decode + band shaping + anti-collapse + denormalise + IMDCT + TDAC window + comb
- * post-filter + de-emphasis, fused; one workgroup per frame.  Replaces the device-side math of
- * celt/decoder.rs:453-837, :1601-1663 and the synthesis the reference lacks.
- * Frames [i*frames_per_group, (i+1)*frames_per_group) must belong to one stream, in time order. */
-int opusgpu_launch_celt(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, uint32_t nframes,
-                        uint32_t frames_per_group, OgCeltState *state, float *pcm, size_t pcm_stride_floats,
-                        const OgCeltDebug *debug /* host struct, may be NULL */, void *stream);
+/* CELT, two kernels per launch:
+ *   K1  og_pvq_kernel: one lane per PVQ leaf (refs[], sorted by size across the whole batch so that the lanes of a
+ *       wavefront run the same trip counts): CWRS index -> pulses, normalise, spreading rotation, collapse mask
+ *       (celt/decoder.rs:541-786); writes the shaped coefficients to the `work` scratch.
+ *   K2+K3 og_celt_kernel: one workgroup per frame: fold / noise fill, Haar + Hadamard reordering, stereo merge
+ *       (celt/decoder.rs:453-538, :788-827, :1601-1663, :1994-2220), then the synthesis the reference lacks
+ *       (anti-collapse, denormalise, IMDCT, TDAC window, comb post-filter, de-emphasis), PCM out.
+ * Frames [i*frames_per_group, (i+1)*frames_per_group) must belong to one stream, in time order.
+ * `work` = opusgpu_celt_work_bytes(nframes) bytes of device scratch, zero-filled ONCE by the caller; the kernels leave
+ * it zero-filled again.  Launches that share `work` must be ordered on one stream. */
+size_t opusgpu_celt_work_bytes(uint32_t nframes);
+/* Host helper: lists the PVQ leaves (K > 0) of hdr[0..nframes) in decreasing size N and counts them per size class
+ * (N > 64, 24 < N <= 64, 8 < N <= 24, N <= 8): K1 runs one launch per class so that the many small leaves do not pay
+ * the LDS of the few large ones.  Returns the total (<= cap; 0 if cap is too small). */
+uint32_t opusgpu_sort_pvq_leaves(const OgCeltHdr *hdr, uint32_t nframes, const OgCeltLeaf *leaves, OgLeafRef *out, uint32_t cap,
+                                 uint32_t class_counts[4]);
+int opusgpu_launch_celt(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, uint32_t nframes, uint32_t frames_per_group,
+                        const OgLeafRef *refs, const uint32_t class_counts[4], void *work, OgCeltState *state, float *pcm,
+                        size_t pcm_stride_floats, const OgCeltDebug *debug /* host struct, may be NULL */, void *stream);
 
 /* SILK: K4 LTP + LPC synthesis with one lane per (stream, channel) over struct-of-arrays state (replaces
  * silk/decoder.rs:1775-1898), then K5 + K6: stereo unmix / mono copy (silk/decoder.rs:2012-2061, :2104-2113) and the

@@ -68,8 +68,13 @@ typedef struct {             /* one decode_band_no_split / decode_band_1 call, 1
     uint8_t cmshift;         /* position of the leaf's blocks inside its quant_band: its collapse mask is
                                 shifted left by this (:1934) and its fill is the quant_band fill shifted right by it */
     uint8_t band;            /* band index */
-    uint16_t reserved;
+    uint16_t pos;            /* first coefficient of the leaf inside its channel's 960-bin frame: (ebands[band] << LM) + off */
 } OgCeltLeaf;
+
+typedef struct {             /* one PVQ leaf (K > 0) to expand: the unit of work of the K1 kernel */
+    uint32_t leaf;           /* index into the launch's leaf array */
+    uint32_t frame;          /* index into the launch's OgCeltHdr array */
+} OgLeafRef;
 
 typedef struct {             /* one CELT frame; fixed stride */
     uint32_t stream;         /* state slot / PCM row of the stream this frame belongs to */

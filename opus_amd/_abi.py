@@ -20,7 +20,11 @@ class CeltBand(C.Structure):
 
 class CeltLeaf(C.Structure):
     _fields_ = [("index", C.c_uint32), ("gain", C.c_float), ("off", C.c_uint8), ("n", C.c_uint8), ("k", C.c_uint8),
-                ("meta", C.c_uint8), ("cmshift", C.c_uint8), ("band", C.c_uint8), ("reserved", C.c_uint16)]
+                ("meta", C.c_uint8), ("cmshift", C.c_uint8), ("band", C.c_uint8), ("pos", C.c_uint16)]
+
+
+class LeafRef(C.Structure):
+    _fields_ = [("leaf", C.c_uint32), ("frame", C.c_uint32)]
 
 
 class CeltHdr(C.Structure):
@@ -95,7 +99,9 @@ PROTOTYPES = {
                                       C.POINTER(SilkFrame), C.c_uint32, C.POINTER(C.c_uint32)]),
     "opusgpu_packet_parse": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(Packet)]),
     "opusgpu_init": (C.c_int, [C.c_int]),
-    "opusgpu_launch_celt": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, _P, _P, C.c_size_t, C.POINTER(CeltDebug), _P]),
+    "opusgpu_launch_celt": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, _P, C.POINTER(C.c_uint32), _P, _P, _P, C.c_size_t, C.POINTER(CeltDebug), _P]),
+    "opusgpu_sort_pvq_leaves": (C.c_uint32, [_P, C.c_uint32, _P, _P, C.c_uint32, C.POINTER(C.c_uint32)]),
+    "opusgpu_celt_work_bytes": (C.c_size_t, [C.c_uint32]),
     "opusgpu_silk_state_bytes": (C.c_size_t, [C.c_uint32]),
     "opusgpu_launch_silk": (C.c_int, [_P, C.c_uint32, _P, C.c_uint32, _P, C.c_size_t, _P, _P]),
     "opusgpu_sizeof_celt_state": (C.c_size_t, []),

@@ -17,6 +17,14 @@
 
 #include "celt_frame_types.h"
 
+struct OgTask {                       // one quant_band call = (band, buffer); 16 bytes in LDS
+    uint16_t boff, n;                 // first bin in the channel buffer, width
+    uint16_t n_b0, cm;                // bins per block after the tf bookkeeping; final collapse mask (PVQ-only tasks)
+    uint8_t buf, flags, recombine, time_divide;
+    uint8_t logB0, norm_row, pad0, pad1;
+};
+enum { OG_T_ACTIVE = 1, OG_T_CHAIN = 2, OG_T_LONG = 8 };
+
 struct OgCeltLds {
     float X[2][960];                  // coefficients (bands) -> MDCT bins -> FFT ping buffer -> de-emphasised PCM
     union {
@@ -26,14 +34,18 @@ struct OgCeltLds {
     union {
         float out[2][OG_OUTLEN];      // [history | frame | tail] time-domain buffer
         struct {
-            uint32_t pvq_u[1272];
-            uint16_t pvq_row[16];
             float scratch[176];       // transformed lowband copy
             float tmp[176];           // Hadamard reorder bounce buffer
         } b;
     } v;
     OgCeltConst k;                    // LDS copy of the small constant tables
-    uint32_t band_cm[2][24];          // OR of the PVQ leaves' collapse masks per (buffer, band), filled by K1
+    uint32_t band_cm[2][24];
+    OgTask task[44];
+    uint32_t stepmask[4];             // which lock-step rounds / sequential bands the frame needs
+    uint8_t bin2band[960];
+    float mrg[21][8][2];              // stereo merge partial sums
+    float mg[21][4];
+          // OR of the PVQ leaves' collapse masks per (buffer, band), filled by K1
     OgCeltHdr hdr;                    // the frame's side-info, staged once (uniform control code reads it from LDS)
     OgCeltLeaf leaves[OG_LDS_LEAVES];
     uint8_t collapse[2][24];
@@ -41,181 +53,7 @@ struct OgCeltLds {
     float carry[2][64];
 };
 
-OG_DEV uint32_t og_lcg(uint32_t s) { return 1664525u * s + 1013904223u; }   // celt/decoder.rs:1595-1599
-
-// ------------------------------------------------------------------------------------------------
-// K1: one lane expands one PVQ leaf.  Serial in N by nature (celt/decoder.rs:541-660); the
-// parallelism is across the ~10^5 leaves of a batch.
-OG_DEV uint32_t og_u(const uint32_t *U, const uint16_t *row, int n, int k)
-{
-    int lo = n < k ? n : k, hi = n < k ? k : n;
-    return U[row[lo] + hi];
-}
-
-// Writes the pulse vector as floats to x[0..n), returns ||y||^2; *cm = collapse mask for `blocks` blocks.
-OG_DEV uint32_t og_cwrsi(const uint32_t *U, const uint16_t *row, int n, int k, uint32_t i, float *x, int blocks,
-                         int *cm_out, int16_t *dbg)
-{
-    uint32_t yy = 0, p, q;
-    int s, k0, val, cm = 0, pos = 0;
-    bool all_zero = false;
-    const int nb = n / blocks;
-    int bl = nb, bi = 0;
-#define OG_PUT(v)                                                                                                   \
-    {                                                                                                               \
-        x[pos] = (float)(v);                                                                                        \
-        if (dbg) dbg[pos] = (int16_t)(v);                                                                           \
-        yy += (uint32_t)((v) * (v));                                                                                \
-        if (v) cm |= 1 << bi;                                                                                       \
-        pos++;                                                                                                      \
-        if (--bl == 0) { bl = nb; bi++; }                                                                           \
-    }
-    while (n > 2) {
-        if (k >= n) {                                   // lots of pulses
-            p = og_u(U, row, n, k + 1);
-            s = -(int)(i >= p);
-            i -= p & (uint32_t)s;
-            k0 = k;
-            q = og_u(U, row, n, n);
-            if (q > i) {
-                k = n;
-                do p = og_u(U, row, --k, n); while (p > i);
-            } else {
-                for (p = og_u(U, row, n, k); p > i; p = og_u(U, row, n, k)) k--;
-            }
-            i -= p;
-            val = (k0 - k + s) ^ s;
-            OG_PUT(val)
-        } else {                                        // lots of dimensions: mostly zeros
-            if (k == 0) { all_zero = true; break; }     // every pulse placed: the rest of x stays zero
-            // Rows k and k+1 of U are contiguous in n, so a run of zeros is decoded with the table reads of four
-            // steps in flight instead of one LDS round trip per coefficient.
-            const uint32_t *Rk = U + row[k], *Rk1 = U + row[k + 1];
-            bool zero = true;
-            while (n > 2 && k < n) {
-                const uint32_t p0 = Rk[n], q0 = Rk1[n], p1 = Rk[n - 1], q1 = Rk1[n - 1];
-                const uint32_t p2 = Rk[n - 2], q2 = Rk1[n - 2], p3 = Rk[n - 3], q3 = Rk1[n - 3];
-                if (!(p0 <= i && i < q0)) { zero = false; break; }
-                i -= p0; OG_PUT(0) n--;
-                if (!(n > 2 && k < n)) break;
-                if (!(p1 <= i && i < q1)) { zero = false; break; }
-                i -= p1; OG_PUT(0) n--;
-                if (!(n > 2 && k < n)) break;
-                if (!(p2 <= i && i < q2)) { zero = false; break; }
-                i -= p2; OG_PUT(0) n--;
-                if (!(n > 2 && k < n)) break;
-                if (!(p3 <= i && i < q3)) { zero = false; break; }
-                i -= p3; OG_PUT(0) n--;
-            }
-            if (!zero) {                                // a pulse sits at this position
-                q = Rk1[n];
-                s = -(int)(i >= q);
-                i -= q & (uint32_t)s;
-                k0 = k;
-                do p = og_u(U, row, --k, n); while (p > i);
-                i -= p;
-                val = (k0 - k + s) ^ s;
-                OG_PUT(val)
-                n--;
-            }
-            continue;
-        }
-        n--;
-    }
-    if (!all_zero) {
-        p = 2 * (uint32_t)k + 1;                        // n == 2
-        s = -(int)(i >= p);
-        i -= p & (uint32_t)s;
-        k0 = k;
-        k = (int)((i + 1) >> 1);
-        if (k) i -= 2 * (uint32_t)k - 1;
-        val = (k0 - k + s) ^ s;
-        OG_PUT(val)
-        s = -(int)i;                                    // n == 1
-        val = (k + s) ^ s;
-        OG_PUT(val)
-    }
-#undef OG_PUT
-    *cm_out = blocks <= 1 ? 1 : cm;
-    return yy;
-}
-
-// RFC 6716 vq.c exp_rotation1 (celt/decoder.rs:676-692).  The reference loops walk x[i], x[i+stride] in place; the
-// `stride` residue classes are independent first-order recurrences, so each runs with its carry in a register
-// (same arithmetic, same order within a class).  Eight steps are loaded, rotated and stored at a time so that the
-// LDS latency is paid per block, not per coefficient.
-OG_DEV void og_rot_fwd(float *x, int i, int stride, int cnt, float c, float s)      // steps at i, i+stride, ...
-{
-    float t = x[i];
-    while (cnt >= 8) {
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) v[j] = x[i + (j + 1) * stride];
-#pragma unroll
-        for (int j = 0; j < 8; j++) { const float x2 = v[j]; v[j] = c * t - s * x2; t = c * x2 + s * t; }
-#pragma unroll
-        for (int j = 0; j < 8; j++) x[i + j * stride] = v[j];
-        i += 8 * stride;
-        cnt -= 8;
-    }
-    for (; cnt > 0; cnt--, i += stride) {
-        const float x2 = x[i + stride];
-        x[i] = c * t - s * x2;
-        t = c * x2 + s * t;
-    }
-    x[i] = t;
-}
-
-OG_DEV void og_rot_bwd(float *x, int i, int stride, int cnt, float c, float s)      // steps at i, i-stride, ...
-{
-    float u = x[i + stride];
-    while (cnt >= 8) {
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) v[j] = x[i - j * stride];
-#pragma unroll
-        for (int j = 0; j < 8; j++) { const float x1 = v[j]; v[j] = c * u + s * x1; u = c * x1 - s * u; }
-#pragma unroll
-        for (int j = 0; j < 8; j++) x[i - j * stride + stride] = v[j];
-        i -= 8 * stride;
-        cnt -= 8;
-    }
-    for (; cnt > 0; cnt--, i -= stride) {
-        const float x1 = x[i];
-        x[i + stride] = c * u + s * x1;
-        u = c * x1 - s * u;
-    }
-    x[i + stride] = u;
-}
-
-OG_DEV void og_exp_rotation1(float *x, int len, int stride, float c, float s)
-{
-    for (int r = 0; r < stride && r < len - stride; r++)                 // forward: i = 0 .. len-stride-1
-        og_rot_fwd(x, r, stride, (len - stride - r + stride - 1) / stride, c, s);
-    const int top = len - 2 * stride - 1;                                // backward: i = top .. 0
-    for (int r = 0; r < stride && r <= top; r++) {
-        const int i = top - ((top - r) % stride);                        // largest i <= top with i = r (mod stride)
-        og_rot_bwd(x, i, stride, (i - r) / stride + 1, c, s);
-    }
-}
-
-OG_DEV void og_exp_rotation(float *x, int len, int stride, int k, int spread)   // celt/decoder.rs:694-721
-{
-    if (2 * k >= len || spread == 0) return;
-    const float gain = (float)len / (float)(len + (20 - 5 * spread) * k);
-    const float theta = 0.5f * gain * gain;
-    const float c = cosf(0.5f * 3.14159265358979323846f * theta), s = cosf(0.5f * 3.14159265358979323846f * (1.f - theta));
-    int stride2 = 0;
-    if (len >= 8 * stride) {
-        stride2 = 1;
-        while ((stride2 * stride2 + stride2) * stride + (stride >> 2) < len) stride2++;
-    }
-    len /= stride;
-    for (int i = 0; i < stride; i++) {
-        if (stride2) og_exp_rotation1(x + i * len, len, stride2, s, c);
-        og_exp_rotation1(x + i * len, len, 1, c, s);
-    }
-}
+#include "celt_pvq.h"
 
 // ------------------------------------------------------------------------------------------------
 // Reductions evaluated in uniform code: every lane gets the same value.  On the GPU each wavefront reduces the
@@ -419,7 +257,16 @@ OG_DEV int og_quant_band(OgBandCtx &c, const OgCeltBand &bd, int chy, float *x, 
     return cm & ((1 << B) - 1);
 }
 
-// celt/decoder.rs:2037-2220 with the range-decoder half removed (the host ran it)
+// celt/decoder.rs:2037-2220 with the range-decoder half removed (the host ran it).
+//
+// The reference walks the bands one after the other, but only two things are truly sequential: folding reads the
+// finished lower bands (`norm`), and the noise seed runs through the fill leaves in decode order.  Everything a
+// quant_band call does to a band whose leaves are all PVQ-coded -- Hadamard interleave, the Haar steps that undo
+// tf time-division / recombination, lowband_out -- depends on that band alone.  So:
+//   pass A  all such (band, buffer) tasks advance in lock-step, one barrier per step for the whole frame;
+//   pass B  the few tasks with live fill leaves run in band order through og_quant_band (as the reference does);
+//   pass C  the mid/side -> left/right merges of all joint bands, in lock-step (norm keeps the mid, so nothing
+//           downstream of a band needs its merged form).
 OG_DEV void og_celt_bands(OgBandCtx &c)
 {
     const OgCeltHdr *h = c.h;
@@ -428,12 +275,148 @@ OG_DEV void og_celt_bands(OgBandCtx &c)
     const int C = (h->flags & OG_F_STEREO) ? 2 : 1;
     const int B = (h->flags & OG_F_TRANSIENT) ? M : 1;
     const int norm_offset = M * L.k.ebands[start];
+    float *tmp_all = &L.v.out[1][0];                    // [2][960] bounce buffer for the lock-step Hadamard reorder
+
+    // ---- set-up: one lane per (band, buffer) task; another 22 lanes build the bin -> band map
+    OG_LANES_BEGIN(tid)
+    for (int t = tid; t < 42; t += OG_WG) {
+        const int i = t >> 1, slot = t & 1;
+        OgTask tk;
+        tk.boff = tk.n = tk.n_b0 = tk.cm = 0;
+        tk.buf = (uint8_t)slot; tk.flags = 0; tk.recombine = tk.time_divide = tk.logB0 = 0; tk.norm_row = 0xFF; tk.pad0 = tk.pad1 = 0;
+        if (i >= start && i < end) {
+            const OgCeltBand bd = h->band[i];
+            const int n = M * L.k.width[i], boff = M * L.k.ebands[i];
+            const bool dual = (bd.flags & OG_B_DUAL) != 0, joint = C == 2 && !dual;
+            const int nfill = slot ? bd.fy : bd.fx;
+            bool active, chain = false;
+            int norm_row = -1;
+            if (C == 1) { active = slot == 0; norm_row = 0; chain = nfill > 0; }
+            else if (dual) { active = true; norm_row = slot; chain = nfill > 0; }
+            else if (n == 1) { active = true; norm_row = slot == 0 ? 0 : -1; }
+            else if (n == 2) { active = slot == ((bd.flags & OG_B_N2SWAP) ? 1 : 0); norm_row = 0; chain = nfill > 0; }
+            else { active = true; norm_row = slot == 0 ? 0 : -1; chain = slot == 0 && nfill > 0 && !(bd.flags & OG_B_MIDFILL0); }
+            (void)joint;
+            if (bd.flags & OG_B_LAST) norm_row = -1;
+            if (active) {
+                tk.boff = (uint16_t)boff; tk.n = (uint16_t)n;
+                tk.flags = OG_T_ACTIVE | (chain ? OG_T_CHAIN : 0) | (B == 1 ? OG_T_LONG : 0);
+                tk.norm_row = (uint8_t)norm_row;
+                if (n == 1) {                           // decode_band_1 (celt/decoder.rs:1466-1495)
+                    const OgCeltLeaf lf = og_leaf(c, bd.leaf0 + (slot ? bd.nx : 0));
+                    L.X[slot][boff] = lf.index ? -1.f : 1.f;
+                    tk.cm = 1;
+                } else {
+                    int Bt = B, n_b = n / B, tf = bd.tf_change, recombine = tf > 0 ? tf : 0, time_divide = 0;
+                    Bt >>= recombine;
+                    n_b <<= recombine;
+                    while ((n_b & 1) == 0 && tf < 0) { Bt <<= 1; n_b >>= 1; time_divide++; tf++; }
+                    tk.recombine = (uint8_t)recombine; tk.time_divide = (uint8_t)time_divide;
+                    tk.logB0 = (uint8_t)(31 - __builtin_clz((unsigned)Bt));
+                    tk.n_b0 = (uint16_t)n_b;
+                    if (!chain) {
+                        int cm = (int)L.band_cm[slot][i];       // fill leaves of such a task are dead: the PVQ masks are all
+                        for (int k = 0; k < time_divide; k++) { Bt >>= 1; cm |= cm >> Bt; }
+                        for (int k = 0; k < recombine; k++) cm = L.k.bit_deinterleave[cm];
+                        Bt <<= recombine;
+                        tk.cm = (uint16_t)(cm & ((1 << Bt) - 1));
+                        if (tk.logB0) OG_ATOMIC_OR(&L.stepmask[0], 1u);
+                        if (time_divide) OG_ATOMIC_OR(&L.stepmask[1], (1u << time_divide) - 1u);
+                        if (recombine) OG_ATOMIC_OR(&L.stepmask[2], (1u << recombine) - 1u);
+                    }
+                }
+                if (chain || (bd.flags & OG_B_MERGE_NORM)) OG_ATOMIC_OR(&L.stepmask[3], 1u << i);
+            } else if (bd.flags & OG_B_MERGE_NORM) {
+                OG_ATOMIC_OR(&L.stepmask[3], 1u << i);
+            }
+        }
+        L.task[t] = tk;
+    }
+    if (tid >= 64 && tid < 64 + 22) {
+        const int b = tid - 64;
+        const int lo = b < 21 ? M * L.k.ebands[b] : M * 100, hi = b < 21 ? M * L.k.ebands[b + 1] : 960;
+        for (int j = lo; j < hi; j++) L.bin2band[j] = (uint8_t)(b < 21 ? b : 255);
+    }
+    OG_LANES_END
+
+#define OG_FOR_TASK_ELEMS(e, tk, p)                                                                                  \
+    for (int e = tid; e < 1920; e += OG_WG) {                                                                        \
+        const int buf = e >= 960, bin = e - 960 * buf;                                                               \
+        const int band_ = L.bin2band[bin];                                                                           \
+        if (band_ == 255) continue;                                                                                  \
+        const OgTask tk = L.task[band_ * 2 + buf];                                                                   \
+        if ((tk.flags & (OG_T_ACTIVE | OG_T_CHAIN)) != OG_T_ACTIVE) continue;                                        \
+        const int p = bin - tk.boff;
+
+    // ---- pass A
+    const uint32_t m_had = L.stepmask[0], m_td = L.stepmask[1], m_rc = L.stepmask[2], m_seq = L.stepmask[3];
+    if (m_had) {                                        // interleave_hadamard (celt/decoder.rs:472-501)
+        OG_LANES_BEGIN(tid)
+        OG_FOR_TASK_ELEMS(e, tk, p)
+            if (!tk.logB0 || tk.n < 2) continue;
+            const int sh = tk.logB0 + tk.recombine, stride = 1 << sh, n0p = tk.n_b0 >> tk.recombine;
+            const int i = p & (stride - 1), j = p >> sh;
+            const int row = (tk.flags & OG_T_LONG) ? L.k.hadamard[stride - 2 + i] : i;
+            tmp_all[e] = L.X[buf][tk.boff + row * n0p + j];
+        }
+        OG_LANES_END
+        OG_LANES_BEGIN(tid)
+        OG_FOR_TASK_ELEMS(e, tk, p)
+            (void)p;
+            if (!tk.logB0 || tk.n < 2) continue;
+            L.X[buf][bin] = tmp_all[e];
+        }
+        OG_LANES_END
+    }
+    for (int r = 0; (m_td >> r) & 1; r++) {             // undo tf time-division: haar1(x, N_B, B) (celt/decoder.rs:2004-2012)
+        OG_LANES_BEGIN(tid)
+        OG_FOR_TASK_ELEMS(e, tk, p)
+            if (tk.time_divide <= r) continue;
+            const int sh = tk.logB0 - (r + 1), st = 1 << sh;
+            if ((p >> sh) & 1) continue;
+            float *x = &L.X[buf][bin];
+            const float a = x[0], b2 = x[st];
+            x[0] = (a + b2) * 0.70710678118654752440f;
+            x[st] = (a - b2) * 0.70710678118654752440f;
+        }
+        OG_LANES_END
+    }
+    for (int r = 0; (m_rc >> r) & 1; r++) {             // undo recombination: haar1(x, N0 >> k, 1 << k) (:2014-2019)
+        OG_LANES_BEGIN(tid)
+        OG_FOR_TASK_ELEMS(e, tk, p)
+            if (tk.recombine <= r) continue;
+            const int st = 1 << r;
+            if ((p >> r) & 1) continue;
+            float *x = &L.X[buf][bin];
+            const float a = x[0], b2 = x[st];
+            x[0] = (a + b2) * 0.70710678118654752440f;
+            x[st] = (a - b2) * 0.70710678118654752440f;
+        }
+        OG_LANES_END
+    }
+    OG_LANES_BEGIN(tid)                                 // lowband_out = sqrt(N0) * x (celt/decoder.rs:2021-2028)
+    OG_FOR_TASK_ELEMS(e, tk, p)
+        (void)p;
+        if (tk.norm_row == 0xFF) continue;
+        L.u.norm[tk.norm_row][bin - norm_offset] = sqrtf((float)tk.n) * L.X[buf][bin];
+    }
+    for (int i = tid; i < 21; i += OG_WG) {             // collapse masks of the bands pass B will not visit
+        if (i < start || i >= end || ((m_seq >> i) & 1)) continue;
+        const int cm0 = L.task[2 * i].cm, cm1 = L.task[2 * i + 1].cm;
+        const bool dual = (h->band[i].flags & OG_B_DUAL) != 0;
+        L.collapse[0][i] = (uint8_t)(dual || C == 1 ? cm0 : (cm0 | cm1));
+        L.collapse[C - 1][i] = (uint8_t)(dual ? cm1 : C == 1 ? cm0 : (cm0 | cm1));
+    }
+    OG_LANES_END
+
+    // ---- pass B: bands with live fill leaves (or the dual -> intensity switch), in order
     for (int i = start; i < end; i++) {
+        if (!((m_seq >> i) & 1)) continue;
         const OgCeltBand bd = h->band[i];
         c.band = i;
-        OG_STAMP_TO(c.cycles, 16 + i)
         const int boff = M * L.k.ebands[i], n = M * L.k.width[i];
         const bool last = (bd.flags & OG_B_LAST) != 0;
+        const OgTask t0 = L.task[2 * i], t1 = L.task[2 * i + 1];
         int x_cm, y_cm;
         if (bd.lowband != 0xFF) {
             x_cm = y_cm = 0;
@@ -451,65 +434,81 @@ OG_DEV void og_celt_bands(OgBandCtx &c)
         const float *lb1 = bd.lowband != 0xFF ? L.u.norm[1] + bd.lowband * M : nullptr;
         float *out0 = last ? nullptr : L.u.norm[0] + boff - norm_offset;
         float *out1 = last ? nullptr : L.u.norm[1] + boff - norm_offset;
-        float *x = L.X[0] + boff, *y = L.X[1] + boff;
-        if (bd.flags & OG_B_DUAL) {
-            x_cm = og_quant_band(c, bd, 0, x, n, B, lb0, out0, x_cm);
-            y_cm = og_quant_band(c, bd, 1, y, n, B, lb1, out1, y_cm);
-        } else if (C == 2 && n == 1) {                  // decode_band_1 on both channels (celt/decoder.rs:1466-1495)
-            (void)og_quant_band(c, bd, 0, x, 1, B, nullptr, out0, 0);
-            (void)og_quant_band(c, bd, 1, y, 1, B, nullptr, nullptr, 0);
-            x_cm = y_cm = 1;
-        } else if (C == 2) {                            // joint stereo (celt/decoder.rs:1795-1862 + RFC 6716 bands.c)
-            const float mid = (1.f / 32768) * bd.imid, side = (1.f / 32768) * bd.iside;
-            int cm;
-            const float inv = (bd.flags & OG_B_INV) ? -1.f : 1.f;
-            if (n == 2) {
-                const int sw = (bd.flags & OG_B_N2SWAP) != 0;
-                float *x2 = sw ? y : x, *y2 = sw ? x : y;
-                cm = og_quant_band(c, bd, sw, x2, n, B, lb0, out0, x_cm | y_cm);
-                const float sign = (bd.flags & OG_B_N2NEG) ? -1.f : 1.f;
-                OG_LANES_BEGIN(tid)
-                if (tid == 0) {
+        int cm0 = t0.cm, cm1 = t1.cm;
+        const bool dual = (bd.flags & OG_B_DUAL) != 0;
+        const int fill0 = dual ? x_cm : (x_cm | y_cm), fill1 = dual ? y_cm : (x_cm | y_cm);
+        if (t0.flags & OG_T_CHAIN) cm0 = og_quant_band(c, bd, 0, L.X[0] + boff, n, B, lb0, out0, fill0);
+        if (t1.flags & OG_T_CHAIN) cm1 = og_quant_band(c, bd, 1, L.X[1] + boff, n, B, dual ? lb1 : lb0, dual ? out1 : out0, fill1);
+        L.collapse[0][i] = (uint8_t)(dual || C == 1 ? cm0 : (cm0 | cm1));
+        L.collapse[C - 1][i] = (uint8_t)(dual ? cm1 : C == 1 ? cm0 : (cm0 | cm1));
+    }
+    OG_BARRIER
+
+    // ---- pass C: stereo merges (celt/decoder.rs:796-827 + the N == 2 case :1826-1862), all joint bands at once
+    if (C == 2) {
+        OG_LANES_BEGIN(tid)
+        if (tid < 21 * 8) {
+            const int i = tid >> 3, sub = tid & 7;
+            const int n = M * L.k.width[i];
+            float xy = 0.f, yy = 0.f;
+            if (i >= start && i < end && (h->band[i].flags & OG_B_JOINT) && n > 2) {
+                const float *x = L.X[0] + M * L.k.ebands[i], *y = L.X[1] + M * L.k.ebands[i];
+                for (int p = sub; p < n; p += 8) { xy += x[p] * y[p]; yy += y[p] * y[p]; }
+            }
+            L.mrg[i][sub][0] = xy;
+            L.mrg[i][sub][1] = yy;
+        }
+        OG_LANES_END
+        OG_LANES_BEGIN(tid)
+        if (tid < 21) {
+            const int i = tid;
+            const OgCeltBand bd = h->band[i];
+            const int n = M * L.k.width[i];
+            float g0 = 0.f, g1 = 0.f, deg = 0.f;
+            if (i >= start && i < end && (bd.flags & OG_B_JOINT)) {
+                const float mid = (1.f / 32768) * bd.imid, side = (1.f / 32768) * bd.iside;
+                const float inv = (bd.flags & OG_B_INV) ? -1.f : 1.f;
+                if (n == 2) {
+                    float *x = L.X[0] + M * L.k.ebands[i], *y = L.X[1] + M * L.k.ebands[i];
+                    const int sw = (bd.flags & OG_B_N2SWAP) != 0;
+                    float *x2 = sw ? y : x, *y2 = sw ? x : y;
+                    const float sign = (bd.flags & OG_B_N2NEG) ? -1.f : 1.f;
                     y2[0] = -sign * x2[1];
                     y2[1] = sign * x2[0];
                     x[0] *= mid; x[1] *= mid; y[0] *= side; y[1] *= side;
                     float t = x[0]; x[0] = t - y[0]; y[0] = inv * (t + y[0]);
                     t = x[1]; x[1] = t - y[1]; y[1] = inv * (t + y[1]);
+                } else {
+                    float xp = 0.f, sd = 0.f;
+                    for (int q = 0; q < 8; q++) { xp += L.mrg[i][q][0]; sd += L.mrg[i][q][1]; }
+                    xp *= mid;
+                    const float e = mid * mid + sd, e0 = e - 2.f * xp, e1 = e + 2.f * xp;
+                    if (e0 < 6e-4f || e1 < 6e-4f) deg = 1.f;
+                    else { g0 = 1.f / sqrtf(e0); g1 = 1.f / sqrtf(e1); }
                 }
-                OG_LANES_END
-            } else {
-                const int fill = (bd.flags & OG_B_MIDFILL0) ? 0 : (x_cm | y_cm);
-                cm = og_quant_band(c, bd, 0, x, n, B, lb0, out0, fill);
-                cm |= og_quant_band(c, bd, 1, y, n, B, nullptr, nullptr, 0);
-                float xp, sd;                           // stereo_merge (celt/decoder.rs:796-827)
-                og_uniform_dot2(x, y, n, &xp, &sd);
-                xp *= mid;
-                const float e = mid * mid + sd, e0 = e - 2.f * xp, e1 = e + 2.f * xp;
-                const bool degenerate = e0 < 6e-4f || e1 < 6e-4f;
-                const float g0 = degenerate ? 0.f : 1.f / sqrtf(e0), g1 = degenerate ? 0.f : 1.f / sqrtf(e1);
-                OG_BARRIER
-                OG_LANES_BEGIN(tid)
-                for (int p = tid; p < n; p += OG_WG) {
-                    if (degenerate) {
-                        y[p] = inv * x[p];
-                    } else {
-                        float v0 = mid * x[p], v1 = y[p];
-                        x[p] = g0 * (v0 - v1);
-                        y[p] = inv * (g1 * (v0 + v1));
-                    }
-                }
-                OG_LANES_END
             }
-            x_cm = y_cm = cm;
-        } else {
-            x_cm = y_cm = og_quant_band(c, bd, 0, x, n, B, lb0, out0, x_cm | y_cm);
+            L.mg[i][0] = g0; L.mg[i][1] = g1; L.mg[i][2] = deg;
         }
-        // every lane stores the same two bytes: no barrier of its own needed (later bands read them after
-        // at least one more barrier; earlier entries are never rewritten)
-        L.collapse[0][i] = (uint8_t)x_cm;
-        L.collapse[C - 1][i] = (uint8_t)y_cm;
+        OG_LANES_END
+        OG_LANES_BEGIN(tid)
+        for (int bin = tid; bin < 960; bin += OG_WG) {
+            const int i = L.bin2band[bin];
+            if (i == 255 || i < start || i >= end) continue;
+            const OgCeltBand bd = h->band[i];
+            if (!(bd.flags & OG_B_JOINT) || M * L.k.width[i] <= 2) continue;
+            const float mid = (1.f / 32768) * bd.imid, inv = (bd.flags & OG_B_INV) ? -1.f : 1.f;
+            float *x = &L.X[0][bin], *y = &L.X[1][bin];
+            if (L.mg[i][2] != 0.f) {
+                *y = inv * *x;
+            } else {
+                const float v0 = mid * *x, v1 = *y;
+                *x = L.mg[i][0] * (v0 - v1);
+                *y = inv * (L.mg[i][1] * (v0 + v1));
+            }
+        }
+        OG_LANES_END
     }
-    OG_BARRIER
+#undef OG_FOR_TASK_ELEMS
 }
 
 // RFC 6716 4.3.5 anti-collapse (bands.c); the reference only reserves its flag bit (celt/decoder.rs:1092)
@@ -661,7 +660,8 @@ OG_DEV void og_wg_comb_filter(float *y0, int nch, int T0, int T1, int n, float g
 // The whole frame.  Uniform arguments; every lane of the workgroup calls it.
 // `dbg` pointers are already offset to this frame (any may be null).
 OG_DEV void og_celt_frame(const OgCeltHdr *hg, const OgCeltLeaf *leaves_base, const OgCeltTables *T, OgCeltState *states,
-                          float *pcm_base, size_t pcm_stride, OgCeltLds &L, const OgCeltDebug &dbg)
+                          float *pcm_base, size_t pcm_stride, OgCeltLds &L, const OgCeltDebug &dbg, float *coef_row,
+                          uint32_t *cm_row)
 {
     int16_t *dbg_pulses = dbg.pulses;
     float *dbg_norm = dbg.norm, *dbg_freq = dbg.freq;
@@ -682,11 +682,12 @@ OG_DEV void og_celt_frame(const OgCeltHdr *hg, const OgCeltLeaf *leaves_base, co
         for (int p = tid; p < nst; p += OG_WG) ld[p] = ls[p];
     }
     for (int p = tid; p < (int)(sizeof(OgCeltConst) / 4); p += OG_WG) ((uint32_t *)&L.k)[p] = ((const uint32_t *)&T->k)[p];
-    for (int p = tid; p < 2 * 960; p += OG_WG) (&L.X[0][0])[p] = 0.f;
+    // K1's output for this frame: shaped PVQ coefficients (zero elsewhere) and the collapse masks of the PVQ leaves.
+    // Both scratch rows are handed back zero-filled for the next launch.
+    for (int p = tid; p < 2 * 960; p += OG_WG) { (&L.X[0][0])[p] = coef_row[p]; coef_row[p] = 0.f; }
     for (int p = tid; p < 2 * 800; p += OG_WG) (&L.u.norm[0][0])[p] = 0.f;
-    for (int p = tid; p < 1272; p += OG_WG) L.v.b.pvq_u[p] = T->pvq_u[p];
-    if (tid < 16) L.v.b.pvq_row[tid] = T->pvq_row[tid];
-    if (tid < 48) { (&L.collapse[0][0])[tid] = 0; (&L.band_cm[0][0])[tid] = 0; }
+    if (tid < 48) { (&L.collapse[0][0])[tid] = 0; (&L.band_cm[0][0])[tid] = cm_row[tid]; cm_row[tid] = 0; }
+    if (tid < 4) L.stepmask[tid] = 0;
     OG_LANES_END
     const OgCeltHdr *h = &L.hdr;
     const int lm = h->lm, M = 1 << lm, N = 120 << lm;
@@ -697,26 +698,6 @@ OG_DEV void og_celt_frame(const OgCeltHdr *hg, const OgCeltLeaf *leaves_base, co
 
     OG_STAMP(1)
     if (!silence) {
-        // ---- phase 1 (K1): one lane per PVQ leaf
-        // leaves are dealt round-robin to the wavefronts: each wave then serialises fewer divergent leaves
-        OG_LANES_BEGIN(tid)
-        for (int l = (tid >> 6) + (tid & 63) * (OG_WG / 64); l < nleaves; l += OG_WG) {
-            const OgCeltLeaf lf = l < OG_LDS_LEAVES ? L.leaves[l] : lv[l];
-            if (lf.k == 0 || (lf.meta & OG_L_N1)) continue;
-            const int band = lf.band, ch = (lf.meta & OG_L_CH_Y) ? 1 : 0;
-            const int pos = (L.k.ebands[band] << lm) + lf.off;
-            const int Bl = 1 << (lf.meta & OG_L_LOGB_MASK);
-            float *x = L.X[ch] + pos;
-            int cm;
-            const uint32_t yy = og_cwrsi(L.v.b.pvq_u, L.v.b.pvq_row, lf.n, lf.k, lf.index, x, Bl, &cm,
-                                         dbg_pulses ? dbg_pulses + ch * 960 + pos : nullptr);
-            const float g = lf.gain / sqrtf((float)yy);                      // celt/decoder.rs:766-786
-            for (int i = 0; i < lf.n; i++) x[i] *= g;
-            og_exp_rotation(x, lf.n, Bl, lf.k, h->spread);
-            OG_ATOMIC_OR(&L.band_cm[ch][band], (uint32_t)cm << lf.cmshift);
-        }
-        OG_LANES_END
-
         OG_STAMP(2)
         // ---- phase 2 (K2): bands in order
         OgBandCtx c;

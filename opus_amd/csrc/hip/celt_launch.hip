@@ -6,10 +6,29 @@
 #include "../host/celt_tables.hpp"
 #include "device_util.hpp"
 
+// K1: 64 leaves per workgroup (one wavefront), vectors lane-interleaved in LDS: element i of lane l at x[i*64 + l], so
+// every access of the serial per-lane loops hits bank l (conflict-free).  NMAX bounds the leaf size of the launch's
+// size class; refs are sorted by decreasing size, so a class is a contiguous range.
+template <int NMAX>
+__global__ __launch_bounds__(64) void og_pvq_kernel(const OgLeafRef *__restrict__ refs, uint32_t nrefs,
+                                                    const OgCeltHdr *__restrict__ hdr, const OgCeltLeaf *__restrict__ leaves,
+                                                    uint32_t nframes, const OgCeltTables *__restrict__ T, void *work,
+                                                    int16_t *dbg_pulses)
+{
+    __shared__ uint32_t U[1272];
+    __shared__ uint16_t row[16];
+    __shared__ float x[NMAX * 64];
+    for (int p = threadIdx.x; p < 1272; p += 64) U[p] = T->pvq_u[p];
+    if (threadIdx.x < 16) row[threadIdx.x] = T->pvq_row[threadIdx.x];
+    __syncthreads();
+    const uint32_t g = blockIdx.x * 64 + threadIdx.x;
+    if (g < nrefs) og_pvq_lane(refs[g], hdr, leaves, nframes, work, U, row, x + threadIdx.x, 64, dbg_pulses);
+}
+
 __global__ __launch_bounds__(OG_WG, 4) void og_celt_kernel(const OgCeltHdr *__restrict__ hdr, const OgCeltLeaf *__restrict__ leaves,
-                                                        uint32_t nframes, uint32_t frames_per_group,
-                                                        const OgCeltTables *__restrict__ T, OgCeltState *state, float *pcm,
-                                                        size_t pcm_stride, OgCeltDebug dbg)
+                                                           uint32_t nframes, uint32_t frames_per_group,
+                                                           const OgCeltTables *__restrict__ T, void *work, OgCeltState *state,
+                                                           float *pcm, size_t pcm_stride, OgCeltDebug dbg)
 {
     __shared__ OgCeltLds L;
     const uint32_t f0 = blockIdx.x * frames_per_group;
@@ -17,12 +36,12 @@ __global__ __launch_bounds__(OG_WG, 4) void og_celt_kernel(const OgCeltHdr *__re
         const uint32_t f = f0 + t;
         if (f >= nframes) break;
         OgCeltDebug d;
-        d.pulses = dbg.pulses ? dbg.pulses + (size_t)f * 1920 : nullptr;
+        d.pulses = nullptr;
         d.norm = dbg.norm ? dbg.norm + (size_t)f * 1920 : nullptr;
         d.freq = dbg.freq ? dbg.freq + (size_t)f * 1920 : nullptr;
         d.collapse = dbg.collapse ? dbg.collapse + (size_t)f * 42 : nullptr;
         d.cycles = dbg.cycles ? dbg.cycles + (size_t)f * 64 : nullptr;
-        og_celt_frame(hdr + f, leaves, T, state, pcm, pcm_stride, L, d);
+        og_celt_frame(hdr + f, leaves, T, state, pcm, pcm_stride, L, d, og_work_coef(work, f), og_work_cm(work, nframes, f));
         __syncthreads();                                // frame t's state stores before frame t+1's loads
     }
 }
@@ -73,11 +92,16 @@ int opusgpu_init(int device)
     return og::celt_tables_for_device(device, &t);
 }
 
+size_t opusgpu_celt_work_bytes(uint32_t nframes) { return (size_t)nframes * (1920 * sizeof(float) + 48 * sizeof(uint32_t)); }
+
 int opusgpu_launch_celt(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, uint32_t nframes, uint32_t frames_per_group,
-                        OgCeltState *state, float *pcm, size_t pcm_stride_floats, const OgCeltDebug *debug, void *stream)
+                        const OgLeafRef *refs, const uint32_t class_counts[4], void *work, OgCeltState *state, float *pcm,
+                        size_t pcm_stride_floats, const OgCeltDebug *debug, void *stream)
 {
     if (nframes == 0) return OPUSGPU_OK;
-    if (!hdr || !leaves || !state || !pcm || frames_per_group == 0) return OPUSGPU_BAD_ARG;
+    if (!hdr || !leaves || !state || !pcm || !work || frames_per_group == 0 || !class_counts) return OPUSGPU_BAD_ARG;
+    const uint32_t nrefs = class_counts[0] + class_counts[1] + class_counts[2] + class_counts[3];
+    if (nrefs && !refs) return OPUSGPU_BAD_ARG;
     int device = 0;
     OG_HIP(hipGetDevice(&device));
     const OgCeltTables *T;
@@ -85,9 +109,26 @@ int opusgpu_launch_celt(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, uint32_t
     if (rc) return rc;
     OgCeltDebug dbg = {nullptr, nullptr, nullptr, nullptr, nullptr};
     if (debug) dbg = *debug;
+    hipStream_t st = (hipStream_t)stream;
+    // K1: one launch per size class (refs are sorted by decreasing N): the many small leaves do not pay the 45 KB of
+    // LDS per wavefront that the few 176-wide ones need.
+    {
+        const OgLeafRef *r = refs;
+#define OG_PVQ_CLASS(NMAX, cnt)                                                                                           \
+        if (cnt) {                                                                                                        \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(og_pvq_kernel<NMAX>), dim3(((cnt) + 63) / 64), dim3(64), 0, st, r, (cnt), hdr,   \
+                               leaves, nframes, T, work, dbg.pulses);                                                     \
+            r += (cnt);                                                                                                   \
+        }
+        OG_PVQ_CLASS(176, class_counts[0])
+        OG_PVQ_CLASS(64, class_counts[1])
+        OG_PVQ_CLASS(24, class_counts[2])
+        OG_PVQ_CLASS(8, class_counts[3])
+#undef OG_PVQ_CLASS
+    }
     const uint32_t groups = (nframes + frames_per_group - 1) / frames_per_group;
-    hipLaunchKernelGGL(og_celt_kernel, dim3(groups), dim3(OG_WG), 0, (hipStream_t)stream, hdr, leaves, nframes,
-                       frames_per_group, T, state, pcm, pcm_stride_floats, dbg);
+    hipLaunchKernelGGL(og_celt_kernel, dim3(groups), dim3(OG_WG), 0, st, hdr, leaves, nframes, frames_per_group, T, work, state,
+                       pcm, pcm_stride_floats, dbg);
     OG_HIP(hipGetLastError());
     return OPUSGPU_OK;
 }

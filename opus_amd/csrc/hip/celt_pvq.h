@@ -1,0 +1,220 @@
+// K1: PVQ leaf expansion (lu-zero/opus src/celt/decoder.rs: cwrsi :541-660, decode_pulses :662-673, unquantize :766-786,
+// exp_rotation :676-721, extract_collapse_mask :723-736).  One lane expands one leaf; the vector lives at x[0], x[xs],
+// x[2*xs] ... so a wavefront can keep 64 leaves lane-interleaved in LDS (xs = 64: bank = lane, conflict-free).
+#pragma once
+#include "wg.h"
+#include "celt_frame_types.h"
+#include "../../../include/opusgpu.h"
+
+OG_DEV uint32_t og_lcg(uint32_t s) { return 1664525u * s + 1013904223u; }   // celt/decoder.rs:1595-1599
+
+// ------------------------------------------------------------------------------------------------
+// K1: one lane expands one PVQ leaf.  Serial in N by nature (celt/decoder.rs:541-660); the
+// parallelism is across the ~10^5 leaves of a batch.
+OG_DEV uint32_t og_u(const uint32_t *U, const uint16_t *row, int n, int k)
+{
+    int lo = n < k ? n : k, hi = n < k ? k : n;
+    return U[row[lo] + hi];
+}
+
+// Writes the pulse vector as floats to x[0..n), returns ||y||^2; *cm = collapse mask for `blocks` blocks.
+OG_DEV uint32_t og_cwrsi(const uint32_t *U, const uint16_t *row, int n, int k, uint32_t i, float *x, int xs, int blocks,
+                         int *cm_out, int16_t *dbg)
+{
+    uint32_t yy = 0, p, q;
+    int s, k0, val, cm = 0, pos = 0;
+    bool all_zero = false;
+    const int nb = n / blocks;
+    int bl = nb, bi = 0;
+#define OG_PUT(v)                                                                                                   \
+    {                                                                                                               \
+        x[pos * xs] = (float)(v);                                                                                        \
+        if (dbg) dbg[pos] = (int16_t)(v);                                                                           \
+        yy += (uint32_t)((v) * (v));                                                                                \
+        if (v) cm |= 1 << bi;                                                                                       \
+        pos++;                                                                                                      \
+        if (--bl == 0) { bl = nb; bi++; }                                                                           \
+    }
+    while (n > 2) {
+        if (k >= n) {                                   // lots of pulses
+            p = og_u(U, row, n, k + 1);
+            s = -(int)(i >= p);
+            i -= p & (uint32_t)s;
+            k0 = k;
+            q = og_u(U, row, n, n);
+            if (q > i) {
+                k = n;
+                do p = og_u(U, row, --k, n); while (p > i);
+            } else {
+                for (p = og_u(U, row, n, k); p > i; p = og_u(U, row, n, k)) k--;
+            }
+            i -= p;
+            val = (k0 - k + s) ^ s;
+            OG_PUT(val)
+        } else {                                        // lots of dimensions: mostly zeros
+            if (k == 0) { all_zero = true; break; }     // every pulse placed: the rest is zeros, no table reads
+            // Rows k and k+1 of U are contiguous in n, so a run of zeros is decoded with the table reads of four
+            // steps in flight instead of one LDS round trip per coefficient.
+            const uint32_t *Rk = U + row[k], *Rk1 = U + row[k + 1];
+            bool zero = true;
+            while (n > 2 && k < n) {
+                const uint32_t p0 = Rk[n], q0 = Rk1[n], p1 = Rk[n - 1], q1 = Rk1[n - 1];
+                const uint32_t p2 = Rk[n - 2], q2 = Rk1[n - 2], p3 = Rk[n - 3], q3 = Rk1[n - 3];
+                if (!(p0 <= i && i < q0)) { zero = false; break; }
+                i -= p0; OG_PUT(0) n--;
+                if (!(n > 2 && k < n)) break;
+                if (!(p1 <= i && i < q1)) { zero = false; break; }
+                i -= p1; OG_PUT(0) n--;
+                if (!(n > 2 && k < n)) break;
+                if (!(p2 <= i && i < q2)) { zero = false; break; }
+                i -= p2; OG_PUT(0) n--;
+                if (!(n > 2 && k < n)) break;
+                if (!(p3 <= i && i < q3)) { zero = false; break; }
+                i -= p3; OG_PUT(0) n--;
+            }
+            if (!zero) {                                // a pulse sits at this position
+                q = Rk1[n];
+                s = -(int)(i >= q);
+                i -= q & (uint32_t)s;
+                k0 = k;
+                do p = og_u(U, row, --k, n); while (p > i);
+                i -= p;
+                val = (k0 - k + s) ^ s;
+                OG_PUT(val)
+                n--;
+            }
+            continue;
+        }
+        n--;
+    }
+    if (all_zero) {
+        for (; n > 0; n--) OG_PUT(0)
+    } else {
+        p = 2 * (uint32_t)k + 1;                        // n == 2
+        s = -(int)(i >= p);
+        i -= p & (uint32_t)s;
+        k0 = k;
+        k = (int)((i + 1) >> 1);
+        if (k) i -= 2 * (uint32_t)k - 1;
+        val = (k0 - k + s) ^ s;
+        OG_PUT(val)
+        s = -(int)i;                                    // n == 1
+        val = (k + s) ^ s;
+        OG_PUT(val)
+    }
+#undef OG_PUT
+    *cm_out = blocks <= 1 ? 1 : cm;
+    return yy;
+}
+
+// RFC 6716 vq.c exp_rotation1 (celt/decoder.rs:676-692).  The reference loops walk x[i], x[i+stride] in place; the
+// `stride` residue classes are independent first-order recurrences, so each runs with its carry in a register
+// (same arithmetic, same order within a class).  Eight steps are loaded, rotated and stored at a time so that the
+// LDS latency is paid per block, not per coefficient.
+OG_DEV void og_rot_fwd(float *x, int xs, int i, int stride, int cnt, float c, float s)      // steps at i, i+stride, ...
+{
+    float t = x[i * xs];
+    while (cnt >= 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = x[(i + (j + 1) * stride) * xs];
+#pragma unroll
+        for (int j = 0; j < 8; j++) { const float x2 = v[j]; v[j] = c * t - s * x2; t = c * x2 + s * t; }
+#pragma unroll
+        for (int j = 0; j < 8; j++) x[(i + j * stride) * xs] = v[j];
+        i += 8 * stride;
+        cnt -= 8;
+    }
+    for (; cnt > 0; cnt--, i += stride) {
+        const float x2 = x[(i + stride) * xs];
+        x[i * xs] = c * t - s * x2;
+        t = c * x2 + s * t;
+    }
+    x[i * xs] = t;
+}
+
+OG_DEV void og_rot_bwd(float *x, int xs, int i, int stride, int cnt, float c, float s)      // steps at i, i-stride, ...
+{
+    float u = x[(i + stride) * xs];
+    while (cnt >= 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = x[(i - j * stride) * xs];
+#pragma unroll
+        for (int j = 0; j < 8; j++) { const float x1 = v[j]; v[j] = c * u + s * x1; u = c * x1 - s * u; }
+#pragma unroll
+        for (int j = 0; j < 8; j++) x[(i - j * stride + stride) * xs] = v[j];
+        i -= 8 * stride;
+        cnt -= 8;
+    }
+    for (; cnt > 0; cnt--, i -= stride) {
+        const float x1 = x[i * xs];
+        x[(i + stride) * xs] = c * u + s * x1;
+        u = c * x1 - s * u;
+    }
+    x[(i + stride) * xs] = u;
+}
+
+OG_DEV void og_exp_rotation1(float *x, int xs, int len, int stride, float c, float s)
+{
+    for (int r = 0; r < stride && r < len - stride; r++)                 // forward: i = 0 .. len-stride-1
+        og_rot_fwd(x, xs, r, stride, (len - stride - r + stride - 1) / stride, c, s);
+    const int top = len - 2 * stride - 1;                                // backward: i = top .. 0
+    for (int r = 0; r < stride && r <= top; r++) {
+        const int i = top - ((top - r) % stride);                        // largest i <= top with i = r (mod stride)
+        og_rot_bwd(x, xs, i, stride, (i - r) / stride + 1, c, s);
+    }
+}
+
+OG_DEV void og_exp_rotation(float *x, int xs, int len, int stride, int k, int spread)   // celt/decoder.rs:694-721
+{
+    if (2 * k >= len || spread == 0) return;
+    const float gain = (float)len / (float)(len + (20 - 5 * spread) * k);
+    const float theta = 0.5f * gain * gain;
+    const float c = cosf(0.5f * 3.14159265358979323846f * theta), s = cosf(0.5f * 3.14159265358979323846f * (1.f - theta));
+    int stride2 = 0;
+    if (len >= 8 * stride) {
+        stride2 = 1;
+        while ((stride2 * stride2 + stride2) * stride + (stride >> 2) < len) stride2++;
+    }
+    len /= stride;
+    for (int i = 0; i < stride; i++) {
+        if (stride2) og_exp_rotation1(x + i * len * xs, xs, len, stride2, s, c);
+        og_exp_rotation1(x + i * len * xs, xs, len, 1, c, s);
+    }
+}
+
+// One PVQ leaf end to end (celt/decoder.rs:662-673 decode_pulses + :766-786 unquantize): pulses -> unit-norm * gain ->
+// spreading rotation, in x[0], x[xs], ... ; returns the collapse mask (already shifted to the leaf's place in its band).
+OG_DEV uint32_t og_pvq_leaf(const uint32_t *U, const uint16_t *row, const OgCeltLeaf &lf, int spread, float *x, int xs, int16_t *dbg)
+{
+    const int Bl = 1 << (lf.meta & OG_L_LOGB_MASK);
+    int cm;
+    const uint32_t yy = og_cwrsi(U, row, lf.n, lf.k, lf.index, x, xs, Bl, &cm, dbg);
+    const float g = lf.gain / sqrtf((float)yy);
+    for (int i = 0; i < lf.n; i++) x[i * xs] *= g;
+    og_exp_rotation(x, xs, lf.n, Bl, lf.k, spread);
+    return (uint32_t)cm << lf.cmshift;
+}
+
+// Scratch shared by the two CELT kernels (layout of `work`, include/opusgpu.h): coef[nframes][2][960] f32 then
+// band_cm[nframes][48] u32 ([buffer][band], 24 per buffer).
+OG_DEV float *og_work_coef(void *work, uint32_t frame) { return (float *)work + (size_t)frame * 1920; }
+OG_DEV uint32_t *og_work_cm(void *work, uint32_t nframes, uint32_t frame)
+{
+    return (uint32_t *)((float *)work + (size_t)nframes * 1920) + (size_t)frame * 48;
+}
+
+// K1 body for one lane.  xl = this lane's vector storage (element stride xs), at least lf.n elements.
+OG_DEV void og_pvq_lane(const OgLeafRef ref, const OgCeltHdr *hdr, const OgCeltLeaf *leaves, uint32_t nframes, void *work,
+                        const uint32_t *U, const uint16_t *row, float *xl, int xs, int16_t *dbg_pulses)
+{
+    const OgCeltLeaf lf = leaves[ref.leaf];
+    const int ch = (lf.meta & OG_L_CH_Y) ? 1 : 0;
+    const int spread = hdr[ref.frame].spread;
+    int16_t *dbg = dbg_pulses ? dbg_pulses + (size_t)ref.frame * 1920 + ch * 960 + lf.pos : nullptr;
+    const uint32_t cm = og_pvq_leaf(U, row, lf, spread, xl, xs, dbg);
+    float *dst = og_work_coef(work, ref.frame) + ch * 960 + lf.pos;
+    for (int i = 0; i < lf.n; i++) dst[i] = xl[i * xs];
+    OG_ATOMIC_OR(og_work_cm(work, nframes, ref.frame) + ch * 24 + lf.band, cm);
+}

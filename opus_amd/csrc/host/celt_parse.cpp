@@ -70,7 +70,8 @@ public:
         OgCeltLeaf l;
         l.index = index; l.gain = gain;
         l.off = uint8_t(off); l.n = uint8_t(n); l.k = uint8_t(k);
-        l.cmshift = uint8_t(cmshift); l.band = uint8_t(band_); l.reserved = 0;
+        l.cmshift = uint8_t(cmshift); l.band = uint8_t(band_);
+        l.pos = uint16_t((int(CELT_EBANDS[band_]) << hdr_->lm) + off);
         const int logb = 31 - __builtin_clz(unsigned(B));
         l.meta = uint8_t(logb | (dead ? OG_L_FILL_DEAD : 0) | (chy ? OG_L_CH_Y : 0) | (n1 ? OG_L_N1 : 0) | (lowband ? OG_L_HAS_LOWBAND : 0));
         leaves_.push_back(l);

@@ -88,11 +88,16 @@ struct opusgpu_batch {
     PinnedBuf<OgCeltHdr> h_celt;
     PinnedBuf<OgCeltLeaf> h_leaves;
     PinnedBuf<OgSilkFrame> h_silk;
+    PinnedBuf<OgLeafRef> h_refs;                            // PVQ leaves per round, sorted by size (K1's work list)
+    std::vector<uint32_t> ref_round_off;
+    std::vector<uint32_t> ref_classes;                      // [rounds][4] leaves per K1 size class
     std::vector<uint32_t> celt_round_off, silk_round_off;   // [rounds + 1]
 
     DeviceBuf<OgCeltHdr> d_celt;
     DeviceBuf<OgCeltLeaf> d_leaves;
     DeviceBuf<OgSilkFrame> d_silk;
+    DeviceBuf<OgLeafRef> d_refs;
+    DeviceBuf<uint8_t> d_work;                              // K1 -> K2 scratch, kept zero-filled between launches
     OgCeltState *d_celt_state = nullptr;
     void *d_silk_state = nullptr;
     float *d_pcm = nullptr;
@@ -103,8 +108,8 @@ struct opusgpu_batch {
     {
         (void)hipSetDevice(device);
         if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
-        h_celt.release(); h_leaves.release(); h_silk.release();
-        d_celt.release(); d_leaves.release(); d_silk.release();
+        h_celt.release(); h_leaves.release(); h_silk.release(); h_refs.release();
+        d_celt.release(); d_leaves.release(); d_silk.release(); d_refs.release(); d_work.release();
         if (d_celt_state) (void)hipFree(d_celt_state);
         if (d_silk_state) (void)hipFree(d_silk_state);
         if (d_pcm) (void)hipFree(d_pcm);
@@ -252,6 +257,18 @@ int opusgpu_batch_send(opusgpu_batch *b, const uint8_t *const *pkts, const uint3
     }
     b->h_celt.n = tot_celt;
     b->h_silk.n = tot_silk;
+    // K1 work lists: per round, that round's PVQ leaves sorted by size; frame indices are relative to the round
+    if ((rc = b->h_refs.reserve(b->h_leaves.n + 1))) return rc;
+    b->ref_round_off.assign(rounds + 1, 0);
+    b->ref_classes.assign(4 * size_t(rounds) + 4, 0);
+    uint32_t nref = 0;
+    for (uint32_t r = 0; r < rounds; r++) {
+        const uint32_t c0 = b->celt_round_off[r], cn = b->celt_round_off[r + 1] - c0;
+        nref += opusgpu_sort_pvq_leaves(b->h_celt.p + c0, cn, b->h_leaves.p, b->h_refs.p + nref, uint32_t(b->h_refs.cap - nref),
+                                        &b->ref_classes[4 * r]);
+        b->ref_round_off[r + 1] = nref;
+    }
+    b->h_refs.n = nref;
     b->pending = true;
     return OPUSGPU_OK;
 }
@@ -268,14 +285,24 @@ int opusgpu_batch_decode(opusgpu_batch *b)
     if (b->h_celt.n) OG_HIP(hipMemcpyAsync(b->d_celt.p, b->h_celt.p, b->h_celt.n * sizeof(OgCeltHdr), hipMemcpyHostToDevice, b->stream));
     if (b->h_leaves.n) OG_HIP(hipMemcpyAsync(b->d_leaves.p, b->h_leaves.p, b->h_leaves.n * sizeof(OgCeltLeaf), hipMemcpyHostToDevice, b->stream));
     if (b->h_silk.n) OG_HIP(hipMemcpyAsync(b->d_silk.p, b->h_silk.p, b->h_silk.n * sizeof(OgSilkFrame), hipMemcpyHostToDevice, b->stream));
+    if ((rc = b->d_refs.reserve(b->h_refs.n + 1))) return rc;
+    if (b->h_refs.n) OG_HIP(hipMemcpyAsync(b->d_refs.p, b->h_refs.p, b->h_refs.n * sizeof(OgLeafRef), hipMemcpyHostToDevice, b->stream));
+    {
+        uint32_t maxc = 0;
+        for (size_t r = 0; r + 1 < b->celt_round_off.size(); r++) maxc = std::max(maxc, b->celt_round_off[r + 1] - b->celt_round_off[r]);
+        const size_t need = opusgpu_celt_work_bytes(maxc), had = b->d_work.cap;
+        if ((rc = b->d_work.reserve(need))) return rc;
+        if (b->d_work.cap != had) OG_HIP(hipMemsetAsync(b->d_work.p, 0, b->d_work.cap, b->stream));   // zero once per (re)allocation
+    }
     const size_t rounds = b->celt_round_off.empty() ? 0 : b->celt_round_off.size() - 1;
     for (size_t r = 0; r < rounds; r++) {               // frame r of every packet; a stream's frames stay in order
         const uint32_t s0 = b->silk_round_off[r], sn = b->silk_round_off[r + 1] - s0;
         if (sn && (rc = opusgpu_launch_silk(b->d_silk.p + s0, sn, b->d_silk_state, b->nstreams, b->d_pcm, b->pcm_stride, nullptr, b->stream)))
             return rc;
         const uint32_t c0 = b->celt_round_off[r], cn = b->celt_round_off[r + 1] - c0;
-        if (cn && (rc = opusgpu_launch_celt(b->d_celt.p + c0, b->d_leaves.p, cn, 1, b->d_celt_state, b->d_pcm, b->pcm_stride,
-                                            nullptr, b->stream)))
+        if (cn && (rc = opusgpu_launch_celt(b->d_celt.p + c0, b->d_leaves.p, cn, 1, b->d_refs.p + b->ref_round_off[r],
+                                            &b->ref_classes[4 * r], b->d_work.p, b->d_celt_state, b->d_pcm,
+                                            b->pcm_stride, nullptr, b->stream)))
             return rc;
     }
     b->pending = false;

@@ -51,3 +51,34 @@ class HostParser:
             self.lib.opusgpu_parser_destroy(self.h)
         except Exception:
             pass
+
+
+class CeltLaunch:
+    """Raw layer-3b CELT launch on torch-owned device memory: sorts the PVQ leaves, uploads, launches K1 + K2/K3."""
+
+    def __init__(self, nframes_max, device="cuda:0"):
+        import torch
+        self.torch = torch
+        self.lib = A.load()
+        self.dev = torch.device(device)
+        self.work = torch.zeros(self.lib.opusgpu_celt_work_bytes(nframes_max), dtype=torch.uint8, device=self.dev)
+        self.keep = []
+
+    def upload(self, hdr_bytes, leaf_bytes, nframes):
+        """hdr_bytes / leaf_bytes: numpy uint8 arrays (host side-info).  -> dict of device tensors + class counts"""
+        torch = self.torch
+        nleaves = leaf_bytes.size // 16
+        refs = (A.LeafRef * max(nleaves, 1))()
+        classes = (C.c_uint32 * 4)()
+        hb = np.ascontiguousarray(hdr_bytes)
+        lb = np.ascontiguousarray(leaf_bytes) if nleaves else np.zeros(16, np.uint8)
+        n = self.lib.opusgpu_sort_pvq_leaves(hb.ctypes.data, nframes, lb.ctypes.data, refs, max(nleaves, 1), classes)
+        rb = np.frombuffer(refs, dtype=np.uint8)[: max(n, 1) * 8].copy()
+        return dict(hdr=torch.from_numpy(hb.copy()).to(self.dev), leaves=torch.from_numpy(lb.copy()).to(self.dev),
+                    refs=torch.from_numpy(rb).to(self.dev), classes=classes, nframes=nframes)
+
+    def launch(self, up, state, pcm, stride, dbg=None, stream=None, frames_per_group=1):
+        rc = self.lib.opusgpu_launch_celt(up["hdr"].data_ptr(), up["leaves"].data_ptr(), up["nframes"], frames_per_group,
+                                          up["refs"].data_ptr(), up["classes"], self.work.data_ptr(), state.data_ptr(),
+                                          pcm.data_ptr(), stride, C.byref(dbg) if dbg is not None else None, stream)
+        assert rc == 0, self.lib.opusgpu_last_error()

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import orc
-from gpu_util import HostParser, check_pcm
+from gpu_util import CeltLaunch, HostParser, check_pcm
 from opus_amd import BatchDecoder, Decoder, _abi as A, synth
 
 pytestmark = pytest.mark.gpu
@@ -110,6 +110,7 @@ def test_stage_dumps_bit_exact_pulses():
     hp = HostParser(2)
     ref = orc.Decoder(2, trace=True)
     dev = torch.device("cuda:0")
+    cl = CeltLaunch(1)
     state = torch.zeros(C.sizeof(A.CeltState), dtype=torch.uint8, device=dev)
     pcm = torch.zeros(5760 * 2, dtype=torch.float32, device=dev)
     for i, p in enumerate(cases):
@@ -119,16 +120,14 @@ def test_stage_dumps_bit_exact_pulses():
         t = ref.trace
         hp.celt[0].stream = 0
         hp.celt[0].pcm_off = 0
-        hdr = torch.frombuffer(bytearray(bytes(hp.celt)[: C.sizeof(A.CeltHdr)]), dtype=torch.uint8).to(dev)
-        leaves = torch.frombuffer(bytearray(bytes(hp.leaves)[: max(nl, 1) * 16]), dtype=torch.uint8).to(dev)
+        up = cl.upload(np.frombuffer(hp.celt, dtype=np.uint8)[: C.sizeof(A.CeltHdr)],
+                       np.frombuffer(hp.leaves, dtype=np.uint8)[: nl * 16], 1)
         pulses = torch.zeros((2, 960), dtype=torch.int16, device=dev)
         norm = torch.zeros((2, 960), dtype=torch.float32, device=dev)
         freq = torch.zeros((2, 960), dtype=torch.float32, device=dev)
         coll = torch.zeros((2, 21), dtype=torch.uint8, device=dev)
         dbg = A.CeltDebug(pulses.data_ptr(), norm.data_ptr(), freq.data_ptr(), coll.data_ptr())
-        rc = lib.opusgpu_launch_celt(hdr.data_ptr(), leaves.data_ptr(), 1, 1, state.data_ptr(), pcm.data_ptr(), 5760 * 2,
-                                     C.byref(dbg), None)
-        assert rc == 0, lib.opusgpu_last_error()
+        cl.launch(up, state, pcm, 5760 * 2, dbg)
         torch.cuda.synchronize()
         Cn = t.C
         assert np.array_equal(pulses.cpu().numpy()[:Cn], np.ctypeslib.as_array(t.pulses)[:Cn]), f"case {i}: pulses"

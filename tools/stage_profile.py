@@ -10,6 +10,8 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from opus_amd import BatchDecoder, _abi as A, synth  # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from gpu_util import CeltLaunch  # noqa: E402
 
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 NF = 6
@@ -17,6 +19,7 @@ lib = A.load()
 dev = torch.device("cuda:0")
 pk = synth.celt_fb_stereo_packets(range(S), NF, 160)
 parser = BatchDecoder(S, 2, 0)
+cl = CeltLaunch(S)
 state = torch.zeros(S * C.sizeof(A.CeltState), dtype=torch.uint8, device=dev)
 pcm = torch.zeros(S * 1920, dtype=torch.float32, device=dev)
 names = ["init", "pvq", "bands", "anticollapse", "denorm", "imdct", "postfilter", "deemph+store"]
@@ -24,12 +27,10 @@ tot = np.zeros(8)
 for f in range(NF):
     assert not any(parser.send([pk[s, f].tobytes() for s in range(S)]))
     celt, leaves, _ = parser.sideinfo()
-    hdr = torch.from_numpy(np.frombuffer(celt, dtype=np.uint8).copy()).to(dev)
-    lv = torch.from_numpy(np.frombuffer(leaves, dtype=np.uint8).copy()).to(dev)
+    up = cl.upload(np.frombuffer(celt, dtype=np.uint8), np.frombuffer(leaves, dtype=np.uint8), S)
     cyc = torch.zeros((S, 64), dtype=torch.int64, device=dev)
     dbg = A.CeltDebug(None, None, None, None, cyc.data_ptr())
-    rc = lib.opusgpu_launch_celt(hdr.data_ptr(), lv.data_ptr(), S, 1, state.data_ptr(), pcm.data_ptr(), 1920, C.byref(dbg), None)
-    assert rc == 0
+    cl.launch(up, state, pcm, 1920, dbg)
     torch.cuda.synchronize()
     c = cyc.cpu().numpy()
     if f >= 1:
