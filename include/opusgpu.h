@@ -145,7 +145,8 @@ typedef struct {               /* optional stage dumps for parity tests; any poi
     float *norm;               /* [nframes][2][960]  normalised coefficients after band decoding */
     float *freq;               /* [nframes][2][960]  denormalised MDCT coefficients */
     uint8_t *collapse;         /* [nframes][2][21]   collapse masks */
-    uint64_t *cycles;          /* [nframes][64]      shader-clock stamps: stages at 0-8, band starts at 16+i (profiling aid) */
+    uint64_t *cycles;          /* [nframes][64] + [177*4096][4]: shader-clock stamps, K2/K3 stages per frame at 0-8, then K1 stages
+                                  per workgroup at ((NMAX*4096 + block)*4) (profiling aid, tools/stage_profile.py) */
 } OgCeltDebug;
 
 /* One-time per-device set-up of the constant tables (twiddles, window, PVQ U table). Called lazily by

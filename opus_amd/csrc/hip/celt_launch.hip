@@ -13,7 +13,7 @@ template <int NMAX>
 __global__ __launch_bounds__(64) void og_pvq_kernel(const OgLeafRef *__restrict__ refs, uint32_t nrefs,
                                                     const OgCeltHdr *__restrict__ hdr, const OgCeltLeaf *__restrict__ leaves,
                                                     uint32_t nframes, const OgCeltTables *__restrict__ T, void *work,
-                                                    int16_t *dbg_pulses)
+                                                    int16_t *dbg_pulses, uint64_t *dbg_cycles)
 {
     __shared__ uint32_t U[1272];
     __shared__ uint16_t row[16];
@@ -22,7 +22,9 @@ __global__ __launch_bounds__(64) void og_pvq_kernel(const OgLeafRef *__restrict_
     if (threadIdx.x < 16) row[threadIdx.x] = T->pvq_row[threadIdx.x];
     __syncthreads();
     const uint32_t g = blockIdx.x * 64 + threadIdx.x;
-    if (g < nrefs) og_pvq_lane(refs[g], hdr, leaves, nframes, work, U, row, x + threadIdx.x, 64, dbg_pulses);
+    // profiling: lane 0 of each workgroup stamps its stages behind the per-frame stamps ([nframes][64]) of the buffer
+    uint64_t *stamps = dbg_cycles && threadIdx.x == 0 ? dbg_cycles + (size_t)nframes * 64 + ((size_t)NMAX * 4096 + blockIdx.x) * 4 : nullptr;
+    if (g < nrefs) og_pvq_lane(refs[g], hdr, leaves, nframes, work, U, row, x + threadIdx.x, 64, dbg_pulses, stamps);
 }
 
 __global__ __launch_bounds__(OG_WG, 4) void og_celt_kernel(const OgCeltHdr *__restrict__ hdr, const OgCeltLeaf *__restrict__ leaves,
@@ -117,7 +119,7 @@ int opusgpu_launch_celt(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, uint32_t
 #define OG_PVQ_CLASS(NMAX, cnt)                                                                                           \
         if (cnt) {                                                                                                        \
             hipLaunchKernelGGL(HIP_KERNEL_NAME(og_pvq_kernel<NMAX>), dim3(((cnt) + 63) / 64), dim3(64), 0, st, r, (cnt), hdr,   \
-                               leaves, nframes, T, work, dbg.pulses);                                                     \
+                               leaves, nframes, T, work, dbg.pulses, dbg.cycles);                                                     \
             r += (cnt);                                                                                                   \
         }
         OG_PVQ_CLASS(176, class_counts[0])

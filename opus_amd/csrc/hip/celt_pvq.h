@@ -186,11 +186,19 @@ OG_DEV void og_exp_rotation(float *x, int xs, int len, int stride, int k, int sp
 
 // One PVQ leaf end to end (celt/decoder.rs:662-673 decode_pulses + :766-786 unquantize): pulses -> unit-norm * gain ->
 // spreading rotation, in x[0], x[xs], ... ; returns the collapse mask (already shifted to the leaf's place in its band).
-OG_DEV uint32_t og_pvq_leaf(const uint32_t *U, const uint16_t *row, const OgCeltLeaf &lf, int spread, float *x, int xs, int16_t *dbg)
+#if defined(__HIP__)
+#define OG_PVQ_STAMP(k) { if (stamps) stamps[k] = (uint64_t)__builtin_readcyclecounter(); }
+#else
+#define OG_PVQ_STAMP(k) {}
+#endif
+OG_DEV uint32_t og_pvq_leaf(const uint32_t *U, const uint16_t *row, const OgCeltLeaf &lf, int spread, float *x, int xs, int16_t *dbg,
+                            uint64_t *stamps /* profiling aid, may be null */)
 {
+    OG_PVQ_STAMP(0)
     const int Bl = 1 << (lf.meta & OG_L_LOGB_MASK);
     int cm;
     const uint32_t yy = og_cwrsi(U, row, lf.n, lf.k, lf.index, x, xs, Bl, &cm, dbg);
+    OG_PVQ_STAMP(1)
     const float g = lf.gain / sqrtf((float)yy);
     for (int i = 0; i < lf.n; i++) x[i * xs] *= g;
     og_exp_rotation(x, xs, lf.n, Bl, lf.k, spread);
@@ -207,14 +215,15 @@ OG_DEV uint32_t *og_work_cm(void *work, uint32_t nframes, uint32_t frame)
 
 // K1 body for one lane.  xl = this lane's vector storage (element stride xs), at least lf.n elements.
 OG_DEV void og_pvq_lane(const OgLeafRef ref, const OgCeltHdr *hdr, const OgCeltLeaf *leaves, uint32_t nframes, void *work,
-                        const uint32_t *U, const uint16_t *row, float *xl, int xs, int16_t *dbg_pulses)
+                        const uint32_t *U, const uint16_t *row, float *xl, int xs, int16_t *dbg_pulses, uint64_t *stamps)
 {
     const OgCeltLeaf lf = leaves[ref.leaf];
     const int ch = (lf.meta & OG_L_CH_Y) ? 1 : 0;
     const int spread = hdr[ref.frame].spread;
     int16_t *dbg = dbg_pulses ? dbg_pulses + (size_t)ref.frame * 1920 + ch * 960 + lf.pos : nullptr;
-    const uint32_t cm = og_pvq_leaf(U, row, lf, spread, xl, xs, dbg);
+    const uint32_t cm = og_pvq_leaf(U, row, lf, spread, xl, xs, dbg, stamps);
     float *dst = og_work_coef(work, ref.frame) + ch * 960 + lf.pos;
     for (int i = 0; i < lf.n; i++) dst[i] = xl[i * xs];
     OG_ATOMIC_OR(og_work_cm(work, nframes, ref.frame) + ch * 24 + lf.band, cm);
+    OG_PVQ_STAMP(3)
 }

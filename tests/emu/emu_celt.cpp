@@ -22,7 +22,7 @@ extern "C" int emu_launch_celt(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, u
             if (!lf.k || (lf.meta & OG_L_N1)) continue;
             float x[176];
             OgLeafRef ref = {hdr[f].leaf_begin + l, f};
-            og_pvq_lane(ref, hdr, leaves, nframes, work.data(), T.pvq_u, T.pvq_row, x, 1, dbg ? dbg->pulses : nullptr);
+            og_pvq_lane(ref, hdr, leaves, nframes, work.data(), T.pvq_u, T.pvq_row, x, 1, dbg ? dbg->pulses : nullptr, nullptr);
         }
     for (uint32_t f = 0; f < nframes; f++) {
         std::memset(&L, 0xA5, sizeof L);               // LDS starts undefined on the device

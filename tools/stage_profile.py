@@ -28,8 +28,9 @@ for f in range(NF):
     assert not any(parser.send([pk[s, f].tobytes() for s in range(S)]))
     celt, leaves, _ = parser.sideinfo()
     up = cl.upload(np.frombuffer(celt, dtype=np.uint8), np.frombuffer(leaves, dtype=np.uint8), S)
-    cyc = torch.zeros((S, 64), dtype=torch.int64, device=dev)
-    dbg = A.CeltDebug(None, None, None, None, cyc.data_ptr())
+    cyc_all = torch.zeros(S * 64 + 177 * 4096 * 4, dtype=torch.int64, device=dev)
+    cyc = cyc_all[: S * 64].view(S, 64)
+    dbg = A.CeltDebug(None, None, None, None, cyc_all.data_ptr())
     cl.launch(up, state, pcm, 1920, dbg)
     torch.cuda.synchronize()
     c = cyc.cpu().numpy()
@@ -47,3 +48,10 @@ for n, v in zip(names, tot / (NF - 1)):
     print(f"{n:14s} {v:12.0f} clk  {100 * v / tot.sum() * (NF - 1):5.1f}%")
 print("mean per-frame total", tot.sum() / (NF - 1), "clk; launch span (last frame)", span, "clk")
 print("per-band mean clk:", " ".join(f"{v:.0f}" for v in band_tot / (NF - 1)))
+k1 = cyc_all[S * 64:].view(177, 4096, 4).cpu().numpy()
+for nmax in (176, 64, 24, 8):
+    blk = k1[nmax]
+    used = blk[:, 0] != 0
+    if used.any():
+        d = np.diff(blk[used].astype(np.float64), axis=1)
+        print(f"K1<{nmax}>: {used.sum()} workgroups; lane-0 mean clk cwrsi {d[:,0].mean():.0f} scale+rotate {d[:,1].mean():.0f} store {d[:,2].mean():.0f}; max total {(blk[used][:,3]-blk[used][:,0]).max()}")
