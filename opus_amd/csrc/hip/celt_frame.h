@@ -17,6 +17,8 @@
 
 #include "celt_frame_types.h"
 
+struct alignas(16) OgF4 { float x, y, z, w; };
+
 struct OgTask {                       // one quant_band call = (band, buffer); 16 bytes in LDS
     uint16_t boff, n;                 // first bin in the channel buffer, width
     uint16_t n_b0, cm;                // bins per block after the tf bookkeeping; final collapse mask (PVQ-only tasks)
@@ -25,7 +27,7 @@ struct OgTask {                       // one quant_band call = (band, buffer); 1
 };
 enum { OG_T_ACTIVE = 1, OG_T_CHAIN = 2, OG_T_LONG = 8 };
 
-struct OgCeltLds {
+struct alignas(16) OgCeltLds {
     float X[2][960];                  // coefficients (bands) -> MDCT bins -> FFT ping buffer -> de-emphasised PCM
     union {
         float norm[2][800];           // folding source (celt/decoder.rs `norm_mid`/`norm_side`)
@@ -44,7 +46,8 @@ struct OgCeltLds {
     uint32_t stepmask[4];             // which lock-step rounds / sequential bands the frame needs
     uint8_t bin2band[960];
     float mrg[21][8][2];              // stereo merge partial sums
-    float mg[21][4];
+    alignas(16) float mg[24][4];      // per-band merge matrix
+    float gband[2][24];               // denormalisation gains
           // OR of the PVQ leaves' collapse masks per (buffer, band), filled by K1
     OgCeltHdr hdr;                    // the frame's side-info, staged once (uniform control code reads it from LDS)
     OgCeltLeaf leaves[OG_LDS_LEAVES];
@@ -348,6 +351,7 @@ OG_DEV void og_celt_bands(OgBandCtx &c)
         if ((tk.flags & (OG_T_ACTIVE | OG_T_CHAIN)) != OG_T_ACTIVE) continue;                                        \
         const int p = bin - tk.boff;
 
+    OG_STAMP_TO(c.cycles, 16)
     // ---- pass A
     const uint32_t m_had = L.stepmask[0], m_td = L.stepmask[1], m_rc = L.stepmask[2], m_seq = L.stepmask[3];
     if (m_had) {                                        // interleave_hadamard (celt/decoder.rs:472-501)
@@ -409,6 +413,7 @@ OG_DEV void og_celt_bands(OgBandCtx &c)
     }
     OG_LANES_END
 
+    OG_STAMP_TO(c.cycles, 17)
     // ---- pass B: bands with live fill leaves (or the dual -> intensity switch), in order
     for (int i = start; i < end; i++) {
         if (!((m_seq >> i) & 1)) continue;
@@ -444,6 +449,7 @@ OG_DEV void og_celt_bands(OgBandCtx &c)
     }
     OG_BARRIER
 
+    OG_STAMP_TO(c.cycles, 18)
     // ---- pass C: stereo merges (celt/decoder.rs:796-827 + the N == 2 case :1826-1862), all joint bands at once
     if (C == 2) {
         OG_LANES_BEGIN(tid)
@@ -460,11 +466,11 @@ OG_DEV void og_celt_bands(OgBandCtx &c)
         }
         OG_LANES_END
         OG_LANES_BEGIN(tid)
-        if (tid < 21) {
+        if (tid < 21) {                                 // per band: x' = ax x + bx y, y' = ay x + by y
             const int i = tid;
             const OgCeltBand bd = h->band[i];
             const int n = M * L.k.width[i];
-            float g0 = 0.f, g1 = 0.f, deg = 0.f;
+            float ax = 1.f, bx = 0.f, ay = 0.f, by = 1.f;
             if (i >= start && i < end && (bd.flags & OG_B_JOINT)) {
                 const float mid = (1.f / 32768) * bd.imid, side = (1.f / 32768) * bd.iside;
                 const float inv = (bd.flags & OG_B_INV) ? -1.f : 1.f;
@@ -483,32 +489,30 @@ OG_DEV void og_celt_bands(OgBandCtx &c)
                     for (int q = 0; q < 8; q++) { xp += L.mrg[i][q][0]; sd += L.mrg[i][q][1]; }
                     xp *= mid;
                     const float e = mid * mid + sd, e0 = e - 2.f * xp, e1 = e + 2.f * xp;
-                    if (e0 < 6e-4f || e1 < 6e-4f) deg = 1.f;
-                    else { g0 = 1.f / sqrtf(e0); g1 = 1.f / sqrtf(e1); }
+                    if (e0 < 6e-4f || e1 < 6e-4f) {     // degenerate: y = x
+                        ay = inv; by = 0.f;
+                    } else {
+                        const float g0 = 1.f / sqrtf(e0), g1 = 1.f / sqrtf(e1);
+                        ax = g0 * mid; bx = -g0; ay = inv * g1 * mid; by = inv * g1;
+                    }
                 }
             }
-            L.mg[i][0] = g0; L.mg[i][1] = g1; L.mg[i][2] = deg;
+            L.mg[i][0] = ax; L.mg[i][1] = bx; L.mg[i][2] = ay; L.mg[i][3] = by;
         }
         OG_LANES_END
         OG_LANES_BEGIN(tid)
         for (int bin = tid; bin < 960; bin += OG_WG) {
             const int i = L.bin2band[bin];
-            if (i == 255 || i < start || i >= end) continue;
-            const OgCeltBand bd = h->band[i];
-            if (!(bd.flags & OG_B_JOINT) || M * L.k.width[i] <= 2) continue;
-            const float mid = (1.f / 32768) * bd.imid, inv = (bd.flags & OG_B_INV) ? -1.f : 1.f;
-            float *x = &L.X[0][bin], *y = &L.X[1][bin];
-            if (L.mg[i][2] != 0.f) {
-                *y = inv * *x;
-            } else {
-                const float v0 = mid * *x, v1 = *y;
-                *x = L.mg[i][0] * (v0 - v1);
-                *y = inv * (L.mg[i][1] * (v0 + v1));
-            }
+            if (i == 255) continue;
+            const OgF4 m4 = *(const OgF4 *)L.mg[i];
+            const float x = L.X[0][bin], y = L.X[1][bin];
+            L.X[0][bin] = m4.x * x + m4.y * y;
+            L.X[1][bin] = m4.z * x + m4.w * y;
         }
         OG_LANES_END
     }
 #undef OG_FOR_TASK_ELEMS
+    OG_STAMP_TO(c.cycles, 19)
 }
 
 // RFC 6716 4.3.5 anti-collapse (bands.c); the reference only reserves its flag bit (celt/decoder.rs:1092)
@@ -684,7 +688,10 @@ OG_DEV void og_celt_frame(const OgCeltHdr *hg, const OgCeltLeaf *leaves_base, co
     for (int p = tid; p < (int)(sizeof(OgCeltConst) / 4); p += OG_WG) ((uint32_t *)&L.k)[p] = ((const uint32_t *)&T->k)[p];
     // K1's output for this frame: shaped PVQ coefficients (zero elsewhere) and the collapse masks of the PVQ leaves.
     // Both scratch rows are handed back zero-filled for the next launch.
-    for (int p = tid; p < 2 * 960; p += OG_WG) { (&L.X[0][0])[p] = coef_row[p]; coef_row[p] = 0.f; }
+    for (int p = tid; p < 2 * 960 / 4; p += OG_WG) {    // 16 bytes per lane
+        ((OgF4 *)&L.X[0][0])[p] = ((const OgF4 *)coef_row)[p];
+        ((OgF4 *)coef_row)[p] = OgF4{0.f, 0.f, 0.f, 0.f};
+    }
     for (int p = tid; p < 2 * 800; p += OG_WG) (&L.u.norm[0][0])[p] = 0.f;
     if (tid < 48) { (&L.collapse[0][0])[tid] = 0; (&L.band_cm[0][0])[tid] = cm_row[tid]; cm_row[tid] = 0; }
     if (tid < 4) L.stepmask[tid] = 0;
@@ -714,36 +721,38 @@ OG_DEV void og_celt_frame(const OgCeltHdr *hg, const OgCeltLeaf *leaves_base, co
     }
     OG_STAMP(4)
 
-    // ---- phase 4: denormalise (RFC 6716 4.3.6) + channel up/down-mix into MDCT bins
-    if (silence) {
-        OG_LANES_BEGIN(tid)
-        for (int p = tid; p < 2 * 960; p += OG_WG) (&L.X[0][0])[p] = 0.f;
-        OG_LANES_END
-    } else {
-        // bins outside [start, end) were never written and are still zero; one pass per band, no barrier between
-        // bands (disjoint bins)
-        for (int b = h->start; b < h->end; b++) {
-            const int lo = L.k.ebands[b] << lm, cnt = (int)L.k.width[b] << lm;
-            const float lg0 = h->energy[0][b] + L.k.emeans[b], lg1 = h->energy[C - 1][b] + L.k.emeans[b];
-            const float g0 = exp2f(lg0 < 32.f ? lg0 : 32.f), g1 = exp2f(lg1 < 32.f ? lg1 : 32.f);
-            OG_LANES_BEGIN_NOSYNC(tid)
-            for (int p = tid; p < C * cnt; p += OG_WG) {
-                const int ch = p >= cnt, j = lo + p - ch * cnt;
-                L.X[ch][j] *= ch ? g1 : g0;
-            }
-            OG_LANES_END_NOSYNC
+    // ---- phase 4: denormalise (RFC 6716 4.3.6) + channel up/down-mix into MDCT bins; the same two regions stage the
+    //      FFT twiddles and this block size's IMDCT twiddles into the (currently idle) history part of the time buffer
+    const int B = transient ? M : 1, NB = N / B, n4 = NB >> 1;
+    OgCf *ldsW = (OgCf *)&L.v.out[0][0], *ldsTw = (OgCf *)&L.v.out[1][0];
+    OG_LANES_BEGIN(tid)
+    for (int t = tid; t < 42; t += OG_WG) {             // per-(channel, band) gains 2^(E + mean), zero outside [start, end)
+        const int ch = t >= 21, b = t - 21 * ch;
+        float g = 0.f;
+        if (!silence && b >= h->start && b < h->end) {
+            const float lg = h->energy[ch < C ? ch : 0][b] + L.k.emeans[b];
+            g = exp2f(lg < 32.f ? lg : 32.f);
         }
-        OG_BARRIER
+        L.gband[ch][b] = g;
     }
-    if (CC == 2 && C == 1) {
-        OG_LANES_BEGIN(tid)
-        for (int p = tid; p < 960; p += OG_WG) L.X[1][p] = L.X[0][p];
-        OG_LANES_END
-    } else if (CC == 1 && C == 2) {
-        OG_LANES_BEGIN(tid)
-        for (int p = tid; p < 960; p += OG_WG) L.X[0][p] = 0.5f * L.X[0][p] + 0.5f * L.X[1][p];
-        OG_LANES_END
+    if (silence)                                        // the band walk (and its bin -> band map) was skipped
+        for (int j = tid; j < 960; j += OG_WG) L.bin2band[j] = 255;
+    for (int p = tid; p < 960; p += OG_WG) ((float *)ldsW)[p] = ((const float *)T->fft_w)[p];
+    for (int p = tid; p < 2 * n4; p += OG_WG) ((float *)ldsTw)[p] = ((const float *)(T->tw + (n4 - 60)))[p];
+    OG_LANES_END
+    OG_LANES_BEGIN(tid)
+    for (int j = tid; j < 960; j += OG_WG) {
+        const int b = L.bin2band[j];
+        float v0 = 0.f, v1 = 0.f;
+        if (b != 255) {
+            v0 = L.X[0][j] * L.gband[0][b];
+            v1 = C == 2 ? L.X[1][j] * L.gband[1][b] : v0;
+            if (CC == 1 && C == 2) v0 = 0.5f * v0 + 0.5f * v1;
+        }
+        L.X[0][j] = v0;
+        L.X[1][j] = v1;
     }
+    OG_LANES_END
     if (dbg_freq) {
         OG_LANES_BEGIN(tid)
         for (int p = tid; p < 2 * 960; p += OG_WG) dbg_freq[p] = (&L.X[0][0])[p];
@@ -752,8 +761,7 @@ OG_DEV void og_celt_frame(const OgCeltHdr *hg, const OgCeltLeaf *leaves_base, co
 
     OG_STAMP(5)
     // ---- phase 5 (K3): IMDCT.  B blocks of NB bins, interleaved with stride B in X.
-    const int B = transient ? M : 1, NB = N / B, n4 = NB >> 1;
-    const OgCf *tw = T->tw + (n4 - 60);
+    const OgCf *tw = ldsTw;
     const float inv_n4 = 1.f / (float)n4;
     OgCf *bufA = &L.u.A[0][0], *bufB = (OgCf *)&L.X[0][0];
     OG_LANES_BEGIN(tid)
@@ -778,10 +786,10 @@ OG_DEV void og_celt_frame(const OgCeltHdr *hg, const OgCeltLeaf *leaves_base, co
         OgCf *src = bufA, *dst = bufB;
         for (int s = 0; s < ns; s++) {
             switch (radix[s]) {
-            case 4: og_wg_fft_stage<4>(src, dst, n4, CC, B, Ns, T->fft_w); break;
-            case 2: og_wg_fft_stage<2>(src, dst, n4, CC, B, Ns, T->fft_w); break;
-            case 3: og_wg_fft_stage<3>(src, dst, n4, CC, B, Ns, T->fft_w); break;
-            default: og_wg_fft_stage<5>(src, dst, n4, CC, B, Ns, T->fft_w); break;
+            case 4: og_wg_fft_stage<4>(src, dst, n4, CC, B, Ns, ldsW); break;
+            case 2: og_wg_fft_stage<2>(src, dst, n4, CC, B, Ns, ldsW); break;
+            case 3: og_wg_fft_stage<3>(src, dst, n4, CC, B, Ns, ldsW); break;
+            default: og_wg_fft_stage<5>(src, dst, n4, CC, B, Ns, ldsW); break;
             }
             Ns *= radix[s];
             OgCf *t = src; src = dst; dst = t;
@@ -844,7 +852,7 @@ OG_DEV void og_celt_frame(const OgCeltHdr *hg, const OgCeltLeaf *leaves_base, co
                                                         // the spectrum when the stage count is odd; it was consumed above)
     OG_LANES_BEGIN(tid)
     if (tid < CC * 60) {
-        const int ch = tid / 60, l = tid - ch * 60;
+        const int ch = tid >= 60, l = tid - ch * 60;
         const float *y = &L.v.out[ch][OG_HIST + l * Lc];
         float m = 0.f, t = 0.f;
         for (int j = 0; j < Lc; j++) { t = y[j] + m; m = coef * t; }
@@ -853,11 +861,15 @@ OG_DEV void og_celt_frame(const OgCeltHdr *hg, const OgCeltLeaf *leaves_base, co
     OG_LANES_END
     float aL = 1.f;
     for (int j = 0; j < Lc; j++) aL *= coef;            // coef^Lc
+    // carry-in of chunk l = sum over earlier chunks q of carry[q] * coef^(Lc*(l-1-q)) (+ the stream's memory); terms
+    // more than `reach` chunks back are below 1e-9 of their chunk's value and are dropped
+    const int reach = 128 / Lc + 1;
     OG_LANES_BEGIN(tid)
     if (tid < CC * 60) {
-        const int ch = tid / 60, l = tid - ch * 60;
-        float m = reset ? 0.f : st->deemph[ch];
-        for (int q = 0; q < l; q++) m = m * aL + L.carry[ch][q];
+        const int ch = tid >= 60, l = tid - ch * 60;
+        const int q0 = l > reach ? l - reach : 0;
+        float m = (reset || q0 > 0) ? 0.f : st->deemph[ch];
+        for (int q = q0; q < l; q++) m = m * aL + L.carry[ch][q];
         const float *y = &L.v.out[ch][OG_HIST + l * Lc];
         float *t = tbuf + ch * 960 + l * Lc;
         for (int j = 0; j < Lc; j++) { const float v = y[j] + m; m = coef * v; t[j] = v; }
@@ -866,24 +878,42 @@ OG_DEV void og_celt_frame(const OgCeltHdr *hg, const OgCeltLeaf *leaves_base, co
     OG_LANES_END
     float *pcm = pcm_base + (size_t)h->stream * pcm_stride + (size_t)h->pcm_off * CC;
     const bool accum = (h->flags & OG_F_ACCUM) != 0;
+    const bool vec = (((uintptr_t)pcm) & 15) == 0;      // 16-byte stores when the caller's row allows it
     OG_LANES_BEGIN(tid)
-    for (int q = tid; q < N * CC; q += OG_WG) {
-        const int j = q / CC, ch = q - j * CC;
-        const float v = tbuf[ch * 960 + j] * (1.f / 32768.f);
-        pcm[q] = accum ? pcm[q] + v : v;
+    if (vec) {
+        const float k = 1.f / 32768.f;
+        for (int q = tid; q < N * CC / 4; q += OG_WG) {
+            OgF4 v;
+            if (CC == 2) {                              // two stereo samples
+                const int j = 2 * q;
+                v = OgF4{tbuf[j] * k, tbuf[960 + j] * k, tbuf[j + 1] * k, tbuf[960 + j + 1] * k};
+            } else {
+                const OgF4 u = ((const OgF4 *)tbuf)[q];
+                v = OgF4{u.x * k, u.y * k, u.z * k, u.w * k};
+            }
+            if (accum) { const OgF4 o = ((const OgF4 *)pcm)[q]; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+            ((OgF4 *)pcm)[q] = v;
+        }
+    } else {
+        for (int q = tid; q < N * CC; q += OG_WG) {
+            const int j = CC == 2 ? q >> 1 : q, ch = CC == 2 ? q & 1 : 0;
+            const float v = tbuf[ch * 960 + j] * (1.f / 32768.f);
+            pcm[q] = accum ? pcm[q] + v : v;
+        }
     }
-    for (int q = tid; q < CC * N; q += OG_WG) {         // history ring (N <= 960 < 1024: no wrap onto itself)
-        const int ch = q / N, i = q - ch * N;
-        st->hist[ch][(pos0 + (uint32_t)i) & 1023u] = L.v.out[ch][OG_HIST + i];
+    // history ring: pos0 and N are multiples of 8, so groups of four samples never straddle the wrap
+    for (int q = tid; q < CC * (N >> 2); q += OG_WG) {
+        const int ch = q >= (N >> 2), i = 4 * (q - ch * (N >> 2));
+        *(OgF4 *)&st->hist[ch][(pos0 + (uint32_t)i) & 1023u] = *(const OgF4 *)&L.v.out[ch][OG_HIST + i];
     }
-    for (int q = tid; q < CC * 60; q += OG_WG) {
-        const int ch = q / 60, i = q - ch * 60;
-        st->overlap[ch][i] = L.v.out[ch][OG_HIST + N + i];
+    for (int q = tid; q < CC * 15; q += OG_WG) {
+        const int ch = q >= 15, i = 4 * (q - ch * 15);
+        *(OgF4 *)&st->overlap[ch][i] = *(const OgF4 *)&L.v.out[ch][OG_HIST + N + i];
     }
     if (reset)                                          // forget the ring's older samples
-        for (int q = tid; q < CC * (1024 - N); q += OG_WG) {
-            const int ch = q / (1024 - N), i = q - ch * (1024 - N);
-            st->hist[ch][N + i] = 0.f;
+        for (int q = tid; q < CC * ((1024 - N) >> 2); q += OG_WG) {
+            const int ch = q >= ((1024 - N) >> 2), i = 4 * (q - ch * ((1024 - N) >> 2));
+            *(OgF4 *)&st->hist[ch][N + i] = OgF4{0.f, 0.f, 0.f, 0.f};
         }
     if (tid == 0) st->pos = pos0 + (uint32_t)N;
     OG_LANES_END

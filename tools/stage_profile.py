@@ -39,7 +39,7 @@ for f in range(NF):
         # stamps 2/3 are skipped on silent frames; ignore rows with non-monotonic stamps
         ok = (d >= 0).all(axis=1)
         tot += d[ok].mean(axis=0)
-        bb = np.concatenate([c[:, 16:37], c[:, 3:4]], axis=1)          # band starts + end of band phase
+        bb = np.concatenate([c[:, 2:3], c[:, 16:20]], axis=1)          # band phase: set-up, pass A, pass B, pass C
         bd = np.diff(bb, axis=1).astype(np.float64)
         okb = ok & (bd >= 0).all(axis=1)
         band_tot = band_tot + bd[okb].mean(axis=0) if "band_tot" in dir() else bd[okb].mean(axis=0)
@@ -47,7 +47,7 @@ for f in range(NF):
 for n, v in zip(names, tot / (NF - 1)):
     print(f"{n:14s} {v:12.0f} clk  {100 * v / tot.sum() * (NF - 1):5.1f}%")
 print("mean per-frame total", tot.sum() / (NF - 1), "clk; launch span (last frame)", span, "clk")
-print("per-band mean clk:", " ".join(f"{v:.0f}" for v in band_tot / (NF - 1)))
+print("band phase (set-up, pass A lock-step, pass B sequential, pass C merges) mean clk:", " ".join(f"{v:.0f}" for v in band_tot / (NF - 1)))
 k1 = cyc_all[S * 64:].view(177, 4096, 4).cpu().numpy()
 for nmax in (176, 64, 24, 8):
     blk = k1[nmax]
