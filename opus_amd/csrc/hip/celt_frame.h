@@ -21,9 +21,9 @@ struct alignas(16) OgF4 { float x, y, z, w; };
 
 struct OgTask {                       // one quant_band call = (band, buffer); 16 bytes in LDS
     uint16_t boff, n;                 // first bin in the channel buffer, width
-    uint16_t n_b0, cm;                // bins per block after the tf bookkeeping; final collapse mask (PVQ-only tasks)
-    uint8_t buf, flags, recombine, time_divide;
-    uint8_t logB0, norm_row, pad0, pad1;
+    uint16_t n0p, cm;                 // OgXform.n0p; final collapse mask (PVQ-only tasks)
+    uint8_t buf, flags, hm, slog;     // OgXform.hm / .slog
+    uint8_t m, norm_row, pad0, pad1;  // popcount(hm); norm row lowband_out goes to (0xFF = none)
 };
 enum { OG_T_ACTIVE = 1, OG_T_CHAIN = 2, OG_T_LONG = 8 };
 
@@ -159,6 +159,56 @@ struct OgBandCtx {
     uint64_t *cycles;                 // profiling stamps (may be null)
 };
 
+// The Haar steps of one quant_band call -- tf recombination (celt/decoder.rs:1708-1716, strides 1, 2, 4) and tf
+// time-division (:1722-1740, strides B, 2B, ...) -- are butterflies on distinct bits of the coefficient index, so
+// together they are a Walsh-Hadamard transform over the bit mask `hm`, scaled by 2^(-m/2).  The Hadamard
+// (de)interleave (:472-538) that follows / precedes them is a permutation.  Fused, every output coefficient is one
+// gather of 2^m inputs: a whole pre- or post-processing chain costs one barrier instead of one per step.
+struct OgXform {
+    int hm;                           // index bits the butterflies act on
+    int slog, n0p, had;               // reorder: stride 2^slog (0 = none), row length, natural / ordery rows
+    float scale;                      // 2^(-popcount(hm)/2)
+};
+
+OG_DEV void og_make_xform(int n, int B, int tf_change, OgXform *t, int *recombine_out, int *time_divide_out, int *B0_out)
+{
+    const int long_blocks = B == 1;
+    int n_b = n / B, recombine = tf_change > 0 ? tf_change : 0, time_divide = 0;
+    B >>= recombine;
+    n_b <<= recombine;
+    const int b1 = 31 - __builtin_clz((unsigned)B);
+    while ((n_b & 1) == 0 && tf_change < 0) { B <<= 1; n_b >>= 1; time_divide++; tf_change++; }
+    t->hm = ((1 << recombine) - 1) | (((1 << time_divide) - 1) << b1);
+    t->slog = B > 1 ? (31 - __builtin_clz((unsigned)B)) + recombine : 0;
+    t->n0p = n_b >> recombine;
+    t->had = long_blocks;
+    const int m = recombine + time_divide;
+    t->scale = (m & 1 ? 0.70710678118654752440f : 1.f) / (float)(1 << (m >> 1));
+    *recombine_out = recombine; *time_divide_out = time_divide; *B0_out = B;
+}
+
+// where interleave_hadamard takes the value at position d from (= where deinterleave_hadamard puts the value of d)
+OG_DEV int og_reorder(const OgXform &t, int d, const uint8_t *ordery)
+{
+    if (!t.slog) return d;
+    const int S = 1 << t.slog, i = d & (S - 1), j = d >> t.slog;
+    return (t.had ? ordery[S - 2 + i] : i) * t.n0p + j;
+}
+
+// Walsh-Hadamard gather: scale * sum over s (= p outside hm) of (-1)^popcount(p & s & hm) * src[perm(s)]
+OG_DEV float og_wht_gather(const OgXform &t, const float *src, int p, const uint8_t *ordery, bool permute_src)
+{
+    float acc = 0.f;
+    int q = 0;
+    do {
+        const int s = (p & ~t.hm) | q;
+        const float v = src[permute_src ? og_reorder(t, s, ordery) : s];
+        acc += (__builtin_popcount((unsigned)(p & q)) & 1) ? -v : v;
+        q = (q - t.hm) & t.hm;
+    } while (q);
+    return acc * t.scale;
+}
+
 OG_DEV OgCeltLeaf og_leaf(const OgBandCtx &c, int idx) { return idx < OG_LDS_LEAVES ? c.L->leaves[idx] : c.lv[idx]; }
 
 // One quant_band call (celt/decoder.rs:1665-1768 pre, :1601-1663 leaves, :1994-2032 post) on channel
@@ -178,31 +228,19 @@ OG_DEV int og_quant_band(OgBandCtx &c, const OgCeltBand &bd, int chy, float *x, 
         OG_LANES_END
         return 1;
     }
-    const int n0 = n, long_blocks = B == 1;
-    int n_b = n / B, tf_change = bd.tf_change, recombine = tf_change > 0 ? tf_change : 0, time_divide = 0;
+    const int n0 = n;
+    OgXform xf;
+    int recombine, time_divide, B0;
+    og_make_xform(n, B, bd.tf_change, &xf, &recombine, &time_divide, &B0);
+    for (int k = 0; k < recombine; k++) fill = L.k.bit_interleave[fill & 0xF] | L.k.bit_interleave[fill >> 4] << 2;
+    for (int k = 0, Bk = B >> recombine; k < time_divide; k++, Bk <<= 1) fill |= fill << Bk;
     const bool need_lowband = lowband && (bd.flags & (chy ? OG_B_FOLD_Y : OG_B_FOLD_X));
-    float *lb = L.v.b.scratch;
-    if (need_lowband) {
+    float *lb = L.v.b.scratch, *tmp = L.v.b.tmp;
+    if (need_lowband) {                                 // Haar steps + deinterleave_hadamard on a copy of the folding source
         OG_LANES_BEGIN(tid)
-        for (int p = tid; p < n; p += OG_WG) lb[p] = lowband[p];
+        for (int p = tid; p < n; p += OG_WG) lb[og_reorder(xf, p, L.k.hadamard)] = og_wht_gather(xf, lowband, p, L.k.hadamard, false);
         OG_LANES_END
     }
-    for (int k = 0; k < recombine; k++) {
-        if (need_lowband) og_wg_haar1(lb, n >> k, 1 << k);
-        fill = L.k.bit_interleave[fill & 0xF] | L.k.bit_interleave[fill >> 4] << 2;
-    }
-    B >>= recombine;
-    n_b <<= recombine;
-    while ((n_b & 1) == 0 && tf_change < 0) {
-        if (need_lowband) og_wg_haar1(lb, n_b, B);
-        fill |= fill << B;
-        B <<= 1;
-        n_b >>= 1;
-        time_divide++;
-        tf_change++;
-    }
-    const int B0 = B, n_b0 = n_b;
-    if (B0 > 1 && need_lowband) og_wg_hadamard_reorder(lb, L.v.b.tmp, n_b >> recombine, B0 << recombine, long_blocks, 0, L.k.hadamard);
 
     int cm = (int)L.band_cm[chy ? 1 : 0][c.band];       // PVQ leaves: expanded (and masks collected) by K1
     for (int l = 0; l < nfill; l++) {                   // fill leaves in decode order (the LCG seed is sequential)
@@ -237,27 +275,30 @@ OG_DEV int og_quant_band(OgBandCtx &c, const OgCeltBand &bd, int chy, float *x, 
         og_wg_renormalize(xl, nn, lf.gain);
     }
 
-    if (B0 > 1) og_wg_hadamard_reorder(x, L.v.b.tmp, n_b >> recombine, B0 << recombine, long_blocks, 1, L.k.hadamard);
-    n_b = n_b0;
-    B = B0;
-    for (int k = 0; k < time_divide; k++) {
-        B >>= 1;
-        n_b <<= 1;
-        cm |= cm >> B;
-        og_wg_haar1(x, n_b, B);
-    }
-    for (int k = 0; k < recombine; k++) {
-        cm = L.k.bit_deinterleave[cm];
-        og_wg_haar1(x, n0 >> k, 1 << k);
-    }
-    B <<= recombine;
-    if (lowband_out) {
-        const float s = sqrtf((float)n0);
+    // interleave_hadamard + the Haar steps that undo time-division and recombination (celt/decoder.rs:1994-2019),
+    // fused; lowband_out = sqrt(N0) * x (:2021-2028) rides on the copy-back
+    for (int k = 0, Bk = B0; k < time_divide; k++) { Bk >>= 1; cm |= cm >> Bk; }
+    for (int k = 0; k < recombine; k++) cm = L.k.bit_deinterleave[cm];
+    const int Bend = (B0 >> time_divide) << recombine;
+    if (xf.hm || xf.slog) {
         OG_LANES_BEGIN(tid)
-        for (int p = tid; p < n0; p += OG_WG) lowband_out[p] = s * x[p];
+        for (int p = tid; p < n; p += OG_WG) tmp[p] = og_wht_gather(xf, x, p, L.k.hadamard, true);
+        OG_LANES_END
+        const float sq = sqrtf((float)n0);
+        OG_LANES_BEGIN(tid)
+        for (int p = tid; p < n; p += OG_WG) {
+            const float v = tmp[p];
+            x[p] = v;
+            if (lowband_out) lowband_out[p] = sq * v;
+        }
+        OG_LANES_END
+    } else if (lowband_out) {
+        const float sq = sqrtf((float)n0);
+        OG_LANES_BEGIN(tid)
+        for (int p = tid; p < n0; p += OG_WG) lowband_out[p] = sq * x[p];
         OG_LANES_END
     }
-    return cm & ((1 << B) - 1);
+    return cm & ((1 << Bend) - 1);
 }
 
 // celt/decoder.rs:2037-2220 with the range-decoder half removed (the host ran it).
@@ -285,12 +326,12 @@ OG_DEV void og_celt_bands(OgBandCtx &c)
     for (int t = tid; t < 42; t += OG_WG) {
         const int i = t >> 1, slot = t & 1;
         OgTask tk;
-        tk.boff = tk.n = tk.n_b0 = tk.cm = 0;
-        tk.buf = (uint8_t)slot; tk.flags = 0; tk.recombine = tk.time_divide = tk.logB0 = 0; tk.norm_row = 0xFF; tk.pad0 = tk.pad1 = 0;
+        tk.boff = tk.n = tk.n0p = tk.cm = 0;
+        tk.buf = (uint8_t)slot; tk.flags = 0; tk.hm = tk.slog = tk.m = 0; tk.norm_row = 0xFF; tk.pad0 = tk.pad1 = 0;
         if (i >= start && i < end) {
             const OgCeltBand bd = h->band[i];
             const int n = M * L.k.width[i], boff = M * L.k.ebands[i];
-            const bool dual = (bd.flags & OG_B_DUAL) != 0, joint = C == 2 && !dual;
+            const bool dual = (bd.flags & OG_B_DUAL) != 0;
             const int nfill = slot ? bd.fy : bd.fx;
             bool active, chain = false;
             int norm_row = -1;
@@ -299,7 +340,6 @@ OG_DEV void og_celt_bands(OgBandCtx &c)
             else if (n == 1) { active = true; norm_row = slot == 0 ? 0 : -1; }
             else if (n == 2) { active = slot == ((bd.flags & OG_B_N2SWAP) ? 1 : 0); norm_row = 0; chain = nfill > 0; }
             else { active = true; norm_row = slot == 0 ? 0 : -1; chain = slot == 0 && nfill > 0 && !(bd.flags & OG_B_MIDFILL0); }
-            (void)joint;
             if (bd.flags & OG_B_LAST) norm_row = -1;
             if (active) {
                 tk.boff = (uint16_t)boff; tk.n = (uint16_t)n;
@@ -310,22 +350,18 @@ OG_DEV void og_celt_bands(OgBandCtx &c)
                     L.X[slot][boff] = lf.index ? -1.f : 1.f;
                     tk.cm = 1;
                 } else {
-                    int Bt = B, n_b = n / B, tf = bd.tf_change, recombine = tf > 0 ? tf : 0, time_divide = 0;
-                    Bt >>= recombine;
-                    n_b <<= recombine;
-                    while ((n_b & 1) == 0 && tf < 0) { Bt <<= 1; n_b >>= 1; time_divide++; tf++; }
-                    tk.recombine = (uint8_t)recombine; tk.time_divide = (uint8_t)time_divide;
-                    tk.logB0 = (uint8_t)(31 - __builtin_clz((unsigned)Bt));
-                    tk.n_b0 = (uint16_t)n_b;
+                    OgXform xf;
+                    int recombine, time_divide, B0;
+                    og_make_xform(n, B, bd.tf_change, &xf, &recombine, &time_divide, &B0);
+                    tk.hm = (uint8_t)xf.hm; tk.slog = (uint8_t)xf.slog; tk.n0p = (uint16_t)xf.n0p;
+                    tk.m = (uint8_t)(recombine + time_divide);
                     if (!chain) {
                         int cm = (int)L.band_cm[slot][i];       // fill leaves of such a task are dead: the PVQ masks are all
-                        for (int k = 0; k < time_divide; k++) { Bt >>= 1; cm |= cm >> Bt; }
+                        for (int k = 0, Bk = B0; k < time_divide; k++) { Bk >>= 1; cm |= cm >> Bk; }
                         for (int k = 0; k < recombine; k++) cm = L.k.bit_deinterleave[cm];
-                        Bt <<= recombine;
-                        tk.cm = (uint16_t)(cm & ((1 << Bt) - 1));
-                        if (tk.logB0) OG_ATOMIC_OR(&L.stepmask[0], 1u);
-                        if (time_divide) OG_ATOMIC_OR(&L.stepmask[1], (1u << time_divide) - 1u);
-                        if (recombine) OG_ATOMIC_OR(&L.stepmask[2], (1u << recombine) - 1u);
+                        const int Bend = (B0 >> time_divide) << recombine;
+                        tk.cm = (uint16_t)(cm & ((1 << Bend) - 1));
+                        if (xf.hm || xf.slog) OG_ATOMIC_OR(&L.stepmask[0], 1u);
                     }
                 }
                 if (chain || (bd.flags & OG_B_MERGE_NORM)) OG_ATOMIC_OR(&L.stepmask[3], 1u << i);
@@ -352,57 +388,25 @@ OG_DEV void og_celt_bands(OgBandCtx &c)
         const int p = bin - tk.boff;
 
     OG_STAMP_TO(c.cycles, 16)
-    // ---- pass A
-    const uint32_t m_had = L.stepmask[0], m_td = L.stepmask[1], m_rc = L.stepmask[2], m_seq = L.stepmask[3];
-    if (m_had) {                                        // interleave_hadamard (celt/decoder.rs:472-501)
+    // ---- pass A: fused post-processing (see OgXform) of every PVQ-only task, then copy-back + lowband_out
+    const uint32_t m_xf = L.stepmask[0], m_seq = L.stepmask[3];
+    if (m_xf) {
         OG_LANES_BEGIN(tid)
         OG_FOR_TASK_ELEMS(e, tk, p)
-            if (!tk.logB0 || tk.n < 2) continue;
-            const int sh = tk.logB0 + tk.recombine, stride = 1 << sh, n0p = tk.n_b0 >> tk.recombine;
-            const int i = p & (stride - 1), j = p >> sh;
-            const int row = (tk.flags & OG_T_LONG) ? L.k.hadamard[stride - 2 + i] : i;
-            tmp_all[e] = L.X[buf][tk.boff + row * n0p + j];
-        }
-        OG_LANES_END
-        OG_LANES_BEGIN(tid)
-        OG_FOR_TASK_ELEMS(e, tk, p)
-            (void)p;
-            if (!tk.logB0 || tk.n < 2) continue;
-            L.X[buf][bin] = tmp_all[e];
-        }
-        OG_LANES_END
-    }
-    for (int r = 0; (m_td >> r) & 1; r++) {             // undo tf time-division: haar1(x, N_B, B) (celt/decoder.rs:2004-2012)
-        OG_LANES_BEGIN(tid)
-        OG_FOR_TASK_ELEMS(e, tk, p)
-            if (tk.time_divide <= r) continue;
-            const int sh = tk.logB0 - (r + 1), st = 1 << sh;
-            if ((p >> sh) & 1) continue;
-            float *x = &L.X[buf][bin];
-            const float a = x[0], b2 = x[st];
-            x[0] = (a + b2) * 0.70710678118654752440f;
-            x[st] = (a - b2) * 0.70710678118654752440f;
-        }
-        OG_LANES_END
-    }
-    for (int r = 0; (m_rc >> r) & 1; r++) {             // undo recombination: haar1(x, N0 >> k, 1 << k) (:2014-2019)
-        OG_LANES_BEGIN(tid)
-        OG_FOR_TASK_ELEMS(e, tk, p)
-            if (tk.recombine <= r) continue;
-            const int st = 1 << r;
-            if ((p >> r) & 1) continue;
-            float *x = &L.X[buf][bin];
-            const float a = x[0], b2 = x[st];
-            x[0] = (a + b2) * 0.70710678118654752440f;
-            x[st] = (a - b2) * 0.70710678118654752440f;
+            if (!(tk.hm | tk.slog)) continue;
+            OgXform xf;
+            xf.hm = tk.hm; xf.slog = tk.slog; xf.n0p = tk.n0p; xf.had = (tk.flags & OG_T_LONG) != 0;
+            xf.scale = (tk.m & 1 ? 0.70710678118654752440f : 1.f) / (float)(1 << (tk.m >> 1));
+            tmp_all[e] = og_wht_gather(xf, &L.X[buf][tk.boff], p, L.k.hadamard, true);
         }
         OG_LANES_END
     }
     OG_LANES_BEGIN(tid)                                 // lowband_out = sqrt(N0) * x (celt/decoder.rs:2021-2028)
     OG_FOR_TASK_ELEMS(e, tk, p)
         (void)p;
-        if (tk.norm_row == 0xFF) continue;
-        L.u.norm[tk.norm_row][bin - norm_offset] = sqrtf((float)tk.n) * L.X[buf][bin];
+        float v = L.X[buf][bin];
+        if (tk.hm | tk.slog) { v = tmp_all[e]; L.X[buf][bin] = v; }
+        if (tk.norm_row != 0xFF) L.u.norm[tk.norm_row][bin - norm_offset] = sqrtf((float)tk.n) * v;
     }
     for (int i = tid; i < 21; i += OG_WG) {             // collapse masks of the bands pass B will not visit
         if (i < start || i >= end || ((m_seq >> i) & 1)) continue;
