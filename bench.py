@@ -65,9 +65,22 @@ def cpu_baseline(packets, budget_s=12.0):
         done = list(ex.map(work, range(sample_streams)))
     dt = time.perf_counter() - t0
     frames = sum(done)
-    return {"value": round(frames * FRAME_S / dt, 2), "unit": "audio-s/s", "cores": cores, "kind": "port",
-            "sample": f"{sample_streams} of the same synthetic streams x {max(done)} frames ({frames} frames) on the CPU oracle "
-                      f"(oracle/liborc.so, scalar C, -O2), one stream per thread"}
+    out = {"value": round(frames * FRAME_S / dt, 2), "unit": "audio-s/s", "cores": cores, "kind": "port",
+           "sample": f"{sample_streams} of the same synthetic streams x {max(done)} frames ({frames} frames) on the CPU oracle "
+                     f"(oracle/liborc.so, scalar C, -O2), one stream per thread"}
+    # BASELINE configs[0]: RFC vector 01 (CELT FB stereo) on one core.  The Rust decoder cannot decode it (no toolchain
+    # here, and its CELT path stops at the first split band), so this too is the oracle.
+    try:
+        _, pk = orc.load_vectors(ids=[1])[1]
+        d = orc.Decoder(2)
+        t0 = time.perf_counter()
+        samples = sum(len(d.decode(p)) for p in pk)
+        dt1 = time.perf_counter() - t0
+        out["c1_vector01"] = {"value": round(samples / 48000.0 / dt1, 2), "unit": "audio-s/s", "cores": 1,
+                              "sample": f"testvector01, {len(pk)} packets, {samples / 48000.0:.1f} s of audio"}
+    except Exception as e:                                  # the fixture is optional for the headline number
+        out["c1_vector01"] = {"error": str(e)}
+    return out
 
 
 def main():

@@ -153,16 +153,19 @@ typedef struct {               /* optional stage dumps for parity tests; any poi
  * the launches too; exposed so a caller can pay the allocation before graph capture. */
 int opusgpu_init(int device);
 
-/* CELT, two kernels per launch:
- *   K1  og_pvq_kernel: one lane per PVQ leaf (refs[], sorted by size across the whole batch so that the lanes of a
- *       wavefront run the same trip counts): CWRS index -> pulses, normalise, spreading rotation, collapse mask
- *       (celt/decoder.rs:541-786); writes the shaped coefficients to the `work` scratch.
+/* CELT, three kernel stages per launch:
+ *   K1  og_pvq_kernel (one launch per leaf size class): one lane per PVQ leaf (refs[], sorted by size across the whole
+ *       batch so that the lanes of a wavefront run the same trip counts): CWRS index -> pulses, normalise, spreading
+ *       rotation, collapse mask (celt/decoder.rs:541-786); writes the shaped coefficients to the `work` scratch.
+ *   plan  og_plan_kernel: one lane per frame: the integer half of decode_bands (celt/decoder.rs:2037-2220): which
+ *       zero-pulse leaves fold / make noise and with which seed, collapse masks, dependency levels of the bands.
  *   K2+K3 og_celt_kernel: one workgroup per frame: fold / noise fill, Haar + Hadamard reordering, stereo merge
- *       (celt/decoder.rs:453-538, :788-827, :1601-1663, :1994-2220), then the synthesis the reference lacks
+ *       (celt/decoder.rs:453-538, :788-827, :1601-1663, :1994-2032), then the synthesis the reference lacks
  *       (anti-collapse, denormalise, IMDCT, TDAC window, comb post-filter, de-emphasis), PCM out.
  * Frames [i*frames_per_group, (i+1)*frames_per_group) must belong to one stream, in time order.
- * `work` = opusgpu_celt_work_bytes(nframes) bytes of device scratch, zero-filled ONCE by the caller; the kernels leave
- * it zero-filled again.  Launches that share `work` must be ordered on one stream. */
+ * `work` = opusgpu_celt_work_bytes(nframes) bytes of device scratch (one block per frame, so a buffer sized for the
+ * largest launch serves smaller ones), zero-filled ONCE by the caller; the kernels hand the parts that must start at
+ * zero back zero-filled.  Launches that share `work` must be ordered on one stream. */
 size_t opusgpu_celt_work_bytes(uint32_t nframes);
 /* Host helper: lists the PVQ leaves (K > 0) of hdr[0..nframes) in decreasing size N and counts them per size class
  * (N > 64, 24 < N <= 64, 8 < N <= 24, N <= 8): K1 runs one launch per class so that the many small leaves do not pay

@@ -37,7 +37,7 @@ def build_lib(force=False, verbose=False):
         return OUT
     objdir = os.path.join(ROOT, "build", "obj")
     os.makedirs(objdir, exist_ok=True)
-    common = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function", "-Wno-missing-braces"]
+    common = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-strict-aliasing", "-Wall", "-Wno-unused-function", "-Wno-missing-braces"]
     objs = []
     for s in srcs:
         o = os.path.join(objdir, s.replace("/", "_") + ".o")
@@ -62,7 +62,7 @@ def build_emu():
     srcs.append(os.path.join(CSRC, "host", "silk_tables.cpp"))
     if not _newer(out, _all_inputs() + srcs):
         return out
-    subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fno-strict-aliasing", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
                            "-Wno-unused-variable", "-Wno-missing-braces", "-o", out] + srcs)
     return out
 

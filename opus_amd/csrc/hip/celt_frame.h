@@ -16,16 +16,11 @@
 #include "../../../include/opusgpu.h"
 
 #include "celt_frame_types.h"
+#include "celt_plan.h"
 
 struct alignas(16) OgF4 { float x, y, z, w; };
 
-struct OgTask {                       // one quant_band call = (band, buffer); 16 bytes in LDS
-    uint16_t boff, n;                 // first bin in the channel buffer, width
-    uint16_t n0p, cm;                 // OgXform.n0p; final collapse mask (PVQ-only tasks)
-    uint8_t buf, flags, hm, slog;     // OgXform.hm / .slog
-    uint8_t m, norm_row, pad0, pad1;  // popcount(hm); norm row lowband_out goes to (0xFF = none)
-};
-enum { OG_T_ACTIVE = 1, OG_T_CHAIN = 2, OG_T_LONG = 8 };
+#define OG_LDS_OPS 48                 // fill ops staged in LDS per frame (C2 frames carry ~5); the rest stay in HBM
 
 struct alignas(16) OgCeltLds {
     float X[2][960];                  // coefficients (bands) -> MDCT bins -> FFT ping buffer -> de-emphasised PCM
@@ -35,25 +30,22 @@ struct alignas(16) OgCeltLds {
     } u;
     union {
         float out[2][OG_OUTLEN];      // [history | frame | tail] time-domain buffer
-        struct {
-            float scratch[176];       // transformed lowband copy
-            float tmp[176];           // Hadamard reorder bounce buffer
+        struct {                      // band-walk lifetime (the time buffer is idle until denormalisation)
+            float lb_all[2 * 960];    // transformed copies of the folding sources, laid out like X
+            float tmp_all[2 * 960];   // bounce buffer of the fused reorder
         } b;
     } v;
     OgCeltConst k;                    // LDS copy of the small constant tables
-    uint32_t band_cm[2][24];
-    OgTask task[44];
-    uint32_t stepmask[4];             // which lock-step rounds / sequential bands the frame needs
+    uint32_t lcg_a[184], lcg_c[184];  // noise-seed jump tables (copy of OgCeltTables')
+    alignas(16) uint32_t plan_head[OG_PLAN_HEAD_BYTES / 4];   // OgBandPlan up to (not including) .op
+    OgFillOp ops[OG_LDS_OPS];
     uint8_t bin2band[960];
-    float mrg[21][8][2];              // stereo merge partial sums
+    float mrg[21][12][2];             // stereo merge partial sums
     alignas(16) float mg[24][4];      // per-band merge matrix
     float gband[2][24];               // denormalisation gains
-          // OR of the PVQ leaves' collapse masks per (buffer, band), filled by K1
     OgCeltHdr hdr;                    // the frame's side-info, staged once (uniform control code reads it from LDS)
-    OgCeltLeaf leaves[OG_LDS_LEAVES];
-    uint8_t collapse[2][24];
     float red[4];
-    float carry[2][64];
+    float carry[OG_WG / 64][64];      // de-emphasis carries; per-wave partial sums during the band walk
 };
 
 #include "celt_pvq.h"
@@ -81,8 +73,20 @@ OG_DEV void og_uniform_dot2(const float *x, const float *y, int n, float *xy, fl
     *xy = og_wave_sum(a);
     *yy = og_wave_sum(b);
 }
+// sum of part[0..63] inside a single-wave section, same association order on the GPU and in the emulation
+OG_DEV float og_wave_tree_sum(const float *part) { return og_wave_sum(part[threadIdx.x & 63]); }
 #else
 #define OG_BARRIER
+OG_DEV float og_wave_tree_sum(const float *part)
+{
+    float v[64], w[64];
+    for (int i = 0; i < 64; i++) v[i] = part[i];
+    for (int m = 32; m; m >>= 1) {
+        for (int i = 0; i < 64; i++) w[i] = v[i] + v[i ^ m];
+        for (int i = 0; i < 64; i++) v[i] = w[i];
+    }
+    return v[0];
+}
 OG_DEV float og_uniform_sumsq(const float *x, int n)
 {
     float e = 0.f;
@@ -100,38 +104,6 @@ OG_DEV void og_uniform_dot2(const float *x, const float *y, int n, float *xy, fl
 
 // ------------------------------------------------------------------------------------------------
 // K2 building blocks: workgroup-collective vector operations on LDS (each ends in a barrier).
-OG_DEV void og_wg_haar1(float *x, int n0, int stride)   // celt/decoder.rs:453-466
-{
-    const float r = 0.70710678118654752440f;
-    const int sh = __builtin_ctz((unsigned)stride), total = (n0 >> 1) * stride;
-    OG_LANES_BEGIN(tid)
-    for (int p = tid; p < total; p += OG_WG) {
-        int i = p & (stride - 1), j = p >> sh;
-        float a = x[stride * 2 * j + i], b = x[stride * (2 * j + 1) + i];
-        x[stride * 2 * j + i] = (a + b) * r;
-        x[stride * (2 * j + 1) + i] = (a - b) * r;
-    }
-    OG_LANES_END
-}
-
-// celt/decoder.rs:472-538.  inverse = 0: deinterleave (frequency order -> block order), 1: interleave.
-OG_DEV void og_wg_hadamard_reorder(float *x, float *tmp, int n0, int stride, int hadamard, int inverse, const uint8_t *ordery)
-{
-    const int sh = __builtin_ctz((unsigned)stride), n = n0 * stride;
-    const uint8_t *ord = ordery + stride - 2;
-    OG_LANES_BEGIN(tid)
-    for (int p = tid; p < n; p += OG_WG) {
-        int i = p & (stride - 1), j = p >> sh;
-        int row = hadamard ? ord[i] : i;
-        if (inverse) tmp[j * stride + i] = x[row * n0 + j];
-        else tmp[row * n0 + j] = x[j * stride + i];
-    }
-    OG_LANES_END
-    OG_LANES_BEGIN(tid)
-    for (int p = tid; p < n; p += OG_WG) x[p] = tmp[p];
-    OG_LANES_END
-}
-
 // x *= gain / ||x||  (celt/decoder.rs:788-794)
 OG_DEV void og_wg_renormalize(float *x, int n, float gain)
 {
@@ -148,322 +120,238 @@ OG_DEV void og_wg_renormalize(float *x, int n, float gain)
 #define OG_STAMP_TO(buf, k) {}
 #endif
 #define OG_STAMP(k) OG_STAMP_TO(dbg.cycles, k)
+#if defined(__HIP__)
+#define OG_CYC() ((uint64_t)__builtin_readcyclecounter())
+#else
+#define OG_CYC() ((uint64_t)0)
+#endif
 
 struct OgBandCtx {
     const OgCeltHdr *h;               // staged in LDS
-    const OgCeltLeaf *lv;             // the frame's leaves in HBM (only those beyond OG_LDS_LEAVES are read from there)
+    const OgBandPlan *plan;           // the frame's plan in HBM (only fill ops beyond OG_LDS_OPS are read from there)
     const OgCeltTables *T;
     OgCeltLds *L;
     uint32_t seed;                    // uniform across the workgroup
-    int lm, band;
+    int lm;
     uint64_t *cycles;                 // profiling stamps (may be null)
 };
 
-// The Haar steps of one quant_band call -- tf recombination (celt/decoder.rs:1708-1716, strides 1, 2, 4) and tf
-// time-division (:1722-1740, strides B, 2B, ...) -- are butterflies on distinct bits of the coefficient index, so
-// together they are a Walsh-Hadamard transform over the bit mask `hm`, scaled by 2^(-m/2).  The Hadamard
-// (de)interleave (:472-538) that follows / precedes them is a permutation.  Fused, every output coefficient is one
-// gather of 2^m inputs: a whole pre- or post-processing chain costs one barrier instead of one per step.
-struct OgXform {
-    int hm;                           // index bits the butterflies act on
-    int slog, n0p, had;               // reorder: stride 2^slog (0 = none), row length, natural / ordery rows
-    float scale;                      // 2^(-popcount(hm)/2)
-};
-
-OG_DEV void og_make_xform(int n, int B, int tf_change, OgXform *t, int *recombine_out, int *time_divide_out, int *B0_out)
+// celt/decoder.rs:468-470 HADAMARD_ORDERY for strides 2, 4, 8, 16, one nibble per entry (entry i at bits 4i)
+OG_DEV int og_ordery(int slog, int i)
 {
-    const int long_blocks = B == 1;
-    int n_b = n / B, recombine = tf_change > 0 ? tf_change : 0, time_divide = 0;
-    B >>= recombine;
-    n_b <<= recombine;
-    const int b1 = 31 - __builtin_clz((unsigned)B);
-    while ((n_b & 1) == 0 && tf_change < 0) { B <<= 1; n_b >>= 1; time_divide++; tf_change++; }
-    t->hm = ((1 << recombine) - 1) | (((1 << time_divide) - 1) << b1);
-    t->slog = B > 1 ? (31 - __builtin_clz((unsigned)B)) + recombine : 0;
-    t->n0p = n_b >> recombine;
-    t->had = long_blocks;
-    const int m = recombine + time_divide;
-    t->scale = (m & 1 ? 0.70710678118654752440f : 1.f) / (float)(1 << (m >> 1));
-    *recombine_out = recombine; *time_divide_out = time_divide; *B0_out = B;
+    const uint64_t t = slog == 1 ? 0x01ull : slog == 2 ? 0x1203ull : slog == 3 ? 0x25163407ull : 0x5A2D691E4B3C780Full;
+    return (int)(t >> (4 * i)) & 15;
 }
 
 // where interleave_hadamard takes the value at position d from (= where deinterleave_hadamard puts the value of d)
-OG_DEV int og_reorder(const OgXform &t, int d, const uint8_t *ordery)
+OG_DEV int og_reorder(int slog, int n0p, int had, int d)
 {
-    if (!t.slog) return d;
-    const int S = 1 << t.slog, i = d & (S - 1), j = d >> t.slog;
-    return (t.had ? ordery[S - 2 + i] : i) * t.n0p + j;
+    if (!slog) return d;
+    const int S = 1 << slog, i = d & (S - 1), j = d >> slog;
+    return (had ? og_ordery(slog, i) : i) * n0p + j;
 }
 
-// Walsh-Hadamard gather: scale * sum over s (= p outside hm) of (-1)^popcount(p & s & hm) * src[perm(s)]
-OG_DEV float og_wht_gather(const OgXform &t, const float *src, int p, const uint8_t *ordery, bool permute_src)
+#if defined(__HIP__)
+template <class T> OG_DEV T og_uniform(const T &v)     // load a wave-uniform record into scalar registers
 {
-    float acc = 0.f;
-    int q = 0;
-    do {
-        const int s = (p & ~t.hm) | q;
-        const float v = src[permute_src ? og_reorder(t, s, ordery) : s];
-        acc += (__builtin_popcount((unsigned)(p & q)) & 1) ? -v : v;
-        q = (q - t.hm) & t.hm;
-    } while (q);
-    return acc * t.scale;
+    static_assert(sizeof(T) % 4 == 0, "whole dwords");
+    uint32_t w[sizeof(T) / 4];
+    __builtin_memcpy(w, &v, sizeof(T));
+#pragma unroll
+    for (unsigned k = 0; k < sizeof(T) / 4; k++) w[k] = OG_U32(w[k]);
+    T r;
+    __builtin_memcpy(&r, w, sizeof(T));
+    return r;
+}
+#else
+template <class T> OG_DEV T og_uniform(const T &v) { return v; }
+#endif
+
+// One lock-step transform pass over the tasks of level `lvl`: every lane owns eight (buffer, bin) slots; loads are
+// issued four slots at a time before anything consumes them, so their LDS latencies overlap.
+//   PRE:  lb_all <- Haar steps + deinterleave_hadamard of the folding source (celt/decoder.rs:1708-1768), for the
+//         level's tasks that fold;
+//   !PRE: tmp_all <- interleave_hadamard + the Haar steps that undo time-division and recombination (:1994-2019), for
+//         the level's tasks that have a transform.
+// maxcnt = the largest 2^m among them (uniform loop bound).
+template <bool PRE>
+OG_DEV void og_level_xform(OgCeltLds &L, int lvl, int maxcnt)
+{
+    const float *src = PRE ? &L.u.norm[0][0] : &L.X[0][0];
+    float *dst = PRE ? L.v.b.lb_all : L.v.b.tmp_all;
+    OG_LANES_BEGIN(tid)
+    for (int half = 0; half < 2; half++) {
+        int band[4], sbase[4], base[4], cnt[4], sh[4], slog[4], n0p[4], had[4], pp[4], dsti[4];
+        float acc[4], scale[4];
+        bool ok[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int e = tid + (half * 4 + k) * OG_WG, ec = e < 1920 ? e : 1919;
+            band[k] = L.bin2band[ec >= 960 ? ec - 960 : ec];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int e = tid + (half * 4 + k) * OG_WG, ec = e < 1920 ? e : 1919;
+            const int slot = ec >= 960, bin = ec - 960 * slot;
+            const OgTask tk = ((const OgTask *)L.plan_head)[(band[k] == 255 ? 0 : band[k]) * 2 + slot];
+            const int rc = tk.rctd & 15, td = tk.rctd >> 4, m = rc + td;
+            ok[k] = e < 1920 && band[k] != 255 && (tk.flags & OG_T_ACTIVE) && tk.level == lvl &&
+                    (PRE ? (tk.flags & OG_T_NEED_LB) != 0 : (tk.hm | tk.slog) != 0);
+            const int p = ok[k] ? bin - tk.boff : 0, hm = ok[k] ? tk.hm : 0;
+            pp[k] = p;
+            cnt[k] = hm ? 1 << m : 1;
+            sh[k] = hm ? __builtin_ctz((unsigned)hm) : 0;
+            base[k] = p & ~hm;
+            slog[k] = ok[k] ? tk.slog : 0; n0p[k] = tk.n0p; had[k] = (tk.flags & OG_T_LONG) != 0;
+            scale[k] = hm ? (m & 1 ? 0.70710678118654752440f : 1.f) / (float)(1 << (m >> 1)) : 1.f;
+            if (PRE) {
+                sbase[k] = ok[k] ? ((tk.flags & OG_T_LB_ROW1) ? 800 : 0) + tk.lowpos : 0;
+                dsti[k] = slot * 960 + tk.boff + og_reorder(slog[k], n0p[k], had[k], p);
+            } else {
+                sbase[k] = ok[k] ? slot * 960 + tk.boff : 0;
+                dsti[k] = ec;
+            }
+            acc[k] = 0.f;
+        }
+        for (int j = 0; j < maxcnt; j++) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const bool on = ok[k] && j < cnt[k];
+                const int q = on ? j << sh[k] : 0, sidx = base[k] | q;
+                const float v = src[sbase[k] + (PRE ? sidx : og_reorder(slog[k], n0p[k], had[k], sidx))];
+                const float wgt = on ? ((__builtin_popcount((unsigned)(pp[k] & q)) & 1) ? -1.f : 1.f) : 0.f;
+                acc[k] += wgt * v;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (ok[k]) dst[dsti[k]] = acc[k] * scale[k];
+    }
+    OG_LANES_END
 }
 
-OG_DEV OgCeltLeaf og_leaf(const OgBandCtx &c, int idx) { return idx < OG_LDS_LEAVES ? c.L->leaves[idx] : c.lv[idx]; }
-
-// One quant_band call (celt/decoder.rs:1665-1768 pre, :1601-1663 leaves, :1994-2032 post) on channel
-// buffer x, for the leaves of band `bd` whose OG_L_CH_Y flag equals chy.  PVQ leaves were expanded by K1.
-OG_DEV int og_quant_band(OgBandCtx &c, const OgCeltBand &bd, int chy, float *x, int n, int B, const float *lowband,
-                         float *lowband_out, int fill)
+// One live fill leaf (celt/decoder.rs:1633-1661 + renormalize_vector :788-794), by wave w alone: n <= 176, at most
+// three coefficients per lane, no workgroup barrier.  Ops of one level touch disjoint coefficients.
+OG_DEV void og_fill_op(OgBandCtx &c, int k, int w)
 {
     OgCeltLds &L = *c.L;
-    const int g0 = bd.leaf0 + (chy ? bd.nx : 0), nfill = chy ? bd.fy : bd.fx;     // this buffer's leaf group
-    if (n == 1) {                                       // celt/decoder.rs:1466-1495
-        const float v = og_leaf(c, g0).index ? -1.f : 1.f;
-        OG_LANES_BEGIN(tid)
-        if (tid == 0) {
-            x[0] = v;
-            if (lowband_out) lowband_out[0] = v;
+    const OgFillOp op = k < OG_LDS_OPS ? og_uniform(L.ops[k]) : og_uniform(c.plan->op[k]);
+    float *xl = &L.X[0][0] + op.pos, *part = L.carry[w];
+    const float *lbl = L.v.b.lb_all + op.pos;
+    const uint32_t *la = L.lcg_a, *lc = L.lcg_c;
+    const int nn = op.n;
+    const uint32_t s0 = op.seed;
+    if (!(op.flags & OG_OP_FOLD)) {                     // noise (celt/decoder.rs:1644-1651)
+        OG_WAVE_BEGIN(lane)
+        float e = 0.f;
+        for (int p = lane; p < nn; p += 64) {
+            uint32_t s = la[p + 1] * s0 + lc[p + 1];
+            const float v = (float)((int32_t)s >> 20);
+            xl[p] = v;
+            e += v * v;
         }
-        OG_LANES_END
-        return 1;
-    }
-    const int n0 = n;
-    OgXform xf;
-    int recombine, time_divide, B0;
-    og_make_xform(n, B, bd.tf_change, &xf, &recombine, &time_divide, &B0);
-    for (int k = 0; k < recombine; k++) fill = L.k.bit_interleave[fill & 0xF] | L.k.bit_interleave[fill >> 4] << 2;
-    for (int k = 0, Bk = B >> recombine; k < time_divide; k++, Bk <<= 1) fill |= fill << Bk;
-    const bool need_lowband = lowband && (bd.flags & (chy ? OG_B_FOLD_Y : OG_B_FOLD_X));
-    float *lb = L.v.b.scratch, *tmp = L.v.b.tmp;
-    if (need_lowband) {                                 // Haar steps + deinterleave_hadamard on a copy of the folding source
-        OG_LANES_BEGIN(tid)
-        for (int p = tid; p < n; p += OG_WG) lb[og_reorder(xf, p, L.k.hadamard)] = og_wht_gather(xf, lowband, p, L.k.hadamard, false);
-        OG_LANES_END
-    }
-
-    int cm = (int)L.band_cm[chy ? 1 : 0][c.band];       // PVQ leaves: expanded (and masks collected) by K1
-    for (int l = 0; l < nfill; l++) {                   // fill leaves in decode order (the LCG seed is sequential)
-        const OgCeltLeaf lf = og_leaf(c, g0 + l);
-        const int Bl = 1 << (lf.meta & OG_L_LOGB_MASK), sh = lf.cmshift;
-        // the leaf's share of the quant_band fill: the recursion only shifts it (side halves) or clears it (theta)
-        const int fl = (lf.meta & OG_L_FILL_DEAD) ? 0 : (fill >> sh) & ((1 << Bl) - 1);
-        if (!fl) continue;                              // x stays zero (celt/decoder.rs:1640-1643)
-        float *xl = x + lf.off;
-        const int nn = lf.n;
-        const uint32_t s0 = c.seed;
-        const uint32_t *la = c.T->lcg_a, *lc = c.T->lcg_c;
-        if (!(lf.meta & OG_L_HAS_LOWBAND)) {            // noise (celt/decoder.rs:1644-1651)
-            OG_LANES_BEGIN(tid)
-            for (int p = tid; p < nn; p += OG_WG) {
-                uint32_t s = la[p + 1] * s0 + lc[p + 1];
-                xl[p] = (float)((int32_t)s >> 20);
-            }
-            OG_LANES_END
-            cm |= ((1 << Bl) - 1) << sh;
-        } else {                                        // fold the lower band in (celt/decoder.rs:1652-1659)
-            const float *lbl = lb + lf.off;
-            OG_LANES_BEGIN(tid)
-            for (int p = tid; p < nn; p += OG_WG) {
-                uint32_t s = la[p + 1] * s0 + lc[p + 1];
-                xl[p] = lbl[p] + ((s & 0x8000) ? 1.f / 256 : -1.f / 256);
-            }
-            OG_LANES_END
-            cm |= fl << sh;
+        part[lane] = e;
+        OG_WAVE_END
+    } else {                                            // fold the lower band in (celt/decoder.rs:1652-1659)
+        OG_WAVE_BEGIN(lane)
+        float e = 0.f;
+        for (int p = lane; p < nn; p += 64) {
+            uint32_t s = la[p + 1] * s0 + lc[p + 1];
+            const float v = lbl[p] + ((s & 0x8000) ? 1.f / 256 : -1.f / 256);
+            xl[p] = v;
+            e += v * v;
         }
-        c.seed = la[nn] * s0 + lc[nn];
-        og_wg_renormalize(xl, nn, lf.gain);
+        part[lane] = e;
+        OG_WAVE_END
     }
-
-    // interleave_hadamard + the Haar steps that undo time-division and recombination (celt/decoder.rs:1994-2019),
-    // fused; lowband_out = sqrt(N0) * x (:2021-2028) rides on the copy-back
-    for (int k = 0, Bk = B0; k < time_divide; k++) { Bk >>= 1; cm |= cm >> Bk; }
-    for (int k = 0; k < recombine; k++) cm = L.k.bit_deinterleave[cm];
-    const int Bend = (B0 >> time_divide) << recombine;
-    if (xf.hm || xf.slog) {
-        OG_LANES_BEGIN(tid)
-        for (int p = tid; p < n; p += OG_WG) tmp[p] = og_wht_gather(xf, x, p, L.k.hadamard, true);
-        OG_LANES_END
-        const float sq = sqrtf((float)n0);
-        OG_LANES_BEGIN(tid)
-        for (int p = tid; p < n; p += OG_WG) {
-            const float v = tmp[p];
-            x[p] = v;
-            if (lowband_out) lowband_out[p] = sq * v;
-        }
-        OG_LANES_END
-    } else if (lowband_out) {
-        const float sq = sqrtf((float)n0);
-        OG_LANES_BEGIN(tid)
-        for (int p = tid; p < n0; p += OG_WG) lowband_out[p] = sq * x[p];
-        OG_LANES_END
-    }
-    return cm & ((1 << Bend) - 1);
+    const float g = op.gain / sqrtf(1e-15f + og_wave_tree_sum(part));
+    OG_WAVE_BEGIN(lane)
+    for (int p = lane; p < nn; p += 64) xl[p] *= g;
+    OG_WAVE_END
 }
 
-// celt/decoder.rs:2037-2220 with the range-decoder half removed (the host ran it).
-//
-// The reference walks the bands one after the other, but only two things are truly sequential: folding reads the
-// finished lower bands (`norm`), and the noise seed runs through the fill leaves in decode order.  Everything a
-// quant_band call does to a band whose leaves are all PVQ-coded -- Hadamard interleave, the Haar steps that undo
-// tf time-division / recombination, lowband_out -- depends on that band alone.  So:
-//   pass A  all such (band, buffer) tasks advance in lock-step, one barrier per step for the whole frame;
-//   pass B  the few tasks with live fill leaves run in band order through og_quant_band (as the reference does);
-//   pass C  the mid/side -> left/right merges of all joint bands, in lock-step (norm keeps the mid, so nothing
-//           downstream of a band needs its merged form).
+// celt/decoder.rs:2037-2220 with the range-decoder half removed (the host ran it) and the integer recurrences
+// (fill masks, noise seeds, collapse masks, dependency levels) already resolved by the plan kernel (celt_plan.h).
+// What is left is sample work, level by level:
+//   level 0   every quant_band call without fill leaves: fused reorder + lowband_out, two lock-step regions;
+//   level l   calls with fill leaves whose folding sources are complete: transformed lowband copies (one region), the
+//             fill leaves themselves (one per wave at a time), then the same two regions as level 0;
+//   merges    the mid/side -> left/right rotations of all joint bands in lock-step (norm keeps the mid, so nothing
+//             downstream of a band needs its merged form).
 OG_DEV void og_celt_bands(OgBandCtx &c)
 {
     const OgCeltHdr *h = c.h;
     OgCeltLds &L = *c.L;
+    const OgBandPlan *PL = (const OgBandPlan *)L.plan_head;      // head fields only
+    const OgTask *tasks = (const OgTask *)L.plan_head;
     const int lm = c.lm, M = 1 << lm, start = h->start, end = h->end;
     const int C = (h->flags & OG_F_STEREO) ? 2 : 1;
-    const int B = (h->flags & OG_F_TRANSIENT) ? M : 1;
     const int norm_offset = M * L.k.ebands[start];
-    float *tmp_all = &L.v.out[1][0];                    // [2][960] bounce buffer for the lock-step Hadamard reorder
-
-    // ---- set-up: one lane per (band, buffer) task; another 22 lanes build the bin -> band map
-    OG_LANES_BEGIN(tid)
-    for (int t = tid; t < 42; t += OG_WG) {
-        const int i = t >> 1, slot = t & 1;
-        OgTask tk;
-        tk.boff = tk.n = tk.n0p = tk.cm = 0;
-        tk.buf = (uint8_t)slot; tk.flags = 0; tk.hm = tk.slog = tk.m = 0; tk.norm_row = 0xFF; tk.pad0 = tk.pad1 = 0;
-        if (i >= start && i < end) {
-            const OgCeltBand bd = h->band[i];
-            const int n = M * L.k.width[i], boff = M * L.k.ebands[i];
-            const bool dual = (bd.flags & OG_B_DUAL) != 0;
-            const int nfill = slot ? bd.fy : bd.fx;
-            bool active, chain = false;
-            int norm_row = -1;
-            if (C == 1) { active = slot == 0; norm_row = 0; chain = nfill > 0; }
-            else if (dual) { active = true; norm_row = slot; chain = nfill > 0; }
-            else if (n == 1) { active = true; norm_row = slot == 0 ? 0 : -1; }
-            else if (n == 2) { active = slot == ((bd.flags & OG_B_N2SWAP) ? 1 : 0); norm_row = 0; chain = nfill > 0; }
-            else { active = true; norm_row = slot == 0 ? 0 : -1; chain = slot == 0 && nfill > 0 && !(bd.flags & OG_B_MIDFILL0); }
-            if (bd.flags & OG_B_LAST) norm_row = -1;
-            if (active) {
-                tk.boff = (uint16_t)boff; tk.n = (uint16_t)n;
-                tk.flags = OG_T_ACTIVE | (chain ? OG_T_CHAIN : 0) | (B == 1 ? OG_T_LONG : 0);
-                tk.norm_row = (uint8_t)norm_row;
-                if (n == 1) {                           // decode_band_1 (celt/decoder.rs:1466-1495)
-                    const OgCeltLeaf lf = og_leaf(c, bd.leaf0 + (slot ? bd.nx : 0));
-                    L.X[slot][boff] = lf.index ? -1.f : 1.f;
-                    tk.cm = 1;
-                } else {
-                    OgXform xf;
-                    int recombine, time_divide, B0;
-                    og_make_xform(n, B, bd.tf_change, &xf, &recombine, &time_divide, &B0);
-                    tk.hm = (uint8_t)xf.hm; tk.slog = (uint8_t)xf.slog; tk.n0p = (uint16_t)xf.n0p;
-                    tk.m = (uint8_t)(recombine + time_divide);
-                    if (!chain) {
-                        int cm = (int)L.band_cm[slot][i];       // fill leaves of such a task are dead: the PVQ masks are all
-                        for (int k = 0, Bk = B0; k < time_divide; k++) { Bk >>= 1; cm |= cm >> Bk; }
-                        for (int k = 0; k < recombine; k++) cm = L.k.bit_deinterleave[cm];
-                        const int Bend = (B0 >> time_divide) << recombine;
-                        tk.cm = (uint16_t)(cm & ((1 << Bend) - 1));
-                        if (xf.hm || xf.slog) OG_ATOMIC_OR(&L.stepmask[0], 1u);
-                    }
-                }
-                if (chain || (bd.flags & OG_B_MERGE_NORM)) OG_ATOMIC_OR(&L.stepmask[3], 1u << i);
-            } else if (bd.flags & OG_B_MERGE_NORM) {
-                OG_ATOMIC_OR(&L.stepmask[3], 1u << i);
-            }
-        }
-        L.task[t] = tk;
-    }
-    if (tid >= 64 && tid < 64 + 22) {
-        const int b = tid - 64;
-        const int lo = b < 21 ? M * L.k.ebands[b] : M * 100, hi = b < 21 ? M * L.k.ebands[b + 1] : 960;
-        for (int j = lo; j < hi; j++) L.bin2band[j] = (uint8_t)(b < 21 ? b : 255);
-    }
-    OG_LANES_END
-
-#define OG_FOR_TASK_ELEMS(e, tk, p)                                                                                  \
-    for (int e = tid; e < 1920; e += OG_WG) {                                                                        \
-        const int buf = e >= 960, bin = e - 960 * buf;                                                               \
-        const int band_ = L.bin2band[bin];                                                                           \
-        if (band_ == 255) continue;                                                                                  \
-        const OgTask tk = L.task[band_ * 2 + buf];                                                                   \
-        if ((tk.flags & (OG_T_ACTIVE | OG_T_CHAIN)) != OG_T_ACTIVE) continue;                                        \
-        const int p = bin - tk.boff;
+    float *Xf = &L.X[0][0];
 
     OG_STAMP_TO(c.cycles, 16)
-    // ---- pass A: fused post-processing (see OgXform) of every PVQ-only task, then copy-back + lowband_out
-    const uint32_t m_xf = L.stepmask[0], m_seq = L.stepmask[3];
-    if (m_xf) {
-        OG_LANES_BEGIN(tid)
-        OG_FOR_TASK_ELEMS(e, tk, p)
-            if (!(tk.hm | tk.slog)) continue;
-            OgXform xf;
-            xf.hm = tk.hm; xf.slog = tk.slog; xf.n0p = tk.n0p; xf.had = (tk.flags & OG_T_LONG) != 0;
-            xf.scale = (tk.m & 1 ? 0.70710678118654752440f : 1.f) / (float)(1 << (tk.m >> 1));
-            tmp_all[e] = og_wht_gather(xf, &L.X[buf][tk.boff], p, L.k.hadamard, true);
-        }
-        OG_LANES_END
-    }
-    OG_LANES_BEGIN(tid)                                 // lowband_out = sqrt(N0) * x (celt/decoder.rs:2021-2028)
-    OG_FOR_TASK_ELEMS(e, tk, p)
-        (void)p;
-        float v = L.X[buf][bin];
-        if (tk.hm | tk.slog) { v = tmp_all[e]; L.X[buf][bin] = v; }
-        if (tk.norm_row != 0xFF) L.u.norm[tk.norm_row][bin - norm_offset] = sqrtf((float)tk.n) * v;
-    }
-    for (int i = tid; i < 21; i += OG_WG) {             // collapse masks of the bands pass B will not visit
-        if (i < start || i >= end || ((m_seq >> i) & 1)) continue;
-        const int cm0 = L.task[2 * i].cm, cm1 = L.task[2 * i + 1].cm;
-        const bool dual = (h->band[i].flags & OG_B_DUAL) != 0;
-        L.collapse[0][i] = (uint8_t)(dual || C == 1 ? cm0 : (cm0 | cm1));
-        L.collapse[C - 1][i] = (uint8_t)(dual ? cm1 : C == 1 ? cm0 : (cm0 | cm1));
-    }
-    OG_LANES_END
-
-    OG_STAMP_TO(c.cycles, 17)
-    // ---- pass B: bands with live fill leaves (or the dual -> intensity switch), in order
-    for (int i = start; i < end; i++) {
-        if (!((m_seq >> i) & 1)) continue;
-        const OgCeltBand bd = h->band[i];
-        c.band = i;
-        const int boff = M * L.k.ebands[i], n = M * L.k.width[i];
-        const bool last = (bd.flags & OG_B_LAST) != 0;
-        const OgTask t0 = L.task[2 * i], t1 = L.task[2 * i + 1];
-        int x_cm, y_cm;
-        if (bd.lowband != 0xFF) {
-            x_cm = y_cm = 0;
-            for (int f = bd.fold_lo; f < bd.fold_hi; f++) { x_cm |= L.collapse[0][f]; y_cm |= L.collapse[C - 1][f]; }
-        } else {
-            x_cm = y_cm = (1 << B) - 1;
-        }
-        if (bd.flags & OG_B_MERGE_NORM) {               // dual -> intensity switch (celt/decoder.rs:2133-2138)
-            const int cnt = boff - norm_offset;
+    const int nlevels = (int)OG_U32(PL->nlevels), merge_level = (int)OG_U32(PL->merge_level);
+    for (int lvl = 0; lvl <= nlevels; lvl++) {
+        if (lvl == merge_level) {                       // dual -> intensity switch (celt/decoder.rs:2133-2138)
+            const int cnt = PL->merge_cnt;
             OG_LANES_BEGIN(tid)
             for (int p = tid; p < cnt; p += OG_WG) L.u.norm[0][p] = 0.5f * (L.u.norm[0][p] + L.u.norm[1][p]);
             OG_LANES_END
         }
-        const float *lb0 = bd.lowband != 0xFF ? L.u.norm[0] + bd.lowband * M : nullptr;
-        const float *lb1 = bd.lowband != 0xFF ? L.u.norm[1] + bd.lowband * M : nullptr;
-        float *out0 = last ? nullptr : L.u.norm[0] + boff - norm_offset;
-        float *out1 = last ? nullptr : L.u.norm[1] + boff - norm_offset;
-        int cm0 = t0.cm, cm1 = t1.cm;
-        const bool dual = (bd.flags & OG_B_DUAL) != 0;
-        const int fill0 = dual ? x_cm : (x_cm | y_cm), fill1 = dual ? y_cm : (x_cm | y_cm);
-        if (t0.flags & OG_T_CHAIN) cm0 = og_quant_band(c, bd, 0, L.X[0] + boff, n, B, lb0, out0, fill0);
-        if (t1.flags & OG_T_CHAIN) cm1 = og_quant_band(c, bd, 1, L.X[1] + boff, n, B, dual ? lb1 : lb0, dual ? out1 : out0, fill1);
-        L.collapse[0][i] = (uint8_t)(dual || C == 1 ? cm0 : (cm0 | cm1));
-        L.collapse[C - 1][i] = (uint8_t)(dual ? cm1 : C == 1 ? cm0 : (cm0 | cm1));
+        const int maxcnt = (int)OG_U32(PL->lvl_maxcnt[lvl]);
+        if (lvl > 0) {
+            og_level_xform<true>(L, lvl, maxcnt ? maxcnt : 1);
+            OG_WAVES_BEGIN(w)
+            const int k1 = (int)OG_U32(PL->op_start[lvl + 1]);
+            for (int k = (int)OG_U32(PL->op_start[lvl]) + w; k < k1; k += OG_WG / 64) og_fill_op(c, k, w);
+            OG_WAVES_END
+        }
+        if (maxcnt) og_level_xform<false>(L, lvl, maxcnt);
+        OG_LANES_BEGIN(tid)                             // copy-back + lowband_out = sqrt(N0) * x (celt/decoder.rs:2021-2028)
+        for (int half = 0; half < 2; half++) {
+            int band[4];
+            float xv[4], tv[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int e = tid + (half * 4 + k) * OG_WG, ec = e < 1920 ? e : 1919;
+                band[k] = L.bin2band[ec >= 960 ? ec - 960 : ec];
+                xv[k] = Xf[ec];
+                tv[k] = L.v.b.tmp_all[ec];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int e = tid + (half * 4 + k) * OG_WG, ec = e < 1920 ? e : 1919;
+                const int slot = ec >= 960, bin = ec - 960 * slot;
+                const OgTask tk = tasks[(band[k] == 255 ? 0 : band[k]) * 2 + slot];
+                if (e >= 1920 || band[k] == 255 || !(tk.flags & OG_T_ACTIVE) || tk.level != lvl) continue;
+                float v = xv[k];
+                if (tk.hm | tk.slog) { v = tv[k]; Xf[ec] = v; }
+                if (tk.norm_row != 0xFF) L.u.norm[tk.norm_row][bin - norm_offset] = sqrtf((float)tk.n) * v;
+            }
+        }
+        OG_LANES_END
+        if (lvl == 0) OG_STAMP_TO(c.cycles, 17)
     }
-    OG_BARRIER
 
     OG_STAMP_TO(c.cycles, 18)
-    // ---- pass C: stereo merges (celt/decoder.rs:796-827 + the N == 2 case :1826-1862), all joint bands at once
+    // ---- merges: stereo_merge (celt/decoder.rs:796-827) + the N == 2 case (:1826-1862), all joint bands at once
     if (C == 2) {
         OG_LANES_BEGIN(tid)
-        if (tid < 21 * 8) {
-            const int i = tid >> 3, sub = tid & 7;
+        if (tid < 21 * 12) {
+            const int i = tid / 12, sub = tid - 12 * i;
             const int n = M * L.k.width[i];
             float xy = 0.f, yy = 0.f;
             if (i >= start && i < end && (h->band[i].flags & OG_B_JOINT) && n > 2) {
                 const float *x = L.X[0] + M * L.k.ebands[i], *y = L.X[1] + M * L.k.ebands[i];
-                for (int p = sub; p < n; p += 8) { xy += x[p] * y[p]; yy += y[p] * y[p]; }
+                float xs[15], ys[15];
+#pragma unroll
+                for (int q = 0; q < 15; q++) {          // n <= 176 = 12 * 14 + 8
+                    const int p = sub + 12 * q < n ? sub + 12 * q : 0;
+                    xs[q] = x[p]; ys[q] = y[p];
+                }
+#pragma unroll
+                for (int q = 0; q < 15; q++)
+                    if (sub + 12 * q < n) { xy += xs[q] * ys[q]; yy += ys[q] * ys[q]; }
             }
             L.mrg[i][sub][0] = xy;
             L.mrg[i][sub][1] = yy;
@@ -490,7 +378,7 @@ OG_DEV void og_celt_bands(OgBandCtx &c)
                     t = x[1]; x[1] = t - y[1]; y[1] = inv * (t + y[1]);
                 } else {
                     float xp = 0.f, sd = 0.f;
-                    for (int q = 0; q < 8; q++) { xp += L.mrg[i][q][0]; sd += L.mrg[i][q][1]; }
+                    for (int q = 0; q < 12; q++) { xp += L.mrg[i][q][0]; sd += L.mrg[i][q][1]; }
                     xp *= mid;
                     const float e = mid * mid + sd, e0 = e - 2.f * xp, e1 = e + 2.f * xp;
                     if (e0 < 6e-4f || e1 < 6e-4f) {     // degenerate: y = x
@@ -505,17 +393,24 @@ OG_DEV void og_celt_bands(OgBandCtx &c)
         }
         OG_LANES_END
         OG_LANES_BEGIN(tid)
-        for (int bin = tid; bin < 960; bin += OG_WG) {
-            const int i = L.bin2band[bin];
-            if (i == 255) continue;
-            const OgF4 m4 = *(const OgF4 *)L.mg[i];
-            const float x = L.X[0][bin], y = L.X[1][bin];
-            L.X[0][bin] = m4.x * x + m4.y * y;
-            L.X[1][bin] = m4.z * x + m4.w * y;
+        int band[4];
+        float xv[4], yv[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int bin = tid + k * OG_WG < 960 ? tid + k * OG_WG : 959;
+            band[k] = L.bin2band[bin]; xv[k] = L.X[0][bin]; yv[k] = L.X[1][bin];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int bin = tid + k * OG_WG;
+            if (bin >= 960 || band[k] == 255) continue;
+            const OgF4 m4 = *(const OgF4 *)L.mg[band[k]];
+            L.X[0][bin] = m4.x * xv[k] + m4.y * yv[k];
+            L.X[1][bin] = m4.z * xv[k] + m4.w * yv[k];
         }
         OG_LANES_END
     }
-#undef OG_FOR_TASK_ELEMS
+    c.seed = PL->seed_out;
     OG_STAMP_TO(c.cycles, 19)
 }
 
@@ -525,7 +420,7 @@ OG_DEV void og_anti_collapse(OgBandCtx &c)
     const OgCeltHdr *h = c.h;
     OgCeltLds &L = *c.L;
     const int lm = c.lm, C = (h->flags & OG_F_STEREO) ? 2 : 1;
-    const uint32_t *la = c.T->lcg_a, *lc = c.T->lcg_c;
+    const uint32_t *la = c.L->lcg_a, *lc = c.L->lcg_c;
     for (int i = h->start; i < h->end; i++) {
         const int n0 = L.k.width[i];
         const int depth = h->pulses_depth[i];
@@ -539,7 +434,7 @@ OG_DEV void og_anti_collapse(OgBandCtx &c)
             if (r > thresh) r = thresh;
             r *= sqrt_1;
             float *x = L.X[ch] + (L.k.ebands[i] << lm);
-            const int mask = L.collapse[ch][i];
+            const int mask = ((const OgBandPlan *)L.plan_head)->collapse[ch][i];
             bool renorm = false;
             for (int k = 0; k < (1 << lm); k++) {
                 if (mask & (1 << k)) continue;
@@ -626,11 +521,11 @@ OG_DEV void og_wg_fft_stage(const OgCf *src, OgCf *dst, int n, int nch, int bloc
     OG_LANES_END
 }
 
-// RFC 6716 celt.c comb_filter, in place, for both channels; y points at sample 0 of channel 0 inside
-// L.v.out, channel stride OG_OUTLEN.  The recursion reaches back >= 13 samples, so `step` samples are
-// independent at a time.
-OG_DEV void og_wg_comb_filter(float *y0, int nch, int T0, int T1, int n, float g0, float g1, int tap0, int tap1,
-                              const float *window, const float (*taps)[4])
+// RFC 6716 celt.c comb_filter, in place, for one channel by one wave (inside an OG_WAVES section): y points at the
+// channel's sample 0 inside L.v.out.  The recursion reaches back >= 13 samples, so `step` samples are independent at a
+// time; the steps are ordered by the wave's own LDS ordering, no workgroup barrier.
+OG_DEV void og_wave_comb_filter(float *y, int T0, int T1, int n, float g0, float g1, int tap0, int tap1,
+                                const float *window, const float (*taps)[4])
 {
     if (g0 == 0.f && g1 == 0.f) return;
     if (T0 < 15) T0 = 15;
@@ -639,15 +534,12 @@ OG_DEV void og_wg_comb_filter(float *y0, int nch, int T0, int T1, int n, float g
     const float g10 = g1 * taps[tap1][0], g11 = g1 * taps[tap1][1], g12 = g1 * taps[tap1][2];
     const int overlap = (g0 == g1 && T0 == T1 && tap0 == tap1) ? 0 : 120;
     const int stop = g1 == 0.f ? overlap : n;          // with g1 == 0 only the cross-fade runs
-    const int lanes = OG_WG / 2;                       // lanes per channel
     int step = (T0 < T1 ? T0 : T1) - 2;
-    if (step > lanes) step = lanes;
+    if (step > 128) step = 128;
     for (int i0 = 0; i0 < stop; i0 += step) {
         const int i1 = i0 + step < stop ? i0 + step : stop;
-        OG_LANES_BEGIN(tid)
-        const int ch = tid / lanes, i = i0 + (tid - ch * lanes);
-        if (ch < nch && i < i1) {
-            float *y = y0 + ch * OG_OUTLEN;
+        OG_WAVE_BEGIN(lane)
+        for (int i = i0 + lane; i < i1; i += 64) {
             if (i < overlap) {
                 const float f = window[i] * window[i];
                 y[i] = y[i] + ((1.f - f) * g00) * y[i - T0]
@@ -660,45 +552,42 @@ OG_DEV void og_wg_comb_filter(float *y0, int nch, int T0, int T1, int n, float g
                 y[i] = y[i] + g10 * y[i - T1] + g11 * (y[i - T1 + 1] + y[i - T1 - 1]) + g12 * (y[i - T1 + 2] + y[i - T1 - 2]);
             }
         }
-        OG_LANES_END
+        OG_WAVE_END
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // The whole frame.  Uniform arguments; every lane of the workgroup calls it.
 // `dbg` pointers are already offset to this frame (any may be null).
-OG_DEV void og_celt_frame(const OgCeltHdr *hg, const OgCeltLeaf *leaves_base, const OgCeltTables *T, OgCeltState *states,
-                          float *pcm_base, size_t pcm_stride, OgCeltLds &L, const OgCeltDebug &dbg, float *coef_row,
-                          uint32_t *cm_row)
+OG_DEV void og_celt_frame(const OgCeltHdr *hg, const OgBandPlan *plan, const OgCeltTables *T, OgCeltState *states,
+                          float *pcm_base, size_t pcm_stride, OgCeltLds &L, const OgCeltDebug &dbg, float *coef_row)
 {
-    int16_t *dbg_pulses = dbg.pulses;
     float *dbg_norm = dbg.norm, *dbg_freq = dbg.freq;
     uint8_t *dbg_collapse = dbg.collapse;
     OG_STAMP(0)
-    const OgCeltLeaf *lv = leaves_base + hg->leaf_begin;
-    const int nleaves = hg->nleaves < OG_MAXLEAF ? hg->nleaves : OG_MAXLEAF;
 
-    // ---- phase 0: stage the side-info and the PVQ table in LDS, clear the coefficient buffers
+    // ---- phase 0: stage the side-info, the band plan and the constants in LDS; fetch K1's coefficients
+    const int lm0 = hg->lm & 3;
     OG_LANES_BEGIN(tid)
     {
         const uint32_t *src = (const uint32_t *)hg;
         uint32_t *dst = (uint32_t *)&L.hdr;
         for (int p = tid; p < (int)(sizeof(OgCeltHdr) / 4); p += OG_WG) dst[p] = src[p];
-        const uint32_t *ls = (const uint32_t *)lv;      // leaves are 4 words
-        uint32_t *ld = (uint32_t *)L.leaves;
-        const int nst = 4 * (nleaves < OG_LDS_LEAVES ? nleaves : OG_LDS_LEAVES);
-        for (int p = tid; p < nst; p += OG_WG) ld[p] = ls[p];
+        const uint32_t *ps = (const uint32_t *)plan;    // head, then the first fill ops
+        for (int p = tid; p < OG_PLAN_HEAD_BYTES / 4; p += OG_WG) L.plan_head[p] = ps[p];
+        uint32_t *od = (uint32_t *)L.ops;
+        for (int p = tid; p < OG_LDS_OPS * 4; p += OG_WG) od[p] = ps[OG_PLAN_HEAD_BYTES / 4 + p];
     }
     for (int p = tid; p < (int)(sizeof(OgCeltConst) / 4); p += OG_WG) ((uint32_t *)&L.k)[p] = ((const uint32_t *)&T->k)[p];
-    // K1's output for this frame: shaped PVQ coefficients (zero elsewhere) and the collapse masks of the PVQ leaves.
-    // Both scratch rows are handed back zero-filled for the next launch.
+    for (int p = tid; p < 184; p += OG_WG) { L.lcg_a[p] = T->lcg_a[p]; L.lcg_c[p] = T->lcg_c[p]; }
+    for (int p = tid; p < 960 / 4; p += OG_WG) ((uint32_t *)L.bin2band)[p] = ((const uint32_t *)T->bin2band[lm0])[p];
+    // K1's output for this frame: shaped PVQ coefficients (zero elsewhere).  The scratch row is handed back zero-filled
+    // for the next launch.
     for (int p = tid; p < 2 * 960 / 4; p += OG_WG) {    // 16 bytes per lane
         ((OgF4 *)&L.X[0][0])[p] = ((const OgF4 *)coef_row)[p];
         ((OgF4 *)coef_row)[p] = OgF4{0.f, 0.f, 0.f, 0.f};
     }
     for (int p = tid; p < 2 * 800; p += OG_WG) (&L.u.norm[0][0])[p] = 0.f;
-    if (tid < 48) { (&L.collapse[0][0])[tid] = 0; (&L.band_cm[0][0])[tid] = cm_row[tid]; cm_row[tid] = 0; }
-    if (tid < 4) L.stepmask[tid] = 0;
     OG_LANES_END
     const OgCeltHdr *h = &L.hdr;
     const int lm = h->lm, M = 1 << lm, N = 120 << lm;
@@ -712,12 +601,12 @@ OG_DEV void og_celt_frame(const OgCeltHdr *hg, const OgCeltLeaf *leaves_base, co
         OG_STAMP(2)
         // ---- phase 2 (K2): bands in order
         OgBandCtx c;
-        c.h = h; c.lv = lv; c.T = T; c.L = &L; c.seed = h->seed; c.lm = lm; c.cycles = dbg.cycles;
+        c.h = h; c.plan = plan; c.T = T; c.L = &L; c.seed = h->seed; c.lm = lm; c.cycles = dbg.cycles;
         og_celt_bands(c);
         if (dbg_norm || dbg_collapse) {
             OG_LANES_BEGIN(tid)
             if (dbg_norm) for (int p = tid; p < 2 * 960; p += OG_WG) dbg_norm[p] = (&L.X[0][0])[p];
-            if (dbg_collapse && tid < 42) dbg_collapse[tid] = L.collapse[tid / 21][tid % 21];
+            if (dbg_collapse && tid < 42) dbg_collapse[tid] = ((const OgBandPlan *)L.plan_head)->collapse[tid / 21][tid % 21];
             OG_LANES_END
         }
         OG_STAMP(3)
@@ -730,33 +619,45 @@ OG_DEV void og_celt_frame(const OgCeltHdr *hg, const OgCeltLeaf *leaves_base, co
     const int B = transient ? M : 1, NB = N / B, n4 = NB >> 1;
     OgCf *ldsW = (OgCf *)&L.v.out[0][0], *ldsTw = (OgCf *)&L.v.out[1][0];
     OG_LANES_BEGIN(tid)
-    for (int t = tid; t < 42; t += OG_WG) {             // per-(channel, band) gains 2^(E + mean), zero outside [start, end)
-        const int ch = t >= 21, b = t - 21 * ch;
+    for (int t = tid; t < 48; t += OG_WG) {             // per-(channel, band) gains 2^(E + mean), zero outside [start, end)
+        const int ch = t >= 24, b = t - 24 * ch;
         float g = 0.f;
-        if (!silence && b >= h->start && b < h->end) {
+        if (!silence && b >= h->start && b < h->end && b < 21) {
             const float lg = h->energy[ch < C ? ch : 0][b] + L.k.emeans[b];
             g = exp2f(lg < 32.f ? lg : 32.f);
         }
         L.gband[ch][b] = g;
     }
-    if (silence)                                        // the band walk (and its bin -> band map) was skipped
-        for (int j = tid; j < 960; j += OG_WG) L.bin2band[j] = 255;
     for (int p = tid; p < 960; p += OG_WG) ((float *)ldsW)[p] = ((const float *)T->fft_w)[p];
     for (int p = tid; p < 2 * n4; p += OG_WG) ((float *)ldsTw)[p] = ((const float *)(T->tw + (n4 - 60)))[p];
     OG_LANES_END
+    OG_STAMP(9)
     OG_LANES_BEGIN(tid)
-    for (int j = tid; j < 960; j += OG_WG) {
-        const int b = L.bin2band[j];
-        float v0 = 0.f, v1 = 0.f;
-        if (b != 255) {
-            v0 = L.X[0][j] * L.gband[0][b];
-            v1 = C == 2 ? L.X[1][j] * L.gband[1][b] : v0;
-            if (CC == 1 && C == 2) v0 = 0.5f * v0 + 0.5f * v1;
-        }
-        L.X[0][j] = v0;
-        L.X[1][j] = v1;
+    int bb[4];
+    float x0[4], x1[4], g0[4], g1[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {                       // loads first (independent), then arithmetic: the LDS latencies overlap
+        const int j = tid + k * OG_WG < 960 ? tid + k * OG_WG : 959;
+        bb[k] = L.bin2band[j];
+        x0[k] = L.X[0][j];
+        x1[k] = L.X[1][j];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int b = bb[k] == 255 ? 23 : bb[k];        // gband[.][21..23] = 0
+        g0[k] = L.gband[0][b];
+        g1[k] = L.gband[1][b];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int j = tid + k * OG_WG;
+        float v0 = x0[k] * g0[k];
+        const float v1 = C == 2 ? x1[k] * g1[k] : v0;
+        if (CC == 1 && C == 2) v0 = 0.5f * v0 + 0.5f * v1;
+        if (j < 960) { L.X[0][j] = v0; L.X[1][j] = v1; }
     }
     OG_LANES_END
+    OG_STAMP(10)
     if (dbg_freq) {
         OG_LANES_BEGIN(tid)
         for (int p = tid; p < 2 * 960; p += OG_WG) dbg_freq[p] = (&L.X[0][0])[p];
@@ -840,46 +741,52 @@ OG_DEV void og_celt_frame(const OgCeltHdr *hg, const OgCeltLeaf *leaves_base, co
             L.v.out[ch][OG_HIST - d] = reset ? 0.f : st->hist[ch][(pos0 - (uint32_t)d) & 1023u];
         }
         OG_LANES_END
-        float *y0 = &L.v.out[0][OG_HIST];
-        og_wg_comb_filter(y0, CC, h->pf_period[0], h->pf_period[1], 120, pg0, pg1, h->pf_tapset[0], h->pf_tapset[1], T->window, L.k.pf_taps);
-        if (lm != 0)
-            og_wg_comb_filter(y0 + 120, CC, h->pf_period[1], h->pf_period[2], N - 120, pg1, pg2, h->pf_tapset[1],
-                              h->pf_tapset[2], T->window, L.k.pf_taps);
     }
+    const bool pf_on = pg0 != 0.f || pg1 != 0.f || (lm != 0 && pg2 != 0.f);
 
     OG_STAMP(7)
-    // ---- phase 7: de-emphasis t[j] = y[j] + 0.85 t[j-1] as a blocked scan (60 lanes x N/60 samples per channel),
-    //      then coalesced PCM + state write-back
+    // ---- phases 6b + 7: comb filter, then de-emphasis t[j] = y[j] + 0.85 t[j-1] as a blocked scan (60 lanes x N/60
+    //      samples), one wave per channel with no workgroup barrier in between; then coalesced PCM + state write-back
     const float coef = 0.85000610f;
     const int Lc = N / 60;
     float *tbuf = &L.X[0][0];                           // [2][960], free since the FFT finished... (bufB may hold
                                                         // the spectrum when the stage count is odd; it was consumed above)
-    OG_LANES_BEGIN(tid)
-    if (tid < CC * 60) {
-        const int ch = tid >= 60, l = tid - ch * 60;
-        const float *y = &L.v.out[ch][OG_HIST + l * Lc];
-        float m = 0.f, t = 0.f;
-        for (int j = 0; j < Lc; j++) { t = y[j] + m; m = coef * t; }
-        L.carry[ch][l] = m;                             // chunk's own contribution to the running memory
-    }
-    OG_LANES_END
     float aL = 1.f;
     for (int j = 0; j < Lc; j++) aL *= coef;            // coef^Lc
-    // carry-in of chunk l = sum over earlier chunks q of carry[q] * coef^(Lc*(l-1-q)) (+ the stream's memory); terms
-    // more than `reach` chunks back are below 1e-9 of their chunk's value and are dropped
-    const int reach = 128 / Lc + 1;
-    OG_LANES_BEGIN(tid)
-    if (tid < CC * 60) {
-        const int ch = tid >= 60, l = tid - ch * 60;
-        const int q0 = l > reach ? l - reach : 0;
-        float m = (reset || q0 > 0) ? 0.f : st->deemph[ch];
-        for (int q = q0; q < l; q++) m = m * aL + L.carry[ch][q];
-        const float *y = &L.v.out[ch][OG_HIST + l * Lc];
-        float *t = tbuf + ch * 960 + l * Lc;
-        for (int j = 0; j < Lc; j++) { const float v = y[j] + m; m = coef * v; t[j] = v; }
-        if (l == 59) st->deemph[ch] = m;
+    OG_WAVES_BEGIN(w)
+    if (w < CC) {
+        const int ch = w;
+        float *y0 = &L.v.out[ch][OG_HIST];
+        if (pf_on) {
+            og_wave_comb_filter(y0, h->pf_period[0], h->pf_period[1], 120, pg0, pg1, h->pf_tapset[0], h->pf_tapset[1], T->window, L.k.pf_taps);
+            if (lm != 0)
+                og_wave_comb_filter(y0 + 120, h->pf_period[1], h->pf_period[2], N - 120, pg1, pg2, h->pf_tapset[1], h->pf_tapset[2],
+                                    T->window, L.k.pf_taps);
+        }
+        OG_WAVE_BEGIN(l)
+        if (l < 60) {
+            const float *y = y0 + l * Lc;
+            float m = 0.f, t = 0.f;
+            for (int j = 0; j < Lc; j++) { t = y[j] + m; m = coef * t; }
+            L.carry[ch][l] = m;                         // chunk's own contribution to the running memory
+        }
+        OG_WAVE_END
+        // carry-in of chunk l = sum over earlier chunks q of carry[q] * coef^(Lc*(l-1-q)) (+ the stream's memory); terms
+        // more than `reach` chunks back are below 1e-9 of their chunk's value and are dropped
+        const int reach = 128 / Lc + 1;
+        OG_WAVE_BEGIN(l)
+        if (l < 60) {
+            const int q0 = l > reach ? l - reach : 0;
+            float m = (reset || q0 > 0) ? 0.f : st->deemph[ch];
+            for (int q = q0; q < l; q++) m = m * aL + L.carry[ch][q];
+            const float *y = y0 + l * Lc;
+            float *t = tbuf + ch * 960 + l * Lc;
+            for (int j = 0; j < Lc; j++) { const float v = y[j] + m; m = coef * v; t[j] = v; }
+            if (l == 59) st->deemph[ch] = m;
+        }
+        OG_WAVE_END
     }
-    OG_LANES_END
+    OG_WAVES_END
     float *pcm = pcm_base + (size_t)h->stream * pcm_stride + (size_t)h->pcm_off * CC;
     const bool accum = (h->flags & OG_F_ACCUM) != 0;
     const bool vec = (((uintptr_t)pcm) & 15) == 0;      // 16-byte stores when the caller's row allows it

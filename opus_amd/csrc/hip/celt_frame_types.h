@@ -8,7 +8,6 @@
 #define OG_HIST 1024                  // comb filter reaches back period + 2 <= 1024 samples
 #define OG_OUTLEN (OG_HIST + 960 + 60)
 #define OG_MAXLEAF 704                // 21 bands x 2 channels x 16 partitions, rounded up
-#define OG_LDS_LEAVES 224             // leaves staged in LDS per frame (C2 frames carry 65-160); the rest stay in HBM
 
 struct OgCf { float r, i; };
 
@@ -28,6 +27,7 @@ struct OgCeltTables {                 // constant tables, built once per device 
     uint32_t lcg_a[184], lcg_c[184];  // seed after j LCG steps = lcg_a[j] * seed + lcg_c[j]
     uint32_t pvq_u[1272];             // U(N,K) rows (celt/decoder.rs:293-409)
     uint16_t pvq_row[16];             // row offsets (celt/decoder.rs:410-413)
+    uint8_t bin2band[4][960];         // per LM: band of MDCT bin j (255 above band 20)
     OgCeltConst k;
 };
 

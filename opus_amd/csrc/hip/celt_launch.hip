@@ -27,8 +27,15 @@ __global__ __launch_bounds__(64) void og_pvq_kernel(const OgLeafRef *__restrict_
     if (g < nrefs) og_pvq_lane(refs[g], hdr, leaves, nframes, work, U, row, x + threadIdx.x, 64, dbg_pulses, stamps);
 }
 
-__global__ __launch_bounds__(OG_WG, 4) void og_celt_kernel(const OgCeltHdr *__restrict__ hdr, const OgCeltLeaf *__restrict__ leaves,
-                                                           uint32_t nframes, uint32_t frames_per_group,
+// Band plan: one lane per frame (celt_plan.h).
+__global__ __launch_bounds__(64) void og_plan_kernel(const OgCeltHdr *__restrict__ hdr, const OgCeltLeaf *__restrict__ leaves,
+                                                     uint32_t nframes, const OgCeltTables *__restrict__ T, void *work)
+{
+    const uint32_t f = blockIdx.x * 64 + threadIdx.x;
+    if (f < nframes) og_plan_frame(hdr, leaves, nframes, f, T, work);
+}
+
+__global__ __launch_bounds__(OG_WG, 4) void og_celt_kernel(const OgCeltHdr *__restrict__ hdr, uint32_t nframes, uint32_t frames_per_group,
                                                            const OgCeltTables *__restrict__ T, void *work, OgCeltState *state,
                                                            float *pcm, size_t pcm_stride, OgCeltDebug dbg)
 {
@@ -43,7 +50,7 @@ __global__ __launch_bounds__(OG_WG, 4) void og_celt_kernel(const OgCeltHdr *__re
         d.freq = dbg.freq ? dbg.freq + (size_t)f * 1920 : nullptr;
         d.collapse = dbg.collapse ? dbg.collapse + (size_t)f * 42 : nullptr;
         d.cycles = dbg.cycles ? dbg.cycles + (size_t)f * 64 : nullptr;
-        og_celt_frame(hdr + f, leaves, T, state, pcm, pcm_stride, L, d, og_work_coef(work, f), og_work_cm(work, nframes, f));
+        og_celt_frame(hdr + f, og_work_plan(work, f), T, state, pcm, pcm_stride, L, d, og_work_coef(work, f));
         __syncthreads();                                // frame t's state stores before frame t+1's loads
     }
 }
@@ -94,7 +101,7 @@ int opusgpu_init(int device)
     return og::celt_tables_for_device(device, &t);
 }
 
-size_t opusgpu_celt_work_bytes(uint32_t nframes) { return (size_t)nframes * (1920 * sizeof(float) + 48 * sizeof(uint32_t)); }
+size_t opusgpu_celt_work_bytes(uint32_t nframes) { return OG_WORK_BYTES(nframes); }
 
 int opusgpu_launch_celt(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, uint32_t nframes, uint32_t frames_per_group,
                         const OgLeafRef *refs, const uint32_t class_counts[4], void *work, OgCeltState *state, float *pcm,
@@ -129,8 +136,9 @@ int opusgpu_launch_celt(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, uint32_t
 #undef OG_PVQ_CLASS
     }
     const uint32_t groups = (nframes + frames_per_group - 1) / frames_per_group;
-    hipLaunchKernelGGL(og_celt_kernel, dim3(groups), dim3(OG_WG), 0, st, hdr, leaves, nframes, frames_per_group, T, work, state,
-                       pcm, pcm_stride_floats, dbg);
+    hipLaunchKernelGGL(og_plan_kernel, dim3((nframes + 63) / 64), dim3(64), 0, st, hdr, leaves, nframes, T, work);
+    hipLaunchKernelGGL(og_celt_kernel, dim3(groups), dim3(OG_WG), 0, st, hdr, nframes, frames_per_group, T, work, state, pcm,
+                       pcm_stride_floats, dbg);
     OG_HIP(hipGetLastError());
     return OPUSGPU_OK;
 }

@@ -1,0 +1,257 @@
+// CELT band plan: the integer half of decode_bands (celt/decoder.rs:2037-2220), one lane per frame.
+//
+// Two things make the reference's band walk sequential: folding reads the finished lower bands, and the noise seed runs
+// through the zero-pulse ("fill") leaves in decode order.  Which fill leaves are live, their seeds, and every collapse
+// mask are integer recurrences over a few dozen records -- slow as uniform code inside a 256-lane workgroup (each step
+// waits a full LDS round trip), trivial as 32768 independent lanes.  So after K1 (which produced the PVQ leaves'
+// collapse masks) one lane per frame derives:
+//   * a task record per quant_band call (band, buffer): geometry of its fused Haar/Hadamard transform, where its
+//     lowband_out goes, where it folds from, and its dependency level (0 = no fill leaves; otherwise 1 + the level of
+//     any fill band it folds from, and past the dual -> intensity switch of `norm`);
+//   * the list of live fill leaves ("fill ops") with their starting seeds, ordered by level;
+//   * the collapse masks of all bands and the seed the frame ends its bands with.
+// The frame kernel then runs level by level with no serial integer work left.
+#pragma once
+#include "wg.h"
+#include "../../../include/opusgpu.h"
+#include "celt_frame_types.h"
+
+struct OgTask {                       // one quant_band call = (band, buffer), task id = 2 * band + buffer; 16 bytes
+    uint16_t boff, n;                 // first bin in the channel buffer, width
+    uint16_t n0p, lowpos;             // OgXform.n0p; offset of the folding source in its norm row
+    uint8_t flags, hm, slog, rctd;    // OG_T_*; OgXform.hm / .slog; recombine | time_divide << 4
+    uint8_t norm_row, level;          // norm row lowband_out goes to (0xFF = none); dependency level
+    uint16_t pad_;
+};
+enum { OG_T_ACTIVE = 1, OG_T_CHAIN = 2, OG_T_NEED_LB = 4, OG_T_LONG = 8, OG_T_LB_ROW1 = 16 };
+
+struct OgFillOp {                     // one live fill leaf (celt/decoder.rs:1633-1661); 16 bytes
+    uint32_t seed;                    // noise seed before the leaf
+    float gain;                       // the leaf's renormalisation target
+    uint16_t pos;                     // buffer * 960 + first bin
+    uint8_t n, flags;                 // width; OG_OP_FOLD: copy of the lower band + dither, else noise
+    uint8_t level, pad_[3];
+};
+enum { OG_OP_FOLD = 1 };
+
+#define OG_MAXLEVEL 23                // 21 bands + the intensity switch, and level 0
+struct alignas(16) OgBandPlan {
+    OgTask task[42];
+    uint8_t collapse[2][24];
+    uint32_t seed_out;
+    uint16_t nops, merge_cnt;         // live fill leaves; norm bins below the dual -> intensity switch
+    uint8_t nlevels, merge_level;     // highest level in use; level the switch precedes (0xFF = none)
+    uint8_t lvl_maxcnt[OG_MAXLEVEL + 1];   // per level: largest 2^m of its tasks' transforms (0 = no transform at all)
+    uint8_t pad_[2];
+    uint16_t op_start[OG_MAXLEVEL + 2];    // ops of level l: op[op_start[l]] .. op[op_start[l + 1]]
+    OgFillOp op[OG_MAXLEAF];          // ordered by level, decode order inside a level
+    OgFillOp op_decode[OG_MAXLEAF];   // scratch: decode order
+};
+#define OG_PLAN_HEAD_BYTES ((int)offsetof(OgBandPlan, op))
+
+// The Haar steps of one quant_band call -- tf recombination (celt/decoder.rs:1708-1716, strides 1, 2, 4) and tf
+// time-division (:1722-1740, strides B, 2B, ...) -- are butterflies on distinct bits of the coefficient index, so
+// together they are a Walsh-Hadamard transform over the bit mask `hm` (a run of m <= 3 bits), scaled by 2^(-m/2).  The
+// Hadamard (de)interleave (:472-538) that follows / precedes them is a permutation.  Fused, every output coefficient
+// is one gather of 2^m inputs.
+struct OgXform {
+    int hm;                           // index bits the butterflies act on
+    int slog, n0p, had;               // reorder: stride 2^slog (0 = none), row length, natural / ordery rows
+    float scale;                      // 2^(-popcount(hm)/2)
+};
+
+OG_DEV void og_make_xform(int n, int B, int tf_change, OgXform *t, int *recombine_out, int *time_divide_out, int *B0_out)
+{
+    const int long_blocks = B == 1;
+    int n_b = n / B, recombine = tf_change > 0 ? tf_change : 0, time_divide = 0;
+    B >>= recombine;
+    n_b <<= recombine;
+    const int b1 = 31 - __builtin_clz((unsigned)B);
+    while ((n_b & 1) == 0 && tf_change < 0) { B <<= 1; n_b >>= 1; time_divide++; tf_change++; }
+    t->hm = ((1 << recombine) - 1) | (((1 << time_divide) - 1) << b1);
+    t->slog = B > 1 ? (31 - __builtin_clz((unsigned)B)) + recombine : 0;
+    t->n0p = n_b >> recombine;
+    t->had = long_blocks;
+    const int m = recombine + time_divide;
+    t->scale = (m & 1 ? 0.70710678118654752440f : 1.f) / (float)(1 << (m >> 1));
+    *recombine_out = recombine; *time_divide_out = time_divide; *B0_out = B;
+}
+
+// Everything here is per-lane serial code on global memory.  coef_row: the frame's K1 output (the signs of the
+// one-bin bands are added to it); cm_row: K1's collapse masks [buffer][24].
+OG_DEV void og_band_plan(const OgCeltHdr *h, const OgCeltLeaf *lv, const OgCeltTables *T, const uint32_t *cm_row, float *coef_row,
+                         OgBandPlan *P)
+{
+    const OgCeltConst &K = T->k;
+    const uint32_t *la = T->lcg_a, *lc = T->lcg_c;
+    const int lm = h->lm, M = 1 << lm, start = h->start, end = h->end;
+    const int C = (h->flags & OG_F_STEREO) ? 2 : 1;
+    const int B = (h->flags & OG_F_TRANSIENT) ? M : 1;
+    const int nleaves = h->nleaves < OG_MAXLEAF ? h->nleaves : OG_MAXLEAF;
+    const int norm_offset = M * K.ebands[start < 21 ? start : 20];
+    uint8_t blevel[21], col0[21], col1[21], maxcnt[OG_MAXLEVEL + 1];
+    for (int i = 0; i < 21; i++) blevel[i] = col0[i] = col1[i] = 0;
+    for (int l = 0; l <= OG_MAXLEVEL; l++) maxcnt[l] = 0;
+    uint32_t seed = h->seed;
+    int floor_lvl = 1, maxlvl = 0, merge_level = 0xFF, merge_cnt = 0, nops = 0;
+    const bool silence = (h->flags & OG_F_SILENCE) != 0;
+
+    for (int i = 0; i < 21; i++) {
+        OgTask tk[2];
+        int cm[2] = {0, 0};
+        for (int slot = 0; slot < 2; slot++) {
+            OgTask &t = tk[slot];
+            t.boff = t.n = t.n0p = t.pad_ = 0; t.lowpos = 0;
+            t.flags = t.hm = t.slog = t.rctd = t.level = 0; t.norm_row = 0xFF;
+        }
+        if (silence || i < start || i >= end) { P->task[2 * i] = tk[0]; P->task[2 * i + 1] = tk[1]; continue; }
+        const OgCeltBand bd = h->band[i];
+        const int n = M * K.width[i], boff = M * K.ebands[i];
+        const bool dual = (bd.flags & OG_B_DUAL) != 0;
+        bool any_chain = false;
+        int rc[2] = {0, 0}, td[2] = {0, 0}, B0[2] = {1, 1};
+        for (int slot = 0; slot < 2; slot++) {
+            OgTask &t = tk[slot];
+            const int nfill = slot ? bd.fy : bd.fx;
+            bool active, chain = false;
+            int norm_row = -1;
+            if (C == 1) { active = slot == 0; norm_row = 0; chain = nfill > 0; }
+            else if (dual) { active = true; norm_row = slot; chain = nfill > 0; }
+            else if (n == 1) { active = true; norm_row = slot == 0 ? 0 : -1; }
+            else if (n == 2) { active = slot == ((bd.flags & OG_B_N2SWAP) ? 1 : 0); norm_row = 0; chain = nfill > 0; }
+            else { active = true; norm_row = slot == 0 ? 0 : -1; chain = slot == 0 && nfill > 0 && !(bd.flags & OG_B_MIDFILL0); }
+            if (bd.flags & OG_B_LAST) norm_row = -1;
+            if (!active) continue;
+            t.boff = (uint16_t)boff; t.n = (uint16_t)n;
+            t.flags = (uint8_t)(OG_T_ACTIVE | (chain ? OG_T_CHAIN : 0) | (B == 1 ? OG_T_LONG : 0));
+            t.norm_row = (uint8_t)norm_row;
+            if (n == 1) {                               // decode_band_1 (celt/decoder.rs:1466-1495)
+                const int li = bd.leaf0 + (slot ? bd.nx : 0);
+                coef_row[slot * 960 + boff] = (li < nleaves && lv[li].index) ? -1.f : 1.f;
+                cm[slot] = 1;
+                continue;
+            }
+            OgXform xf;
+            og_make_xform(n, B, bd.tf_change, &xf, &rc[slot], &td[slot], &B0[slot]);
+            t.hm = (uint8_t)xf.hm; t.slog = (uint8_t)xf.slog; t.n0p = (uint16_t)xf.n0p;
+            t.rctd = (uint8_t)(rc[slot] | td[slot] << 4);
+            any_chain |= chain;
+            if (!chain) {                               // its fill leaves (if any) are dead: the PVQ masks are all
+                int m = (int)cm_row[slot * 24 + i];
+                for (int k = 0, Bk = B0[slot]; k < td[slot]; k++) { Bk >>= 1; m |= m >> Bk; }
+                for (int k = 0; k < rc[slot]; k++) m = K.bit_deinterleave[m & 255];
+                cm[slot] = m & ((1 << ((B0[slot] >> td[slot]) << rc[slot])) - 1);
+            }
+        }
+        int lvl = 0;
+        if (any_chain || (bd.flags & OG_B_MERGE_NORM)) {
+            int x_cm, y_cm;
+            lvl = floor_lvl;
+            if (bd.lowband != 0xFF) {
+                x_cm = y_cm = 0;
+                for (int f = bd.fold_lo; f < bd.fold_hi && f < 21; f++) {
+                    x_cm |= col0[f];
+                    y_cm |= C == 2 ? col1[f] : col0[f];
+                    if (blevel[f] >= lvl) lvl = blevel[f] + 1;
+                }
+            } else {
+                x_cm = y_cm = (1 << B) - 1;
+            }
+            if (bd.flags & OG_B_MERGE_NORM) {           // dual -> intensity switch (celt/decoder.rs:2133-2138): every lower
+                if (lvl <= maxlvl) lvl = maxlvl + 1;    // band is finished first, every later fill band comes after
+                floor_lvl = merge_level = lvl;
+                merge_cnt = boff - norm_offset;
+            }
+            if (lvl > OG_MAXLEVEL) lvl = OG_MAXLEVEL;   // cannot happen (one level per band at most, plus the switch)
+            for (int slot = 0; slot < 2; slot++) {
+                OgTask &t = tk[slot];
+                if (!(t.flags & OG_T_CHAIN)) continue;
+                // the integer half of a quant_band call with fill leaves: fill transforms (celt/decoder.rs:1700-1740),
+                // which leaves fold / make noise (:1633-1661), mask transforms (:1994-2019)
+                int fill = dual ? (slot ? y_cm : x_cm) : (x_cm | y_cm);
+                for (int k = 0; k < rc[slot]; k++) fill = K.bit_interleave[fill & 0xF] | K.bit_interleave[(fill >> 4) & 0xF] << 2;
+                for (int k = 0, Bk = B >> rc[slot]; k < td[slot]; k++, Bk <<= 1) fill |= fill << Bk;
+                t.level = (uint8_t)lvl;
+                if (bd.lowband != 0xFF && (bd.flags & (slot ? OG_B_FOLD_Y : OG_B_FOLD_X))) {
+                    t.flags |= OG_T_NEED_LB | ((dual && slot) ? OG_T_LB_ROW1 : 0);
+                    t.lowpos = (uint16_t)(bd.lowband * M);
+                }
+                const int g0 = bd.leaf0 + (slot ? bd.nx : 0), nfill = slot ? bd.fy : bd.fx;
+                int m = (int)cm_row[slot * 24 + i];     // PVQ leaves: expanded (and masks collected) by K1
+                for (int l = 0; l < nfill && g0 + l < nleaves; l++) {
+                    const OgCeltLeaf lf = lv[g0 + l];
+                    const int Bl = 1 << (lf.meta & OG_L_LOGB_MASK), sh = lf.cmshift;
+                    // the leaf's share of the fill: the recursion only shifts it (side halves) or clears it (theta)
+                    const int fl = (lf.meta & OG_L_FILL_DEAD) ? 0 : (fill >> sh) & ((1 << Bl) - 1);
+                    if (!fl) continue;                  // x stays zero (celt/decoder.rs:1640-1643)
+                    const bool fold = (lf.meta & OG_L_HAS_LOWBAND) != 0;
+                    const int nn = lf.n < 184 ? lf.n : 183;
+                    if (nops < OG_MAXLEAF) {
+                        OgFillOp op;
+                        op.seed = seed; op.gain = lf.gain;
+                        op.pos = (uint16_t)(slot * 960 + boff + lf.off);
+                        op.n = (uint8_t)nn; op.flags = fold ? OG_OP_FOLD : 0;
+                        op.level = (uint8_t)lvl; op.pad_[0] = op.pad_[1] = op.pad_[2] = 0;
+                        P->op_decode[nops++] = op;
+                    }
+                    m |= (fold ? fl : (1 << Bl) - 1) << sh;
+                    seed = la[nn] * seed + lc[nn];
+                }
+                for (int k = 0, Bk = B0[slot]; k < td[slot]; k++) { Bk >>= 1; m |= m >> Bk; }
+                for (int k = 0; k < rc[slot]; k++) m = K.bit_deinterleave[m & 255];
+                cm[slot] = m & ((1 << ((B0[slot] >> td[slot]) << rc[slot])) - 1);
+            }
+            if (any_chain) blevel[i] = (uint8_t)lvl;
+            if (lvl > maxlvl) maxlvl = lvl;
+        }
+        for (int slot = 0; slot < 2; slot++) {          // transform sizes per level (non-fill tasks are level 0)
+            const OgTask &t = tk[slot];
+            if (!(t.flags & OG_T_ACTIVE) || t.n == 1) continue;
+            const int cnt = (t.hm || t.slog) ? 1 << ((t.rctd & 15) + (t.rctd >> 4)) : 0;
+            if (cnt > maxcnt[t.level]) maxcnt[t.level] = (uint8_t)cnt;
+        }
+        col0[i] = (uint8_t)(dual || C == 1 ? cm[0] : (cm[0] | cm[1]));
+        col1[i] = (uint8_t)(dual ? cm[1] : C == 1 ? cm[0] : (cm[0] | cm[1]));
+        P->task[2 * i] = tk[0];
+        P->task[2 * i + 1] = tk[1];
+    }
+    for (int i = 0; i < 24; i++) {
+        P->collapse[0][i] = i < 21 ? col0[i] : 0;
+        P->collapse[1][i] = i < 21 ? (C == 2 ? col1[i] : col0[i]) : 0;
+    }
+    P->seed_out = seed;
+    P->nops = (uint16_t)nops; P->merge_cnt = (uint16_t)merge_cnt;
+    P->nlevels = (uint8_t)maxlvl; P->merge_level = (uint8_t)merge_level;
+    for (int l = 0; l <= OG_MAXLEVEL; l++) P->lvl_maxcnt[l] = maxcnt[l];
+    P->pad_[0] = P->pad_[1] = 0;
+    // counting sort of the ops by level (stable)
+    uint16_t cursor[OG_MAXLEVEL + 2];
+    for (int l = 0; l <= OG_MAXLEVEL + 1; l++) cursor[l] = 0;
+    for (int j = 0; j < nops; j++) cursor[P->op_decode[j].level + 1]++;
+    for (int l = 0; l <= OG_MAXLEVEL; l++) cursor[l + 1] = (uint16_t)(cursor[l + 1] + cursor[l]);
+    for (int l = 0; l <= OG_MAXLEVEL + 1; l++) P->op_start[l] = cursor[l];
+    for (int j = 0; j < nops; j++) {
+        const OgFillOp op = P->op_decode[j];
+        P->op[cursor[op.level]++] = op;
+    }
+}
+
+// Scratch shared by the CELT kernels (layout of `work`, include/opusgpu.h), one block per frame so that the layout does
+// not move with the launch size: coef[2][960] f32 (K1 -> frame kernel; kept zero between launches), band_cm[48] u32
+// ([buffer][band], 24 per buffer; K1 -> plan; kept zero), OgBandPlan (plan -> frame kernel).
+#define OG_WORK_STRIDE (1920 * 4 + 48 * 4 + sizeof(OgBandPlan))
+#define OG_WORK_BYTES(nframes) ((size_t)(nframes) * OG_WORK_STRIDE)
+OG_DEV float *og_work_coef(void *work, uint32_t frame) { return (float *)((char *)work + (size_t)frame * OG_WORK_STRIDE); }
+OG_DEV uint32_t *og_work_cm(void *work, uint32_t frame) { return (uint32_t *)((char *)work + (size_t)frame * OG_WORK_STRIDE + 1920 * 4); }
+OG_DEV OgBandPlan *og_work_plan(void *work, uint32_t frame)
+{
+    return (OgBandPlan *)((char *)work + (size_t)frame * OG_WORK_STRIDE + 1920 * 4 + 48 * 4);
+}
+
+// The plan of frame f: consumes (and re-zeroes) K1's collapse masks.
+OG_DEV void og_plan_frame(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, uint32_t nframes, uint32_t f, const OgCeltTables *T, void *work)
+{
+    uint32_t *cm = og_work_cm(work, f);
+    og_band_plan(hdr + f, leaves + hdr[f].leaf_begin, T, cm, og_work_coef(work, f), og_work_plan(work, f));
+    for (int i = 0; i < 48; i++) cm[i] = 0;
+}

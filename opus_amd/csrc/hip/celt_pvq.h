@@ -205,14 +205,6 @@ OG_DEV uint32_t og_pvq_leaf(const uint32_t *U, const uint16_t *row, const OgCelt
     return (uint32_t)cm << lf.cmshift;
 }
 
-// Scratch shared by the two CELT kernels (layout of `work`, include/opusgpu.h): coef[nframes][2][960] f32 then
-// band_cm[nframes][48] u32 ([buffer][band], 24 per buffer).
-OG_DEV float *og_work_coef(void *work, uint32_t frame) { return (float *)work + (size_t)frame * 1920; }
-OG_DEV uint32_t *og_work_cm(void *work, uint32_t nframes, uint32_t frame)
-{
-    return (uint32_t *)((float *)work + (size_t)nframes * 1920) + (size_t)frame * 48;
-}
-
 // K1 body for one lane.  xl = this lane's vector storage (element stride xs), at least lf.n elements.
 OG_DEV void og_pvq_lane(const OgLeafRef ref, const OgCeltHdr *hdr, const OgCeltLeaf *leaves, uint32_t nframes, void *work,
                         const uint32_t *U, const uint16_t *row, float *xl, int xs, int16_t *dbg_pulses, uint64_t *stamps)
@@ -224,6 +216,6 @@ OG_DEV void og_pvq_lane(const OgLeafRef ref, const OgCeltHdr *hdr, const OgCeltL
     const uint32_t cm = og_pvq_leaf(U, row, lf, spread, xl, xs, dbg, stamps);
     float *dst = og_work_coef(work, ref.frame) + ch * 960 + lf.pos;
     for (int i = 0; i < lf.n; i++) dst[i] = xl[i * xs];
-    OG_ATOMIC_OR(og_work_cm(work, nframes, ref.frame) + ch * 24 + lf.band, cm);
+    OG_ATOMIC_OR(og_work_cm(work, ref.frame) + ch * 24 + lf.band, cm);
     OG_PVQ_STAMP(3)
 }

@@ -20,6 +20,21 @@
 #define OG_ATOMIC_OR(p, v) atomicOr((p), (v))
 #define OG_LANES_BEGIN_NOSYNC(tid) { const int tid = (int)threadIdx.x; {
 #define OG_LANES_END_NOSYNC } }           /* regions that touch disjoint data; an explicit OG_BARRIER follows the batch */
+// Wavefront-granular sections.  Short dependent chains (a handful of <= 176-element vector steps) cost a full
+// workgroup barrier per step when all four waves work on one of them; a single wave needs none (LDS operations of
+// one wave complete in issue order).  So independent chains go one per wave:
+//     OG_WAVES_BEGIN(w)   uniform-per-wave code, w = wave index 0..OG_WG/64-1, with regions
+//         OG_WAVE_BEGIN(lane)  per-lane code, lane = 0..63  OG_WAVE_END     <- compiler-level fence only
+//     OG_WAVES_END                                                          <- workgroup barrier
+// OG_WAVE0_BEGIN .. OG_WAVE0_END is the same with only wave 0 running (the others wait at the closing barrier).
+// OG_U32 tells the compiler a value is wave-uniform (it moves to a scalar register, and so does what is derived from it).
+#define OG_WAVES_BEGIN(w) { const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); {
+#define OG_WAVES_END } } __syncthreads();
+#define OG_WAVE0_BEGIN if (threadIdx.x < 64) {
+#define OG_WAVE0_END } __syncthreads();
+#define OG_WAVE_BEGIN(lane) { const int lane = (int)(threadIdx.x & 63); {
+#define OG_WAVE_END } } __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+#define OG_U32(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
 #else
 #include <math.h>
 #define OG_DEV static inline
@@ -28,4 +43,11 @@
 #define OG_ATOMIC_OR(p, v) (*(p) |= (v))
 #define OG_LANES_BEGIN_NOSYNC(tid) for (int tid = 0; tid < OG_WG; tid++) { {
 #define OG_LANES_END_NOSYNC } }
+#define OG_WAVES_BEGIN(w) for (int w = 0; w < OG_WG / 64; w++) { {
+#define OG_WAVES_END } }
+#define OG_WAVE0_BEGIN {
+#define OG_WAVE0_END }
+#define OG_U32(x) ((uint32_t)(x))
+#define OG_WAVE_BEGIN(lane) for (int lane = 0; lane < 64; lane++) { {
+#define OG_WAVE_END } }
 #endif

@@ -38,4 +38,11 @@ void og_fill_celt_tables(OgCeltTables *t)
     for (int i = 0; i < 32; i++) k.hadamard[i] = i < 30 ? CELT_HADAMARD_ORDERY[i] : 0;
     for (int i = 0; i < 1272; i++) t->pvq_u[i] = CELT_PVQ_U[i];
     for (int i = 0; i < 16; i++) t->pvq_row[i] = i < 15 ? CELT_PVQ_U_ROW[i] : 0;
+    for (int lm = 0; lm < 4; lm++)
+        for (int j = 0; j < 960; j++) {
+            int b = 255;
+            for (int i = 0; i < 21; i++)
+                if (j >= (CELT_EBANDS[i] << lm) && j < (CELT_EBANDS[i + 1] << lm)) b = i;
+            t->bin2band[lm][j] = (uint8_t)b;
+        }
 }

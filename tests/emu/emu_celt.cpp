@@ -14,8 +14,8 @@ extern "C" int emu_launch_celt(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, u
     if (!init) { og_fill_celt_tables(&T); init = true; }
     static OgCeltLds L;
     (void)frames_per_group;
-    // K1: every PVQ leaf of every frame (order is irrelevant to the result), then K2+K3 frame by frame
-    std::vector<float> work((size_t)nframes * (1920 + 48), 0.f);
+    // K1: every PVQ leaf of every frame (order is irrelevant to the result), the band plans, then K2+K3 frame by frame
+    std::vector<float> work(OG_WORK_BYTES(nframes) / 4 + 4, 0.f);
     for (uint32_t f = 0; f < nframes; f++)
         for (uint32_t l = 0; l < hdr[f].nleaves; l++) {
             const OgCeltLeaf &lf = leaves[hdr[f].leaf_begin + l];
@@ -24,6 +24,7 @@ extern "C" int emu_launch_celt(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, u
             OgLeafRef ref = {hdr[f].leaf_begin + l, f};
             og_pvq_lane(ref, hdr, leaves, nframes, work.data(), T.pvq_u, T.pvq_row, x, 1, dbg ? dbg->pulses : nullptr, nullptr);
         }
+    for (uint32_t f = 0; f < nframes; f++) og_plan_frame(hdr, leaves, nframes, f, &T, work.data());
     for (uint32_t f = 0; f < nframes; f++) {
         std::memset(&L, 0xA5, sizeof L);               // LDS starts undefined on the device
         OgCeltDebug d = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -32,8 +33,7 @@ extern "C" int emu_launch_celt(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, u
             d.freq = dbg->freq ? dbg->freq + (size_t)f * 1920 : nullptr;
             d.collapse = dbg->collapse ? dbg->collapse + (size_t)f * 42 : nullptr;
         }
-        og_celt_frame(hdr + f, leaves, &T, state, pcm, pcm_stride, L, d, og_work_coef(work.data(), f),
-                      og_work_cm(work.data(), nframes, f));
+        og_celt_frame(hdr + f, og_work_plan(work.data(), f), &T, state, pcm, pcm_stride, L, d, og_work_coef(work.data(), f));
     }
     return 0;
 }

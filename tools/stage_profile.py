@@ -22,7 +22,7 @@ parser = BatchDecoder(S, 2, 0)
 cl = CeltLaunch(S)
 state = torch.zeros(S * C.sizeof(A.CeltState), dtype=torch.uint8, device=dev)
 pcm = torch.zeros(S * 1920, dtype=torch.float32, device=dev)
-names = ["init", "pvq", "bands", "anticollapse", "denorm", "imdct", "postfilter", "deemph+store"]
+names = ["init", "pvq", "bands", "anticollapse", "denorm", "imdct", "pf-history", "comb+deemph+store"]
 tot = np.zeros(8)
 for f in range(NF):
     assert not any(parser.send([pk[s, f].tobytes() for s in range(S)]))
@@ -44,10 +44,11 @@ for f in range(NF):
         okb = ok & (bd >= 0).all(axis=1)
         band_tot = band_tot + bd[okb].mean(axis=0) if "band_tot" in dir() else bd[okb].mean(axis=0)
         span = c[:, 8].max() - c[:, 0].min()
+        print("denorm apply region clk", (c[:, 10] - c[:, 9]).mean())
 for n, v in zip(names, tot / (NF - 1)):
     print(f"{n:14s} {v:12.0f} clk  {100 * v / tot.sum() * (NF - 1):5.1f}%")
 print("mean per-frame total", tot.sum() / (NF - 1), "clk; launch span (last frame)", span, "clk")
-print("band phase (set-up, pass A lock-step, pass B sequential, pass C merges) mean clk:", " ".join(f"{v:.0f}" for v in band_tot / (NF - 1)))
+print("band phase (-, level 0, fill levels, merges) mean clk:", " ".join(f"{v:.0f}" for v in band_tot / (NF - 1)))
 k1 = cyc_all[S * 64:].view(177, 4096, 4).cpu().numpy()
 for nmax in (176, 64, 24, 8):
     blk = k1[nmax]
