@@ -54,16 +54,17 @@ def build_oracle():
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
 
 
-def build_emu():
-    """CPU emulation of the kernel bodies: a test fixture (tests/emu), never shipped in libopusgpu.so."""
-    out = os.path.join(ROOT, "tests", "emu", "libemu.so")
+def build_emu(variant="", defines=()):
+    """CPU emulation of the kernel bodies: a test fixture (tests/emu), never shipped in libopusgpu.so.
+    `variant` + `defines` build a second copy with other compile-time limits (tests of the overflow paths)."""
+    out = os.path.join(ROOT, "tests", "emu", f"libemu{variant}.so")
     srcs = [os.path.join(ROOT, "tests", "emu", f) for f in os.listdir(os.path.join(ROOT, "tests", "emu")) if f.endswith(".cpp")]
     srcs.append(os.path.join(CSRC, "host", "celt_tables.cpp"))
     srcs.append(os.path.join(CSRC, "host", "silk_tables.cpp"))
-    if not _newer(out, _all_inputs() + srcs):
+    if not _newer(out, _all_inputs() + srcs + [os.path.abspath(__file__)]):
         return out
     subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fno-strict-aliasing", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
-                           "-Wno-unused-variable", "-Wno-missing-braces", "-o", out] + srcs)
+                           "-Wno-unused-variable", "-Wno-missing-braces", "-Wno-unknown-pragmas"] + [f"-D{d}" for d in defines] + ["-o", out] + srcs)
     return out
 
 

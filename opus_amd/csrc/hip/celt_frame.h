@@ -20,7 +20,9 @@
 
 struct alignas(16) OgF4 { float x, y, z, w; };
 
+#ifndef OG_LDS_OPS
 #define OG_LDS_OPS 48                 // fill ops staged in LDS per frame (C2 frames carry ~5); the rest stay in HBM
+#endif
 
 struct alignas(16) OgCeltLds {
     float X[2][960];                  // coefficients (bands) -> MDCT bins -> FFT ping buffer -> de-emphasised PCM

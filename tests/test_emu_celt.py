@@ -47,6 +47,23 @@ def test_emu_vectors(emu, vid, n, ch):
     _run(emu, pk, ch)
 
 
+@pytest.fixture(scope="module")
+def emu_small():
+    """same kernel body with room for 4 fill ops in LDS: the rest are read from the plan in global memory"""
+    lib = C.CDLL(build.build_emu("_ops4", ["OG_LDS_OPS=4"]))
+    lib.emu_launch_celt.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    return lib
+
+
+@pytest.mark.parametrize("payload", [8, 24, 80])
+def test_emu_low_rate_many_fill_leaves(emu, emu_small, payload):
+    """starved frames: most bands carry no pulses, up to 42 noise / folded leaves per frame over several levels"""
+    pk = synth.celt_fb_stereo_packets(range(3), 30, payload)
+    for lib in (emu, emu_small):
+        for s in range(3):
+            _run(lib, [pk[s, f].tobytes() for f in range(30)], 2)
+
+
 @pytest.mark.parametrize("payload", [160, 320])
 def test_emu_synthetic(emu, payload):
     pk = synth.celt_fb_stereo_packets(range(6), 25, payload)
