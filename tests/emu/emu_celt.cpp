@@ -38,3 +38,26 @@ extern "C" int emu_launch_celt(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, u
     return 0;
 }
 extern "C" size_t emu_lds_bytes(void) { return sizeof(OgCeltLds); }
+
+// Diagnostic: band-plan statistics of one frame (K1 collapse masks are not needed for levels / op counts).
+extern "C" void emu_plan_stats(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, uint32_t f, int32_t out[8])
+{
+    static OgCeltTables T;
+    static bool init = false;
+    if (!init) { og_fill_celt_tables(&T); init = true; }
+    std::vector<float> work(OG_WORK_BYTES(f + 1) / 4 + 4, 0.f);
+    og_plan_frame(hdr, leaves, f + 1, f, &T, work.data());
+    const OgBandPlan *P = og_work_plan(work.data(), f);
+    out[0] = P->nlevels; out[1] = P->nops; out[2] = P->merge_level;
+    int xf0 = 0, xfn = 0, act = 0;
+    for (int t = 0; t < 42; t++) {
+        const OgTask &k = P->task[t];
+        if (!(k.flags & OG_T_ACTIVE)) continue;
+        act++;
+        if (k.hm | k.slog) { if (k.level == 0) xf0++; else xfn++; }
+    }
+    out[3] = act; out[4] = xf0; out[5] = xfn;
+    int mc = 0;
+    for (int l = 0; l <= OG_MAXLEVEL; l++) if (P->lvl_maxcnt[l] > mc) mc = P->lvl_maxcnt[l];
+    out[6] = mc; out[7] = hdr[f].nleaves;
+}

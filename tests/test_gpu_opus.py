@@ -57,6 +57,29 @@ def test_reference_silk_goldens_on_gpu(name, nframes, fs):
     assert np.array_equal(np.concatenate(left), np.array(k["left"], np.float32))
 
 
+@pytest.mark.parametrize("vid", list(range(1, 13)))
+def test_opus_compare_gpu_vs_oracle(vid):
+    """the RFC's own conformance metric (tools/opus_compare.py; no `.dec` files exist here, so the oracle's PCM stands
+    in as the reference): quality 100 = indistinguishable, >= 0 passes; the GPU path must be at 99.9 or better"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(orc.ROOT, "tools"))
+    import opus_compare as oc
+    extra, pk = orc.load_vectors(ids=[vid], max_packets=150)[vid]
+    d = Decoder(0)
+    d.set_extradata(extra)
+    d.configure()
+    ref = orc.Decoder(2)
+    out, exp = [], []
+    for p in pk:
+        d.send_packet(p)
+        out.append(d.receive_frame())
+        exp.append(ref.decode(p))
+    out, exp = np.concatenate(out), np.concatenate(exp)
+    q, err = oc.compare(oc.to_pcm16(exp), oc.to_pcm16(out), 48000, True)
+    assert q >= 99.9, f"vector {vid}: opus_compare quality {q:.2f} (error {err:.4g})"
+
+
 def test_batch_all_modes():
     """BASELINE config 5 shape in small: the 12 vectors as independent streams of one batch, 60 packets each"""
     V = orc.load_vectors()
