@@ -64,6 +64,40 @@ int opusgpu_decoder_receive_frame(opusgpu_decoder *, float *pcm, size_t cap_floa
  * reset all decoder state (Silk::flush silk/decoder.rs:1934-1940 + CELT reset). */
 int opusgpu_decoder_flush(opusgpu_decoder *);
 
+/* OpusHead (RFC 7845 5.1) as Dec::configure reads it (decoder.rs:133-182: channels byte 9, output gain bytes 16-17,
+ * mapping family byte 18, stream / coupled counts and channel mapping behind them).  Family 0 fills the implicit
+ * mono / stereo mapping (decoder.rs:158-165).  Returns OPUSGPU_CONFIG_INVALID for a malformed header,
+ * OPUSGPU_CONFIG_INCOMPLETE when a family != 0 header is cut short (decoder.rs:167), OPUSGPU_UNSUPPORTED for a
+ * major version other than 0. */
+typedef struct {
+    uint8_t version, channels;
+    uint16_t pre_skip;                  /* 48 kHz samples to drop at the start of the stream */
+    uint32_t input_sample_rate;         /* informational (the RFC vectors carry 44100) */
+    int16_t output_gain_q8;             /* dB in Q7.8, to be applied to the decoded PCM */
+    uint8_t mapping_family, stream_count, coupled_count;
+    uint8_t mapping[255];
+} OgOpusHead;
+int opusgpu_opus_head_parse(const uint8_t *extra, size_t len, OgOpusHead *out);
+/* Layer-1 decoders apply what the header asks for, which the reference reads and then ignores (decoder.rs:137-150):
+ * receive_frame drops the first pre_skip samples of the stream and scales the PCM by 10^(output_gain_q8 / 5120).
+ * Both are no-ops for the RFC 6716 vectors (pre-skip 0, gain 0). */
+
+/* ------------------------------------------------------------------------------------------------
+ * Container layer: the packets of one Opus track out of a Matroska (.mka/.mkv/.webm) or Ogg (.opus) file image.
+ * Stands in for the `matroska` + `av-format` crates the reference's integration tests use to feed send_packet
+ * (decoder.rs:202-232).  The handle copies what it needs; `data` may be released after open.  Matroska: first
+ * A_OPUS track, CodecPrivate = OpusHead, SimpleBlocks and BlockGroups, all four lacing modes, unknown-size
+ * Segment / Cluster.  Ogg: first logical stream that starts with OpusHead, page CRCs verified, packets spanning pages
+ * reassembled, OpusTags skipped.  pts = nanoseconds (Matroska) or the granule position of the page the packet ends
+ * on, -1 for the others (Ogg). */
+typedef struct opusgpu_demux opusgpu_demux;
+int opusgpu_demux_open(opusgpu_demux **out, const uint8_t *data, size_t len);
+void opusgpu_demux_close(opusgpu_demux *);
+int opusgpu_demux_info(const opusgpu_demux *, int *container /* 0 Matroska, 1 Ogg */, const uint8_t **extradata,
+                       size_t *extralen, uint32_t *npackets);
+/* Packet i (valid until close).  OPUSGPU_MORE_DATA_NEEDED past the end. */
+int opusgpu_demux_packet(const opusgpu_demux *, uint32_t i, const uint8_t **pkt, size_t *len, int64_t *pts);
+
 /* ------------------------------------------------------------------------------------------------
  * Layer 2: a batch of independent streams on one GPU (one handle per GPU; streams shard across GPUs
  * with no collective).  Each stream is a `Dec` of the reference. */

@@ -64,6 +64,12 @@ class CeltState(C.Structure):
                 ("pos", C.c_uint32), ("pad_", C.c_uint32)]
 
 
+class OpusHead(C.Structure):
+    _fields_ = [("version", C.c_uint8), ("channels", C.c_uint8), ("pre_skip", C.c_uint16), ("input_sample_rate", C.c_uint32),
+                ("output_gain_q8", C.c_int16), ("mapping_family", C.c_uint8), ("stream_count", C.c_uint8),
+                ("coupled_count", C.c_uint8), ("mapping", C.c_uint8 * 255)]
+
+
 class CeltDebug(C.Structure):
     _fields_ = [("pulses", C.c_void_p), ("norm", C.c_void_p), ("freq", C.c_void_p), ("collapse", C.c_void_p), ("cycles", C.c_void_p)]
 
@@ -81,6 +87,11 @@ PROTOTYPES = {
     "opusgpu_decoder_send_packet": (C.c_int, [_P, C.c_char_p, C.c_size_t]),
     "opusgpu_decoder_receive_frame": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
     "opusgpu_decoder_flush": (C.c_int, [_P]),
+    "opusgpu_opus_head_parse": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(OpusHead)]),
+    "opusgpu_demux_open": (C.c_int, [C.POINTER(_P), C.c_char_p, C.c_size_t]),
+    "opusgpu_demux_close": (None, [_P]),
+    "opusgpu_demux_info": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(_P), C.POINTER(C.c_size_t), C.POINTER(C.c_uint32)]),
+    "opusgpu_demux_packet": (C.c_int, [_P, C.c_uint32, C.POINTER(_P), C.POINTER(C.c_size_t), C.POINTER(C.c_int64)]),
     "opusgpu_batch_create": (C.c_int, [C.POINTER(_P), C.c_uint32, C.c_int, C.c_int]),
     "opusgpu_batch_destroy": (None, [_P]),
     "opusgpu_batch_send": (C.c_int, [_P, C.POINTER(C.c_char_p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_int32)]),

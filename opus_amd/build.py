@@ -8,7 +8,7 @@ CSRC = os.path.join(ROOT, "opus_amd", "csrc")
 OUT = os.path.join(ROOT, "opus_amd", "libopusgpu.so")
 
 HOST_SOURCES = ["host/packet.cpp", "host/celt_parse.cpp", "host/silk_parse.cpp", "host/stream_parser.cpp",
-                "host/capi_parse.cpp", "host/celt_tables.cpp", "host/silk_tables.cpp", "host/engine.cpp"]
+                "host/capi_parse.cpp", "host/container.cpp", "host/celt_tables.cpp", "host/silk_tables.cpp", "host/engine.cpp"]
 HIP_SOURCES = ["hip/celt_launch.hip", "hip/silk_launch.hip"]
 
 

@@ -6,6 +6,7 @@
 // Dec::send_packet (decoder.rs:48-127), batch_decode the device half.
 #include <hip/hip_runtime_api.h>
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
@@ -369,6 +370,9 @@ struct opusgpu_decoder {
     std::vector<uint8_t> extradata;
     opusgpu_batch *batch = nullptr;
     std::deque<std::vector<float>> queue;
+    uint32_t skip_left = 0;             // OpusHead pre-skip still to drop (48 kHz samples)
+    uint32_t pre_skip = 0;
+    float out_gain = 1.f;               // 10^(output_gain_q8 / (20 * 256))
     ~opusgpu_decoder() { delete batch; }
 };
 
@@ -397,21 +401,25 @@ int opusgpu_decoder_configure(opusgpu_decoder *d)
     if (!d) return OPUSGPU_BAD_ARG;
     int channels = 2;                                   // decoder.rs:136-145
     const std::vector<uint8_t> &e = d->extradata;
+    d->pre_skip = 0;
+    d->out_gain = 1.f;
     if (!e.empty()) {
-        if (e.size() < 19 || std::memcmp(e.data(), "OpusHead", 8) != 0) return OPUSGPU_CONFIG_INVALID;
-        channels = e[9];
-        const int mapping_family = e[18];
-        if (channels < 1) return OPUSGPU_CONFIG_INVALID;
-        if (channels > 2 || mapping_family != 0) {
-            // decoder.rs:151-171: explicit stream maps / >2 channels end in unimplemented!(); mono/stereo with a
-            // family-0 header is everything the reference can configure
-            if (channels > 2) return OPUSGPU_UNSUPPORTED;
-            if (e.size() < size_t(21 + channels)) return OPUSGPU_CONFIG_INCOMPLETE;   // decoder.rs:167
-        }
+        OgOpusHead head;
+        const int hrc = opusgpu_opus_head_parse(e.data(), e.size(), &head);
+        // decoder.rs:151-171: explicit stream maps / > 2 channels end in unimplemented!(); mono / stereo is everything
+        // the reference can configure
+        if (hrc == OPUSGPU_OK && (head.channels > 2 || head.stream_count != 1)) return OPUSGPU_UNSUPPORTED;
+        if (hrc == OPUSGPU_CONFIG_INVALID && e.size() >= 19 && std::memcmp(e.data(), "OpusHead", 8) == 0 && e[9] > 2 && e[18] == 0)
+            return OPUSGPU_UNSUPPORTED;                 // family 0 with > 2 channels: same dead end (decoder.rs:170-171)
+        if (hrc) return hrc;
+        channels = head.channels;
+        d->pre_skip = head.pre_skip;
+        d->out_gain = head.output_gain_q8 ? std::pow(10.f, float(head.output_gain_q8) / (20.f * 256.f)) : 1.f;
     }
     delete d->batch;
     d->batch = nullptr;
     d->queue.clear();
+    d->skip_left = d->pre_skip;
     d->channels = channels;
     int rc = opusgpu_batch_create(&d->batch, 1, channels, d->device);
     d->configured = rc == OPUSGPU_OK;
@@ -434,6 +442,12 @@ int opusgpu_decoder_send_packet(opusgpu_decoder *d, const uint8_t *pkt, size_t l
     size_t n = 0;
     if ((rc = opusgpu_batch_read(d->batch, 0, out.data(), out.size(), &n))) return rc;
     out.resize(n * d->channels);
+    if (d->skip_left) {                                 // RFC 7845 4.2: the first pre_skip samples are decoder warm-up
+        const size_t drop = std::min<size_t>(d->skip_left, n);
+        out.erase(out.begin(), out.begin() + drop * d->channels);
+        d->skip_left -= uint32_t(drop);
+    }
+    if (d->out_gain != 1.f) for (float &v : out) v *= d->out_gain;
     d->queue.push_back(std::move(out));
     return OPUSGPU_OK;
 }
@@ -455,6 +469,7 @@ int opusgpu_decoder_flush(opusgpu_decoder *d)
 {
     if (!d) return OPUSGPU_BAD_ARG;
     d->queue.clear();
+    d->skip_left = d->pre_skip;
     if (d->batch) return opusgpu_batch_flush(d->batch, 0);
     return OPUSGPU_OK;
 }

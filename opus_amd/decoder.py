@@ -33,6 +33,56 @@ def parse_packet(pkt):
                 nframes=p.nframes, padding=p.padding, frames=[(p.off[i], p.len[i]) for i in range(p.nframes)])
 
 
+def parse_opus_head(extra):
+    """OpusHead -> dict (what Dec::configure reads, decoder.rs:133-182)."""
+    h = A.OpusHead()
+    b = bytes(extra)
+    _chk(A.load().opusgpu_opus_head_parse(b, len(b), C.byref(h)), "opus_head_parse")
+    return dict(version=h.version, channels=h.channels, pre_skip=h.pre_skip, input_sample_rate=h.input_sample_rate,
+                output_gain_q8=h.output_gain_q8, mapping_family=h.mapping_family, stream_count=h.stream_count,
+                coupled_count=h.coupled_count, mapping=list(h.mapping[: h.channels]))
+
+
+class Demuxer:
+    """Packets of the Opus track of a Matroska or Ogg file image (stands in for the matroska / av-format crates of the
+    reference's tests, decoder.rs:202-232)."""
+
+    def __init__(self, data):
+        self._lib = A.load()
+        self._h = C.c_void_p()
+        b = bytes(data)
+        _chk(self._lib.opusgpu_demux_open(C.byref(self._h), b, len(b)), "demux_open")
+        cont, ex, el, n = C.c_int(), C.c_void_p(), C.c_size_t(), C.c_uint32()
+        _chk(self._lib.opusgpu_demux_info(self._h, C.byref(cont), C.byref(ex), C.byref(el), C.byref(n)), "demux_info")
+        self.container = "ogg" if cont.value else "matroska"
+        self.extradata = C.string_at(ex, el.value)
+        self.npackets = n.value
+
+    def packet(self, i):
+        """-> (bytes, pts)"""
+        p, l, pts = C.c_void_p(), C.c_size_t(), C.c_int64()
+        _chk(self._lib.opusgpu_demux_packet(self._h, i, C.byref(p), C.byref(l), C.byref(pts)), "demux_packet")
+        return C.string_at(p, l.value), pts.value
+
+    def __len__(self):
+        return self.npackets
+
+    def __iter__(self):
+        for i in range(self.npackets):
+            yield self.packet(i)[0]
+
+    def close(self):
+        if self._h:
+            self._lib.opusgpu_demux_close(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Decoder:
     """One stream: set_extradata -> configure -> (send_packet -> receive_frame)* -> flush (decoder.rs:42-188)."""
 

@@ -7,7 +7,7 @@ import pytest
 
 import orc
 from gpu_util import HostParser, check_pcm
-from opus_amd import BatchDecoder, Decoder, _abi as A
+from opus_amd import BatchDecoder, Decoder, _abi as A, parse_packet
 
 pytestmark = pytest.mark.gpu
 K = orc.kats()
@@ -78,6 +78,33 @@ def test_opus_compare_gpu_vs_oracle(vid):
     out, exp = np.concatenate(out), np.concatenate(exp)
     q, err = oc.compare(oc.to_pcm16(exp), oc.to_pcm16(out), 48000, True)
     assert q >= 99.9, f"vector {vid}: opus_compare quality {q:.2f} (error {err:.4g})"
+
+
+def test_container_to_pcm_with_pre_skip_and_gain():
+    """file image -> demux -> decoder, with an OpusHead that asks for pre-skip and output gain (the reference reads both
+    and ignores them, decoder.rs:137-150; RFC 7845 wants them applied)"""
+    import struct
+    from test_container import make_mka, make_ogg
+    from opus_amd import Demuxer
+    extra, pk = orc.load_vectors(ids=[10], max_packets=80)[10]
+    head = extra[:10] + struct.pack("<HIh", 1000, 48000, -1536) + extra[18:]     # 1000 samples, -6 dB
+    ref = orc.Decoder(2)
+    exp = np.concatenate([ref.decode(p) for p in pk])[1000:] * np.float32(10.0 ** (-1536 / 5120.0))
+    for image in (make_mka(head, pk, lacing="xiph"), make_ogg(head, pk)):
+        dm = Demuxer(image)
+        d = Decoder(0)
+        d.set_extradata(dm.extradata)
+        d.configure()
+        out = []
+        for p in dm:
+            d.send_packet(p)
+            out.append(d.receive_frame())
+        out = np.concatenate(out)
+        check_pcm(exp, out, "pre-skip + gain")
+        d.flush()                                   # a flushed stream starts over: pre-skip applies again
+        d.send_packet(pk[0])
+        info = parse_packet(pk[0])
+        assert d.receive_frame().shape[0] == max(0, info["frame_size"] * info["nframes"] - 1000)
 
 
 def test_batch_all_modes():
