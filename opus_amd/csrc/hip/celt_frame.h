@@ -42,8 +42,7 @@ struct alignas(16) OgCeltLds {
     alignas(16) uint32_t plan_head[OG_PLAN_HEAD_BYTES / 4];   // OgBandPlan up to (not including) .op
     OgFillOp ops[OG_LDS_OPS];
     uint8_t bin2band[960];
-    float mrg[21][12][2];             // stereo merge partial sums
-    alignas(16) float mg[24][4];      // per-band merge matrix
+    float mrg[OG_WG / 64][2][64];     // stereo merge partial sums, per wave
     float gband[2][24];               // denormalisation gains
     OgCeltHdr hdr;                    // the frame's side-info, staged once (uniform control code reads it from LDS)
     float red[4];
@@ -169,67 +168,31 @@ template <class T> OG_DEV T og_uniform(const T &v)     // load a wave-uniform re
 template <class T> OG_DEV T og_uniform(const T &v) { return v; }
 #endif
 
-// One lock-step transform pass over the tasks of level `lvl`: every lane owns eight (buffer, bin) slots; loads are
-// issued four slots at a time before anything consumes them, so their LDS latencies overlap.
-//   PRE:  lb_all <- Haar steps + deinterleave_hadamard of the folding source (celt/decoder.rs:1708-1768), for the
-//         level's tasks that fold;
-//   !PRE: tmp_all <- interleave_hadamard + the Haar steps that undo time-division and recombination (:1994-2019), for
-//         the level's tasks that have a transform.
-// maxcnt = the largest 2^m among them (uniform loop bound).
+// The transform of one quant_band call, by one wave (inside an OG_WAVES section; the task record is wave-uniform, so
+// its fields sit in scalar registers and the lanes only do the gather):
+//   PRE:  lb_all <- Haar steps + deinterleave_hadamard of the folding source (celt/decoder.rs:1708-1768);
+//   !PRE: tmp_all <- interleave_hadamard + the Haar steps that undo time-division and recombination (:1994-2019).
 template <bool PRE>
-OG_DEV void og_level_xform(OgCeltLds &L, int lvl, int maxcnt)
+OG_DEV void og_task_xform(OgCeltLds &L, const OgTask tk, int slot)
 {
-    const float *src = PRE ? &L.u.norm[0][0] : &L.X[0][0];
-    float *dst = PRE ? L.v.b.lb_all : L.v.b.tmp_all;
-    OG_LANES_BEGIN(tid)
-    for (int half = 0; half < 2; half++) {
-        int band[4], sbase[4], base[4], cnt[4], sh[4], slog[4], n0p[4], had[4], pp[4], dsti[4];
-        float acc[4], scale[4];
-        bool ok[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int e = tid + (half * 4 + k) * OG_WG, ec = e < 1920 ? e : 1919;
-            band[k] = L.bin2band[ec >= 960 ? ec - 960 : ec];
+    const int n = tk.n, rc = tk.rctd & 15, td = tk.rctd >> 4, m = rc + td, hm = tk.hm;
+    const int cnt = hm ? 1 << m : 1, sh = hm ? __builtin_ctz((unsigned)hm) : 0;
+    const int slog = tk.slog, n0p = tk.n0p, had = (tk.flags & OG_T_LONG) != 0;
+    const float scale = hm ? (m & 1 ? 0.70710678118654752440f : 1.f) / (float)(1 << (m >> 1)) : 1.f;
+    const float *src = PRE ? &L.u.norm[0][0] + ((tk.flags & OG_T_LB_ROW1) ? 800 : 0) + tk.lowpos : &L.X[0][0] + slot * 960 + tk.boff;
+    float *dst = (PRE ? L.v.b.lb_all : L.v.b.tmp_all) + slot * 960 + tk.boff;
+    OG_WAVE_BEGIN(lane)
+    for (int p = lane; p < n; p += 64) {
+        const int base = p & ~hm, ph = (p >> sh) & (cnt - 1);
+        float acc = 0.f;
+        for (int j = 0; j < cnt; j++) {
+            const int sidx = base | (j << sh);
+            const float v = src[PRE ? sidx : og_reorder(slog, n0p, had, sidx)];
+            acc += (__builtin_popcount((unsigned)(ph & j)) & 1) ? -v : v;
         }
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int e = tid + (half * 4 + k) * OG_WG, ec = e < 1920 ? e : 1919;
-            const int slot = ec >= 960, bin = ec - 960 * slot;
-            const OgTask tk = ((const OgTask *)L.plan_head)[(band[k] == 255 ? 0 : band[k]) * 2 + slot];
-            const int rc = tk.rctd & 15, td = tk.rctd >> 4, m = rc + td;
-            ok[k] = e < 1920 && band[k] != 255 && (tk.flags & OG_T_ACTIVE) && tk.level == lvl &&
-                    (PRE ? (tk.flags & OG_T_NEED_LB) != 0 : (tk.hm | tk.slog) != 0);
-            const int p = ok[k] ? bin - tk.boff : 0, hm = ok[k] ? tk.hm : 0;
-            pp[k] = p;
-            cnt[k] = hm ? 1 << m : 1;
-            sh[k] = hm ? __builtin_ctz((unsigned)hm) : 0;
-            base[k] = p & ~hm;
-            slog[k] = ok[k] ? tk.slog : 0; n0p[k] = tk.n0p; had[k] = (tk.flags & OG_T_LONG) != 0;
-            scale[k] = hm ? (m & 1 ? 0.70710678118654752440f : 1.f) / (float)(1 << (m >> 1)) : 1.f;
-            if (PRE) {
-                sbase[k] = ok[k] ? ((tk.flags & OG_T_LB_ROW1) ? 800 : 0) + tk.lowpos : 0;
-                dsti[k] = slot * 960 + tk.boff + og_reorder(slog[k], n0p[k], had[k], p);
-            } else {
-                sbase[k] = ok[k] ? slot * 960 + tk.boff : 0;
-                dsti[k] = ec;
-            }
-            acc[k] = 0.f;
-        }
-        for (int j = 0; j < maxcnt; j++) {
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const bool on = ok[k] && j < cnt[k];
-                const int q = on ? j << sh[k] : 0, sidx = base[k] | q;
-                const float v = src[sbase[k] + (PRE ? sidx : og_reorder(slog[k], n0p[k], had[k], sidx))];
-                const float wgt = on ? ((__builtin_popcount((unsigned)(pp[k] & q)) & 1) ? -1.f : 1.f) : 0.f;
-                acc[k] += wgt * v;
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-            if (ok[k]) dst[dsti[k]] = acc[k] * scale[k];
+        dst[PRE ? og_reorder(slog, n0p, had, p) : p] = acc * scale;
     }
-    OG_LANES_END
+    OG_WAVE_END
 }
 
 // One live fill leaf (celt/decoder.rs:1633-1661 + renormalize_vector :788-794), by wave w alone: n <= 176, at most
@@ -274,11 +237,12 @@ OG_DEV void og_fill_op(OgBandCtx &c, int k, int w)
 
 // celt/decoder.rs:2037-2220 with the range-decoder half removed (the host ran it) and the integer recurrences
 // (fill masks, noise seeds, collapse masks, dependency levels) already resolved by the plan kernel (celt_plan.h).
-// What is left is sample work, level by level:
-//   level 0   every quant_band call without fill leaves: fused reorder + lowband_out, two lock-step regions;
-//   level l   calls with fill leaves whose folding sources are complete: transformed lowband copies (one region), the
-//             fill leaves themselves (one per wave at a time), then the same two regions as level 0;
-//   merges    the mid/side -> left/right rotations of all joint bands in lock-step (norm keeps the mid, so nothing
+// What is left is sample work on independent quant_band calls ("tasks"), dealt out to the waves level by level:
+//   level 0   every call without fill leaves;
+//   level l   calls with fill leaves whose folding sources are complete.
+// A wave takes a task from start to end -- transformed lowband copy, fill leaves, reorder + Haar, lowband_out -- with
+// no workgroup barrier (the tasks of a level touch disjoint coefficients); the workgroup meets once per level.
+//   merges    the mid/side -> left/right rotations, one joint band per wave at a time (norm keeps the mid, so nothing
 //             downstream of a band needs its merged form).
 OG_DEV void og_celt_bands(OgBandCtx &c)
 {
@@ -300,76 +264,49 @@ OG_DEV void og_celt_bands(OgBandCtx &c)
             for (int p = tid; p < cnt; p += OG_WG) L.u.norm[0][p] = 0.5f * (L.u.norm[0][p] + L.u.norm[1][p]);
             OG_LANES_END
         }
-        const int maxcnt = (int)OG_U32(PL->lvl_maxcnt[lvl]);
-        if (lvl > 0) {
-            og_level_xform<true>(L, lvl, maxcnt ? maxcnt : 1);
-            OG_WAVES_BEGIN(w)
-            const int k1 = (int)OG_U32(PL->op_start[lvl + 1]);
-            for (int k = (int)OG_U32(PL->op_start[lvl]) + w; k < k1; k += OG_WG / 64) og_fill_op(c, k, w);
-            OG_WAVES_END
-        }
-        if (maxcnt) og_level_xform<false>(L, lvl, maxcnt);
-        OG_LANES_BEGIN(tid)                             // copy-back + lowband_out = sqrt(N0) * x (celt/decoder.rs:2021-2028)
-        for (int half = 0; half < 2; half++) {
-            int band[4];
-            float xv[4], tv[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int e = tid + (half * 4 + k) * OG_WG, ec = e < 1920 ? e : 1919;
-                band[k] = L.bin2band[ec >= 960 ? ec - 960 : ec];
-                xv[k] = Xf[ec];
-                tv[k] = L.v.b.tmp_all[ec];
-            }
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int e = tid + (half * 4 + k) * OG_WG, ec = e < 1920 ? e : 1919;
-                const int slot = ec >= 960, bin = ec - 960 * slot;
-                const OgTask tk = tasks[(band[k] == 255 ? 0 : band[k]) * 2 + slot];
-                if (e >= 1920 || band[k] == 255 || !(tk.flags & OG_T_ACTIVE) || tk.level != lvl) continue;
-                float v = xv[k];
-                if (tk.hm | tk.slog) { v = tv[k]; Xf[ec] = v; }
-                if (tk.norm_row != 0xFF) L.u.norm[tk.norm_row][bin - norm_offset] = sqrtf((float)tk.n) * v;
+        OG_WAVES_BEGIN(w)
+        const int t1 = (int)OG_U32(PL->task_start[lvl + 1]);
+        for (int ti = (int)OG_U32(PL->task_start[lvl]) + w; ti < t1; ti += OG_WG / 64) {
+            const int id = (int)OG_U32(PL->order[ti]), slot = id & 1;
+            const OgTask tk = og_uniform(tasks[id]);
+            if (tk.flags & OG_T_NEED_LB) og_task_xform<true>(L, tk, slot);
+            const int k0 = tk.ops & 1023, k1 = k0 + (tk.ops >> 10);
+            for (int k = k0; k < k1; k++) og_fill_op(c, k, w);
+            const bool xf = (tk.hm | tk.slog) != 0;
+            if (xf) og_task_xform<false>(L, tk, slot);
+            if (xf || tk.norm_row != 0xFF) {            // copy-back + lowband_out = sqrt(N0) * x (celt/decoder.rs:2021-2028)
+                const int n = tk.n;
+                float *x = Xf + slot * 960 + tk.boff;
+                const float *t = L.v.b.tmp_all + slot * 960 + tk.boff;
+                float *nr = tk.norm_row != 0xFF ? &L.u.norm[tk.norm_row][tk.boff - norm_offset] : nullptr;
+                const float sq = sqrtf((float)n);
+                OG_WAVE_BEGIN(lane)
+                for (int p = lane; p < n; p += 64) {
+                    float v;
+                    if (xf) { v = t[p]; x[p] = v; } else v = x[p];
+                    if (nr) nr[p] = sq * v;
+                }
+                OG_WAVE_END
             }
         }
-        OG_LANES_END
+        OG_WAVES_END
         if (lvl == 0) OG_STAMP_TO(c.cycles, 17)
     }
 
     OG_STAMP_TO(c.cycles, 18)
-    // ---- merges: stereo_merge (celt/decoder.rs:796-827) + the N == 2 case (:1826-1862), all joint bands at once
+    // ---- merges: stereo_merge (celt/decoder.rs:796-827) + the N == 2 case (:1826-1862)
     if (C == 2) {
-        OG_LANES_BEGIN(tid)
-        if (tid < 21 * 12) {
-            const int i = tid / 12, sub = tid - 12 * i;
+        OG_WAVES_BEGIN(w)
+        for (int i = start + w; i < end; i += OG_WG / 64) {
+            const OgCeltBand bd = og_uniform(h->band[i]);
+            if (!(bd.flags & OG_B_JOINT)) continue;
             const int n = M * L.k.width[i];
-            float xy = 0.f, yy = 0.f;
-            if (i >= start && i < end && (h->band[i].flags & OG_B_JOINT) && n > 2) {
-                const float *x = L.X[0] + M * L.k.ebands[i], *y = L.X[1] + M * L.k.ebands[i];
-                float xs[15], ys[15];
-#pragma unroll
-                for (int q = 0; q < 15; q++) {          // n <= 176 = 12 * 14 + 8
-                    const int p = sub + 12 * q < n ? sub + 12 * q : 0;
-                    xs[q] = x[p]; ys[q] = y[p];
-                }
-#pragma unroll
-                for (int q = 0; q < 15; q++)
-                    if (sub + 12 * q < n) { xy += xs[q] * ys[q]; yy += ys[q] * ys[q]; }
-            }
-            L.mrg[i][sub][0] = xy;
-            L.mrg[i][sub][1] = yy;
-        }
-        OG_LANES_END
-        OG_LANES_BEGIN(tid)
-        if (tid < 21) {                                 // per band: x' = ax x + bx y, y' = ay x + by y
-            const int i = tid;
-            const OgCeltBand bd = h->band[i];
-            const int n = M * L.k.width[i];
-            float ax = 1.f, bx = 0.f, ay = 0.f, by = 1.f;
-            if (i >= start && i < end && (bd.flags & OG_B_JOINT)) {
-                const float mid = (1.f / 32768) * bd.imid, side = (1.f / 32768) * bd.iside;
-                const float inv = (bd.flags & OG_B_INV) ? -1.f : 1.f;
-                if (n == 2) {
-                    float *x = L.X[0] + M * L.k.ebands[i], *y = L.X[1] + M * L.k.ebands[i];
+            float *x = L.X[0] + M * L.k.ebands[i], *y = L.X[1] + M * L.k.ebands[i];
+            const float mid = (1.f / 32768) * bd.imid, side = (1.f / 32768) * bd.iside;
+            const float inv = (bd.flags & OG_B_INV) ? -1.f : 1.f;
+            if (n == 2) {
+                OG_WAVE_BEGIN(lane)
+                if (lane == 0) {
                     const int sw = (bd.flags & OG_B_N2SWAP) != 0;
                     float *x2 = sw ? y : x, *y2 = sw ? x : y;
                     const float sign = (bd.flags & OG_B_N2NEG) ? -1.f : 1.f;
@@ -378,39 +315,32 @@ OG_DEV void og_celt_bands(OgBandCtx &c)
                     x[0] *= mid; x[1] *= mid; y[0] *= side; y[1] *= side;
                     float t = x[0]; x[0] = t - y[0]; y[0] = inv * (t + y[0]);
                     t = x[1]; x[1] = t - y[1]; y[1] = inv * (t + y[1]);
-                } else {
-                    float xp = 0.f, sd = 0.f;
-                    for (int q = 0; q < 12; q++) { xp += L.mrg[i][q][0]; sd += L.mrg[i][q][1]; }
-                    xp *= mid;
-                    const float e = mid * mid + sd, e0 = e - 2.f * xp, e1 = e + 2.f * xp;
-                    if (e0 < 6e-4f || e1 < 6e-4f) {     // degenerate: y = x
-                        ay = inv; by = 0.f;
-                    } else {
-                        const float g0 = 1.f / sqrtf(e0), g1 = 1.f / sqrtf(e1);
-                        ax = g0 * mid; bx = -g0; ay = inv * g1 * mid; by = inv * g1;
-                    }
                 }
+                OG_WAVE_END
+                continue;
             }
-            L.mg[i][0] = ax; L.mg[i][1] = bx; L.mg[i][2] = ay; L.mg[i][3] = by;
+            float *pa = L.mrg[w][0], *pb = L.mrg[w][1];
+            OG_WAVE_BEGIN(lane)
+            float a = 0.f, b = 0.f;
+            for (int p = lane; p < n; p += 64) { a += x[p] * y[p]; b += y[p] * y[p]; }
+            pa[lane] = a; pb[lane] = b;
+            OG_WAVE_END
+            const float xp = mid * og_wave_tree_sum(pa), sd = og_wave_tree_sum(pb);
+            const float e = mid * mid + sd, e0 = e - 2.f * xp, e1 = e + 2.f * xp;
+            float ax = 1.f, bx = 0.f, ay = inv, by = 0.f;              // degenerate: y = x
+            if (!(e0 < 6e-4f || e1 < 6e-4f)) {
+                const float g0 = 1.f / sqrtf(e0), g1 = 1.f / sqrtf(e1);
+                ax = g0 * mid; bx = -g0; ay = inv * g1 * mid; by = inv * g1;
+            }
+            OG_WAVE_BEGIN(lane)
+            for (int p = lane; p < n; p += 64) {
+                const float xv = x[p], yv = y[p];
+                x[p] = ax * xv + bx * yv;
+                y[p] = ay * xv + by * yv;
+            }
+            OG_WAVE_END
         }
-        OG_LANES_END
-        OG_LANES_BEGIN(tid)
-        int band[4];
-        float xv[4], yv[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int bin = tid + k * OG_WG < 960 ? tid + k * OG_WG : 959;
-            band[k] = L.bin2band[bin]; xv[k] = L.X[0][bin]; yv[k] = L.X[1][bin];
-        }
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int bin = tid + k * OG_WG;
-            if (bin >= 960 || band[k] == 255) continue;
-            const OgF4 m4 = *(const OgF4 *)L.mg[band[k]];
-            L.X[0][bin] = m4.x * xv[k] + m4.y * yv[k];
-            L.X[1][bin] = m4.z * xv[k] + m4.w * yv[k];
-        }
-        OG_LANES_END
+        OG_WAVES_END
     }
     c.seed = PL->seed_out;
     OG_STAMP_TO(c.cycles, 19)

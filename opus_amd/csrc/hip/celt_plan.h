@@ -21,7 +21,7 @@ struct OgTask {                       // one quant_band call = (band, buffer), t
     uint16_t n0p, lowpos;             // OgXform.n0p; offset of the folding source in its norm row
     uint8_t flags, hm, slog, rctd;    // OG_T_*; OgXform.hm / .slog; recombine | time_divide << 4
     uint8_t norm_row, level;          // norm row lowband_out goes to (0xFF = none); dependency level
-    uint16_t pad_;
+    uint16_t ops;                     // its live fill leaves: first index in OgBandPlan.op | count << 10
 };
 enum { OG_T_ACTIVE = 1, OG_T_CHAIN = 2, OG_T_NEED_LB = 4, OG_T_LONG = 8, OG_T_LB_ROW1 = 16 };
 
@@ -30,7 +30,7 @@ struct OgFillOp {                     // one live fill leaf (celt/decoder.rs:163
     float gain;                       // the leaf's renormalisation target
     uint16_t pos;                     // buffer * 960 + first bin
     uint8_t n, flags;                 // width; OG_OP_FOLD: copy of the lower band + dither, else noise
-    uint8_t level, pad_[3];
+    uint8_t level, task, pad_[2];     // level and id of the quant_band call it belongs to
 };
 enum { OG_OP_FOLD = 1 };
 
@@ -44,6 +44,9 @@ struct alignas(16) OgBandPlan {
     uint8_t lvl_maxcnt[OG_MAXLEVEL + 1];   // per level: largest 2^m of its tasks' transforms (0 = no transform at all)
     uint8_t pad_[2];
     uint16_t op_start[OG_MAXLEVEL + 2];    // ops of level l: op[op_start[l]] .. op[op_start[l + 1]]
+    uint8_t order[44];                // active task ids sorted by level (band order inside a level)
+    uint8_t task_start[OG_MAXLEVEL + 3];   // tasks of level l: order[task_start[l]] .. order[task_start[l + 1]]
+    uint8_t pad2_[3];
     OgFillOp op[OG_MAXLEAF];          // ordered by level, decode order inside a level
     OgFillOp op_decode[OG_MAXLEAF];   // scratch: decode order
 };
@@ -101,7 +104,7 @@ OG_DEV void og_band_plan(const OgCeltHdr *h, const OgCeltLeaf *lv, const OgCeltT
         int cm[2] = {0, 0};
         for (int slot = 0; slot < 2; slot++) {
             OgTask &t = tk[slot];
-            t.boff = t.n = t.n0p = t.pad_ = 0; t.lowpos = 0;
+            t.boff = t.n = t.n0p = t.ops = 0; t.lowpos = 0;
             t.flags = t.hm = t.slog = t.rctd = t.level = 0; t.norm_row = 0xFF;
         }
         if (silence || i < start || i >= end) { P->task[2 * i] = tk[0]; P->task[2 * i + 1] = tk[1]; continue; }
@@ -178,6 +181,7 @@ OG_DEV void og_band_plan(const OgCeltHdr *h, const OgCeltLeaf *lv, const OgCeltT
                 }
                 const int g0 = bd.leaf0 + (slot ? bd.nx : 0), nfill = slot ? bd.fy : bd.fx;
                 int m = (int)cm_row[slot * 24 + i];     // PVQ leaves: expanded (and masks collected) by K1
+                int live = 0;
                 for (int l = 0; l < nfill && g0 + l < nleaves; l++) {
                     const OgCeltLeaf lf = lv[g0 + l];
                     const int Bl = 1 << (lf.meta & OG_L_LOGB_MASK), sh = lf.cmshift;
@@ -191,8 +195,9 @@ OG_DEV void og_band_plan(const OgCeltHdr *h, const OgCeltLeaf *lv, const OgCeltT
                         op.seed = seed; op.gain = lf.gain;
                         op.pos = (uint16_t)(slot * 960 + boff + lf.off);
                         op.n = (uint8_t)nn; op.flags = fold ? OG_OP_FOLD : 0;
-                        op.level = (uint8_t)lvl; op.pad_[0] = op.pad_[1] = op.pad_[2] = 0;
+                        op.level = (uint8_t)lvl; op.task = (uint8_t)(2 * i + slot); op.pad_[0] = op.pad_[1] = 0;
                         P->op_decode[nops++] = op;
+                        live++;
                     }
                     m |= (fold ? fl : (1 << Bl) - 1) << sh;
                     seed = la[nn] * seed + lc[nn];
@@ -200,6 +205,7 @@ OG_DEV void og_band_plan(const OgCeltHdr *h, const OgCeltLeaf *lv, const OgCeltT
                 for (int k = 0, Bk = B0[slot]; k < td[slot]; k++) { Bk >>= 1; m |= m >> Bk; }
                 for (int k = 0; k < rc[slot]; k++) m = K.bit_deinterleave[m & 255];
                 cm[slot] = m & ((1 << ((B0[slot] >> td[slot]) << rc[slot])) - 1);
+                t.ops = (uint16_t)(live << 10);     // the first index is filled in once the ops are sorted
             }
             if (any_chain) blevel[i] = (uint8_t)lvl;
             if (lvl > maxlvl) maxlvl = lvl;
@@ -230,10 +236,26 @@ OG_DEV void og_band_plan(const OgCeltHdr *h, const OgCeltLeaf *lv, const OgCeltT
     for (int j = 0; j < nops; j++) cursor[P->op_decode[j].level + 1]++;
     for (int l = 0; l <= OG_MAXLEVEL; l++) cursor[l + 1] = (uint16_t)(cursor[l + 1] + cursor[l]);
     for (int l = 0; l <= OG_MAXLEVEL + 1; l++) P->op_start[l] = cursor[l];
+    int prev_task = -1;
     for (int j = 0; j < nops; j++) {
         const OgFillOp op = P->op_decode[j];
-        P->op[cursor[op.level]++] = op;
+        const int at = cursor[op.level]++;
+        P->op[at] = op;
+        if (op.task != prev_task) {                     // a task's ops are consecutive before and after the (stable) sort
+            P->task[op.task].ops = (uint16_t)(P->task[op.task].ops | at);
+            prev_task = op.task;
+        }
     }
+    // counting sort of the active tasks by level (stable: band order inside a level)
+    uint8_t tcur[OG_MAXLEVEL + 3];
+    for (int l = 0; l <= OG_MAXLEVEL + 2; l++) tcur[l] = 0;
+    for (int t = 0; t < 42; t++)
+        if (P->task[t].flags & OG_T_ACTIVE) tcur[P->task[t].level + 1]++;
+    for (int l = 0; l <= OG_MAXLEVEL + 1; l++) tcur[l + 1] = (uint8_t)(tcur[l + 1] + tcur[l]);
+    for (int l = 0; l <= OG_MAXLEVEL + 2; l++) P->task_start[l] = tcur[l];
+    for (int t = 0; t < 42; t++)
+        if (P->task[t].flags & OG_T_ACTIVE) P->order[tcur[P->task[t].level]++] = (uint8_t)t;
+    P->pad2_[0] = P->pad2_[1] = P->pad2_[2] = 0;
 }
 
 // Scratch shared by the CELT kernels (layout of `work`, include/opusgpu.h), one block per frame so that the layout does
