@@ -65,14 +65,23 @@ int device_fail(hipError_t e, const char *what)
     return OPUSGPU_DEVICE;
 }
 
+// Per-device context, built once: the constant tables, and three side streams + events with which a launch runs its
+// four K1 size classes side by side (each class alone is latency-bound at low occupancy; together they overlap).
+struct DevCtx {
+    OgCeltTables *tables = nullptr;
+    hipStream_t side[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t fork = nullptr, join[3] = {nullptr, nullptr, nullptr};
+};
 static std::mutex g_tables_mu;
-static OgCeltTables *g_celt_tables[64];
+static std::mutex g_fork_mu;            // fork / join sequences on the shared side streams are enqueued one launch at a time
+static DevCtx g_ctx[64];
 
-int celt_tables_for_device(int device, const OgCeltTables **out)
+static int ctx_for_device(int device, DevCtx **out)
 {
     if (device < 0 || device >= 64) return OPUSGPU_BAD_ARG;
     std::lock_guard<std::mutex> lk(g_tables_mu);
-    if (!g_celt_tables[device]) {
+    DevCtx &c = g_ctx[device];
+    if (!c.tables) {
         int prev = 0;
         OG_HIP(hipGetDevice(&prev));
         OG_HIP(hipSetDevice(device));
@@ -81,11 +90,25 @@ int celt_tables_for_device(int device, const OgCeltTables **out)
         hipError_t e = hipMalloc(&dev, sizeof(OgCeltTables));
         if (e == hipSuccess) e = hipMemcpy(dev, host, sizeof(OgCeltTables), hipMemcpyHostToDevice);
         delete host;
+        for (int k = 0; k < 3 && e == hipSuccess; k++) {
+            e = hipStreamCreateWithFlags(&c.side[k], hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&c.join[k], hipEventDisableTiming);
+        }
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c.fork, hipEventDisableTiming);
         (void)hipSetDevice(prev);
-        if (e != hipSuccess) return device_fail(e, "celt tables upload");
-        g_celt_tables[device] = dev;
+        if (e != hipSuccess) return device_fail(e, "celt device set-up");
+        c.tables = dev;
     }
-    *out = g_celt_tables[device];
+    *out = &c;
+    return OPUSGPU_OK;
+}
+
+int celt_tables_for_device(int device, const OgCeltTables **out)
+{
+    DevCtx *c;
+    int rc = ctx_for_device(device, &c);
+    if (rc) return rc;
+    *out = c->tables;
     return OPUSGPU_OK;
 }
 
@@ -113,27 +136,44 @@ int opusgpu_launch_celt(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, uint32_t
     if (nrefs && !refs) return OPUSGPU_BAD_ARG;
     int device = 0;
     OG_HIP(hipGetDevice(&device));
-    const OgCeltTables *T;
-    int rc = og::celt_tables_for_device(device, &T);
+    og::DevCtx *ctx;
+    int rc = og::ctx_for_device(device, &ctx);
     if (rc) return rc;
+    const OgCeltTables *T = ctx->tables;
     OgCeltDebug dbg = {nullptr, nullptr, nullptr, nullptr, nullptr};
     if (debug) dbg = *debug;
     hipStream_t st = (hipStream_t)stream;
     // K1: one launch per size class (refs are sorted by decreasing N): the many small leaves do not pay the 45 KB of
-    // LDS per wavefront that the few 176-wide ones need.
+    // LDS per wavefront that the few 176-wide ones need.  The first class present runs on the caller's stream, the
+    // others on the side streams, forked from and joined back into the caller's stream with events.
     {
+        std::lock_guard<std::mutex> lk(og::g_fork_mu);
+        int nclasses = 0;
+        for (int c = 0; c < 4; c++) nclasses += class_counts[c] != 0;
+        if (nclasses > 1) OG_HIP(hipEventRecord(ctx->fork, st));
         const OgLeafRef *r = refs;
-#define OG_PVQ_CLASS(NMAX, cnt)                                                                                           \
-        if (cnt) {                                                                                                        \
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(og_pvq_kernel<NMAX>), dim3(((cnt) + 63) / 64), dim3(64), 0, st, r, (cnt), hdr,   \
-                               leaves, nframes, T, work, dbg.pulses, dbg.cycles);                                                     \
-            r += (cnt);                                                                                                   \
+        int used = 0;
+        bool first = true;
+        for (int c = 0; c < 4; c++) {
+            const uint32_t cnt = class_counts[c];
+            if (!cnt) continue;
+            hipStream_t cur = st;
+            if (!first) {
+                cur = ctx->side[used];
+                OG_HIP(hipStreamWaitEvent(cur, ctx->fork, 0));
+            }
+            const dim3 grid((cnt + 63) / 64), block(64);
+            switch (c) {
+            case 0: hipLaunchKernelGGL(HIP_KERNEL_NAME(og_pvq_kernel<176>), grid, block, 0, cur, r, cnt, hdr, leaves, nframes, T, work, dbg.pulses, dbg.cycles); break;
+            case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(og_pvq_kernel<64>), grid, block, 0, cur, r, cnt, hdr, leaves, nframes, T, work, dbg.pulses, dbg.cycles); break;
+            case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(og_pvq_kernel<24>), grid, block, 0, cur, r, cnt, hdr, leaves, nframes, T, work, dbg.pulses, dbg.cycles); break;
+            default: hipLaunchKernelGGL(HIP_KERNEL_NAME(og_pvq_kernel<8>), grid, block, 0, cur, r, cnt, hdr, leaves, nframes, T, work, dbg.pulses, dbg.cycles); break;
+            }
+            if (!first) OG_HIP(hipEventRecord(ctx->join[used++], cur));
+            first = false;
+            r += cnt;
         }
-        OG_PVQ_CLASS(176, class_counts[0])
-        OG_PVQ_CLASS(64, class_counts[1])
-        OG_PVQ_CLASS(24, class_counts[2])
-        OG_PVQ_CLASS(8, class_counts[3])
-#undef OG_PVQ_CLASS
+        for (int k = 0; k < used; k++) OG_HIP(hipStreamWaitEvent(st, ctx->join[k], 0));
     }
     const uint32_t groups = (nframes + frames_per_group - 1) / frames_per_group;
     hipLaunchKernelGGL(og_plan_kernel, dim3((nframes + 63) / 64), dim3(64), 0, st, hdr, leaves, nframes, T, work);
