@@ -76,6 +76,13 @@ OG_DEV void og_uniform_dot2(const float *x, const float *y, int n, float *xy, fl
 }
 // sum of part[0..63] inside a single-wave section, same association order on the GPU and in the emulation
 OG_DEV float og_wave_tree_sum(const float *part) { return og_wave_sum(part[threadIdx.x & 63]); }
+// sum over the 16-lane group of `lane` (every lane of the wave must call it)
+OG_DEV float og_group16_sum(const float *part, int lane)
+{
+    float v = part[lane];
+    for (int m = 8; m; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
 #else
 #define OG_BARRIER
 OG_DEV float og_wave_tree_sum(const float *part)
@@ -87,6 +94,16 @@ OG_DEV float og_wave_tree_sum(const float *part)
         for (int i = 0; i < 64; i++) v[i] = w[i];
     }
     return v[0];
+}
+OG_DEV float og_group16_sum(const float *part, int lane)
+{
+    float v[16], w[16];
+    for (int i = 0; i < 16; i++) v[i] = part[(lane & ~15) + i];
+    for (int m = 8; m; m >>= 1) {
+        for (int i = 0; i < 16; i++) w[i] = v[i] + v[i ^ m];
+        for (int i = 0; i < 16; i++) v[i] = w[i];
+    }
+    return v[lane & 15];
 }
 OG_DEV float og_uniform_sumsq(const float *x, int n)
 {
@@ -294,49 +311,57 @@ OG_DEV void og_celt_bands(OgBandCtx &c)
     }
 
     OG_STAMP_TO(c.cycles, 18)
-    // ---- merges: stereo_merge (celt/decoder.rs:796-827) + the N == 2 case (:1826-1862)
+    // ---- merges: stereo_merge (celt/decoder.rs:796-827) + the N == 2 case (:1826-1862): a band per 16-lane group,
+    //      four bands per wave at a time (the dot products reduce inside the group, no barrier)
     if (C == 2) {
         OG_WAVES_BEGIN(w)
-        for (int i = start + w; i < end; i += OG_WG / 64) {
-            const OgCeltBand bd = og_uniform(h->band[i]);
-            if (!(bd.flags & OG_B_JOINT)) continue;
-            const int n = M * L.k.width[i];
-            float *x = L.X[0] + M * L.k.ebands[i], *y = L.X[1] + M * L.k.ebands[i];
-            const float mid = (1.f / 32768) * bd.imid, side = (1.f / 32768) * bd.iside;
-            const float inv = (bd.flags & OG_B_INV) ? -1.f : 1.f;
-            if (n == 2) {
-                OG_WAVE_BEGIN(lane)
-                if (lane == 0) {
-                    const int sw = (bd.flags & OG_B_N2SWAP) != 0;
-                    float *x2 = sw ? y : x, *y2 = sw ? x : y;
-                    const float sign = (bd.flags & OG_B_N2NEG) ? -1.f : 1.f;
-                    y2[0] = -sign * x2[1];
-                    y2[1] = sign * x2[0];
-                    x[0] *= mid; x[1] *= mid; y[0] *= side; y[1] *= side;
-                    float t = x[0]; x[0] = t - y[0]; y[0] = inv * (t + y[0]);
-                    t = x[1]; x[1] = t - y[1]; y[1] = inv * (t + y[1]);
-                }
-                OG_WAVE_END
-                continue;
-            }
+        for (int i0 = start + 4 * w; i0 < end; i0 += 4 * (OG_WG / 64)) {
             float *pa = L.mrg[w][0], *pb = L.mrg[w][1];
             OG_WAVE_BEGIN(lane)
+            const int i = i0 + (lane >> 4), l = lane & 15;
             float a = 0.f, b = 0.f;
-            for (int p = lane; p < n; p += 64) { a += x[p] * y[p]; b += y[p] * y[p]; }
+            if (i < end && (h->band[i].flags & OG_B_JOINT)) {
+                const int n = M * L.k.width[i];
+                const float *x = L.X[0] + M * L.k.ebands[i], *y = L.X[1] + M * L.k.ebands[i];
+                if (n > 2)
+                    for (int p = l; p < n; p += 16) { a += x[p] * y[p]; b += y[p] * y[p]; }
+            }
             pa[lane] = a; pb[lane] = b;
             OG_WAVE_END
-            const float xp = mid * og_wave_tree_sum(pa), sd = og_wave_tree_sum(pb);
-            const float e = mid * mid + sd, e0 = e - 2.f * xp, e1 = e + 2.f * xp;
-            float ax = 1.f, bx = 0.f, ay = inv, by = 0.f;              // degenerate: y = x
-            if (!(e0 < 6e-4f || e1 < 6e-4f)) {
-                const float g0 = 1.f / sqrtf(e0), g1 = 1.f / sqrtf(e1);
-                ax = g0 * mid; bx = -g0; ay = inv * g1 * mid; by = inv * g1;
-            }
             OG_WAVE_BEGIN(lane)
-            for (int p = lane; p < n; p += 64) {
-                const float xv = x[p], yv = y[p];
-                x[p] = ax * xv + bx * yv;
-                y[p] = ay * xv + by * yv;
+            const int i = i0 + (lane >> 4), l = lane & 15;
+            const float xy = og_group16_sum(pa, lane), yy = og_group16_sum(pb, lane);
+            if (i < end && (h->band[i].flags & OG_B_JOINT)) {
+                const OgCeltBand bd = h->band[i];
+                const int n = M * L.k.width[i];
+                float *x = L.X[0] + M * L.k.ebands[i], *y = L.X[1] + M * L.k.ebands[i];
+                const float mid = (1.f / 32768) * bd.imid, side = (1.f / 32768) * bd.iside;
+                const float inv = (bd.flags & OG_B_INV) ? -1.f : 1.f;
+                if (n == 2) {
+                    if (l == 0) {
+                        const int sw = (bd.flags & OG_B_N2SWAP) != 0;
+                        float *x2 = sw ? y : x, *y2 = sw ? x : y;
+                        const float sign = (bd.flags & OG_B_N2NEG) ? -1.f : 1.f;
+                        y2[0] = -sign * x2[1];
+                        y2[1] = sign * x2[0];
+                        x[0] *= mid; x[1] *= mid; y[0] *= side; y[1] *= side;
+                        float t = x[0]; x[0] = t - y[0]; y[0] = inv * (t + y[0]);
+                        t = x[1]; x[1] = t - y[1]; y[1] = inv * (t + y[1]);
+                    }
+                } else {
+                    const float xp = mid * xy, sd = yy;
+                    const float e = mid * mid + sd, e0 = e - 2.f * xp, e1 = e + 2.f * xp;
+                    float ax = 1.f, bx = 0.f, ay = inv, by = 0.f;      // degenerate: y = x
+                    if (!(e0 < 6e-4f || e1 < 6e-4f)) {
+                        const float g0 = 1.f / sqrtf(e0), g1 = 1.f / sqrtf(e1);
+                        ax = g0 * mid; bx = -g0; ay = inv * g1 * mid; by = inv * g1;
+                    }
+                    for (int p = l; p < n; p += 16) {
+                        const float xv = x[p], yv = y[p];
+                        x[p] = ax * xv + bx * yv;
+                        y[p] = ay * xv + by * yv;
+                    }
+                }
             }
             OG_WAVE_END
         }
@@ -677,10 +702,10 @@ OG_DEV void og_celt_frame(const OgCeltHdr *hg, const OgBandPlan *plan, const OgC
     const bool pf_on = pg0 != 0.f || pg1 != 0.f || (lm != 0 && pg2 != 0.f);
 
     OG_STAMP(7)
-    // ---- phases 6b + 7: comb filter, then de-emphasis t[j] = y[j] + 0.85 t[j-1] as a blocked scan (60 lanes x N/60
-    //      samples), one wave per channel with no workgroup barrier in between; then coalesced PCM + state write-back
+    // ---- phases 6b + 7: comb filter, then de-emphasis t[j] = y[j] + 0.85 t[j-1] as a blocked scan (N/15 lanes x 15
+    //      samples: an odd chunk length keeps the lanes' LDS accesses on distinct banks), one wave per channel with no workgroup barrier in between; then coalesced PCM + state write-back
     const float coef = 0.85000610f;
-    const int Lc = N / 60;
+    const int Lc = 15, nl = N / Lc;                     // 8 << lm lanes
     float *tbuf = &L.X[0][0];                           // [2][960], free since the FFT finished... (bufB may hold
                                                         // the spectrum when the stage count is odd; it was consumed above)
     float aL = 1.f;
@@ -696,7 +721,7 @@ OG_DEV void og_celt_frame(const OgCeltHdr *hg, const OgBandPlan *plan, const OgC
                                     T->window, L.k.pf_taps);
         }
         OG_WAVE_BEGIN(l)
-        if (l < 60) {
+        if (l < nl) {
             const float *y = y0 + l * Lc;
             float m = 0.f, t = 0.f;
             for (int j = 0; j < Lc; j++) { t = y[j] + m; m = coef * t; }
@@ -707,14 +732,14 @@ OG_DEV void og_celt_frame(const OgCeltHdr *hg, const OgBandPlan *plan, const OgC
         // more than `reach` chunks back are below 1e-9 of their chunk's value and are dropped
         const int reach = 128 / Lc + 1;
         OG_WAVE_BEGIN(l)
-        if (l < 60) {
+        if (l < nl) {
             const int q0 = l > reach ? l - reach : 0;
             float m = (reset || q0 > 0) ? 0.f : st->deemph[ch];
             for (int q = q0; q < l; q++) m = m * aL + L.carry[ch][q];
             const float *y = y0 + l * Lc;
             float *t = tbuf + ch * 960 + l * Lc;
             for (int j = 0; j < Lc; j++) { const float v = y[j] + m; m = coef * v; t[j] = v; }
-            if (l == 59) st->deemph[ch] = m;
+            if (l == nl - 1) st->deemph[ch] = m;
         }
         OG_WAVE_END
     }

@@ -6,25 +6,25 @@
 #include "../host/celt_tables.hpp"
 #include "device_util.hpp"
 
-// K1: 64 leaves per workgroup (one wavefront), vectors lane-interleaved in LDS: element i of lane l at x[i*64 + l], so
-// every access of the serial per-lane loops hits bank l (conflict-free).  NMAX bounds the leaf size of the launch's
-// size class; refs are sorted by decreasing size, so a class is a contiguous range.
-template <int NMAX>
-__global__ __launch_bounds__(64) void og_pvq_kernel(const OgLeafRef *__restrict__ refs, uint32_t nrefs,
-                                                    const OgCeltHdr *__restrict__ hdr, const OgCeltLeaf *__restrict__ leaves,
-                                                    uint32_t nframes, const OgCeltTables *__restrict__ T, void *work,
-                                                    int16_t *dbg_pulses, uint64_t *dbg_cycles)
+// K1: one lane per PVQ leaf, WGS / 64 wavefronts per workgroup sharing one copy of the unpacked U table.  A wave's 64
+// vectors are lane-interleaved in LDS: element i of lane l at x[i*64 + l], so every access of the serial per-lane loops
+// hits bank l (conflict-free).  NMAX bounds the leaf size of the launch's size class; refs are sorted by decreasing size,
+// so a class is a contiguous range.
+template <int NMAX, int WGS>
+__global__ __launch_bounds__(WGS) void og_pvq_kernel(const OgLeafRef *__restrict__ refs, uint32_t nrefs,
+                                                     const OgCeltHdr *__restrict__ hdr, const OgCeltLeaf *__restrict__ leaves,
+                                                     uint32_t nframes, const OgCeltTables *__restrict__ T, void *work,
+                                                     int16_t *dbg_pulses, uint64_t *dbg_cycles)
 {
-    __shared__ uint32_t U[1272];
-    __shared__ uint16_t row[16];
-    __shared__ float x[NMAX * 64];
-    for (int p = threadIdx.x; p < 1272; p += 64) U[p] = T->pvq_u[p];
-    if (threadIdx.x < 16) row[threadIdx.x] = T->pvq_row[threadIdx.x];
+    __shared__ uint32_t U2[15 * OG_U2_STRIDE];
+    __shared__ float x[NMAX * WGS];
+    for (int p = threadIdx.x; p < 15 * OG_U2_STRIDE; p += WGS) U2[p] = T->pvq_u2[p];
     __syncthreads();
-    const uint32_t g = blockIdx.x * 64 + threadIdx.x;
+    const uint32_t g = blockIdx.x * WGS + threadIdx.x;
     // profiling: lane 0 of each workgroup stamps its stages behind the per-frame stamps ([nframes][64]) of the buffer
-    uint64_t *stamps = dbg_cycles && threadIdx.x == 0 ? dbg_cycles + (size_t)nframes * 64 + ((size_t)NMAX * 4096 + blockIdx.x) * 4 : nullptr;
-    if (g < nrefs) og_pvq_lane(refs[g], hdr, leaves, nframes, work, U, row, x + threadIdx.x, 64, dbg_pulses, stamps);
+    uint64_t *stamps = dbg_cycles && threadIdx.x == 0 && blockIdx.x < 4096 ? dbg_cycles + (size_t)nframes * 64 + ((size_t)NMAX * 4096 + blockIdx.x) * 4 : nullptr;
+    if (g < nrefs)
+        og_pvq_lane(refs[g], hdr, leaves, nframes, work, U2, x + (threadIdx.x >> 6) * (NMAX * 64) + (threadIdx.x & 63), 64, dbg_pulses, stamps);
 }
 
 // Band plan: one lane per frame (celt_plan.h).
@@ -162,13 +162,16 @@ int opusgpu_launch_celt(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, uint32_t
                 cur = ctx->side[used];
                 OG_HIP(hipStreamWaitEvent(cur, ctx->fork, 0));
             }
-            const dim3 grid((cnt + 63) / 64), block(64);
+#define OG_PVQ_LAUNCH(NMAX, WGS)                                                                                          \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(og_pvq_kernel<NMAX, WGS>), dim3((cnt + (WGS) - 1) / (WGS)), dim3(WGS), 0, cur, r, cnt, \
+                               hdr, leaves, nframes, T, work, dbg.pulses, dbg.cycles)
             switch (c) {
-            case 0: hipLaunchKernelGGL(HIP_KERNEL_NAME(og_pvq_kernel<176>), grid, block, 0, cur, r, cnt, hdr, leaves, nframes, T, work, dbg.pulses, dbg.cycles); break;
-            case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(og_pvq_kernel<64>), grid, block, 0, cur, r, cnt, hdr, leaves, nframes, T, work, dbg.pulses, dbg.cycles); break;
-            case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(og_pvq_kernel<24>), grid, block, 0, cur, r, cnt, hdr, leaves, nframes, T, work, dbg.pulses, dbg.cycles); break;
-            default: hipLaunchKernelGGL(HIP_KERNEL_NAME(og_pvq_kernel<8>), grid, block, 0, cur, r, cnt, hdr, leaves, nframes, T, work, dbg.pulses, dbg.cycles); break;
+            case 0: OG_PVQ_LAUNCH(176, 64); break;
+            case 1: OG_PVQ_LAUNCH(64, 128); break;
+            case 2: OG_PVQ_LAUNCH(24, 256); break;
+            default: OG_PVQ_LAUNCH(8, 256); break;
             }
+#undef OG_PVQ_LAUNCH
             if (!first) OG_HIP(hipEventRecord(ctx->join[used++], cur));
             first = false;
             r += cnt;

@@ -11,94 +11,72 @@ OG_DEV uint32_t og_lcg(uint32_t s) { return 1664525u * s + 1013904223u; }   // c
 // ------------------------------------------------------------------------------------------------
 // K1: one lane expands one PVQ leaf.  Serial in N by nature (celt/decoder.rs:541-660); the
 // parallelism is across the ~10^5 leaves of a batch.
-OG_DEV uint32_t og_u(const uint32_t *U, const uint16_t *row, int n, int k)
+#define OG_U2_STRIDE 177              // U2[lo * 177 + hi] = U(lo, hi), lo = min(n, k) <= 14, hi = max(n, k) <= 176
+OG_DEV uint32_t og_u2(const uint32_t *U2, int n, int k)
 {
-    int lo = n < k ? n : k, hi = n < k ? k : n;
-    return U[row[lo] + hi];
+    const int lo = n < k ? n : k, hi = n < k ? k : n;
+    return U2[lo * OG_U2_STRIDE + hi];
 }
 
-// Writes the pulse vector as floats to x[0..n), returns ||y||^2; *cm = collapse mask for `blocks` blocks.
-OG_DEV uint32_t og_cwrsi(const uint32_t *U, const uint16_t *row, int n, int k, uint32_t i, float *x, int xs, int blocks,
-                         int *cm_out, int16_t *dbg)
+// cwrsi (celt/decoder.rs:541-660) as one branch-uniform loop, so that the 64 leaves of a wavefront -- each in a
+// different place of its own vector -- execute the same instructions.  The reference's two cases ("lots of pulses" /
+// "lots of dimensions") are two ways of walking the same search: with (n, k) dimensions / pulses left, the sign is
+// i >= U(n, k+1), and the number of pulses left after this coefficient is the largest k' <= k with U(n, k') <= i.
+// Every iteration probes two table entries whose addresses do not depend on each other:
+//   phase 0 (new coefficient): U(n, k) and U(n, k+1) -> sign, and a zero coefficient is finished in this iteration;
+//   phase 1 (search):          U(n, kk) and U(n, kk-1) -> two candidates per iteration.
+// Writes the pulse vector as floats to x[0], x[xs], ...; returns ||y||^2; *cm_out = collapse mask over `blocks` blocks.
+OG_DEV uint32_t og_cwrsi(const uint32_t *U2, int n, int k, uint32_t i, float *x, int xs, int blocks, int *cm_out, int16_t *dbg)
 {
-    uint32_t yy = 0, p, q;
-    int s, k0, val, cm = 0, pos = 0;
-    bool all_zero = false;
+    uint32_t yy = 0;
+    int cm = 0, pos = 0, s = 0, k0 = k, kk = k, phase = 0;
     const int nb = n / blocks;
     int bl = nb, bi = 0;
 #define OG_PUT(v)                                                                                                   \
     {                                                                                                               \
-        x[pos * xs] = (float)(v);                                                                                        \
+        x[pos * xs] = (float)(v);                                                                                   \
         if (dbg) dbg[pos] = (int16_t)(v);                                                                           \
         yy += (uint32_t)((v) * (v));                                                                                \
         if (v) cm |= 1 << bi;                                                                                       \
         pos++;                                                                                                      \
         if (--bl == 0) { bl = nb; bi++; }                                                                           \
     }
-    while (n > 2) {
-        if (k >= n) {                                   // lots of pulses
-            p = og_u(U, row, n, k + 1);
-            s = -(int)(i >= p);
-            i -= p & (uint32_t)s;
+    while (n > 2 && k > 0) {
+        const int kb = phase ? (kk > 0 ? kk - 1 : 0) : kk + 1;
+        const uint32_t pA = og_u2(U2, n, kk), pB = og_u2(U2, n, kb);
+        bool emit = false;
+        int val = 0;
+        if (!phase) {
+            s = -(int)(i >= pB);
+            i -= pB & (uint32_t)s;
             k0 = k;
-            q = og_u(U, row, n, n);
-            if (q > i) {
-                k = n;
-                do p = og_u(U, row, --k, n); while (p > i);
+            if (!s && pA <= i) { i -= pA; emit = true; }                     // this coefficient is zero
+            else { kk = k - 1; phase = 1; }                                     // pA > i here: at least one pulse
+        } else {
+            const bool atA = pA <= i, atB = pB <= i;
+            if (atA || atB) {
+                const int found = atA ? kk : kk - 1;
+                i -= atA ? pA : pB;
+                val = (k0 - found + s) ^ s;
+                k = found; kk = found; phase = 0;
+                emit = true;
             } else {
-                for (p = og_u(U, row, n, k); p > i; p = og_u(U, row, n, k)) k--;
+                kk -= 2;
             }
-            i -= p;
-            val = (k0 - k + s) ^ s;
-            OG_PUT(val)
-        } else {                                        // lots of dimensions: mostly zeros
-            if (k == 0) { all_zero = true; break; }     // every pulse placed: the rest is zeros, no table reads
-            // Rows k and k+1 of U are contiguous in n, so a run of zeros is decoded with the table reads of four
-            // steps in flight instead of one LDS round trip per coefficient.
-            const uint32_t *Rk = U + row[k], *Rk1 = U + row[k + 1];
-            bool zero = true;
-            while (n > 2 && k < n) {
-                const uint32_t p0 = Rk[n], q0 = Rk1[n], p1 = Rk[n - 1], q1 = Rk1[n - 1];
-                const uint32_t p2 = Rk[n - 2], q2 = Rk1[n - 2], p3 = Rk[n - 3], q3 = Rk1[n - 3];
-                if (!(p0 <= i && i < q0)) { zero = false; break; }
-                i -= p0; OG_PUT(0) n--;
-                if (!(n > 2 && k < n)) break;
-                if (!(p1 <= i && i < q1)) { zero = false; break; }
-                i -= p1; OG_PUT(0) n--;
-                if (!(n > 2 && k < n)) break;
-                if (!(p2 <= i && i < q2)) { zero = false; break; }
-                i -= p2; OG_PUT(0) n--;
-                if (!(n > 2 && k < n)) break;
-                if (!(p3 <= i && i < q3)) { zero = false; break; }
-                i -= p3; OG_PUT(0) n--;
-            }
-            if (!zero) {                                // a pulse sits at this position
-                q = Rk1[n];
-                s = -(int)(i >= q);
-                i -= q & (uint32_t)s;
-                k0 = k;
-                do p = og_u(U, row, --k, n); while (p > i);
-                i -= p;
-                val = (k0 - k + s) ^ s;
-                OG_PUT(val)
-                n--;
-            }
-            continue;
         }
-        n--;
+        if (emit) { OG_PUT(val) n--; }
     }
-    if (all_zero) {
-        for (; n > 0; n--) OG_PUT(0)
-    } else {
-        p = 2 * (uint32_t)k + 1;                        // n == 2
+    for (; n > 2; n--) OG_PUT(0)                                               // every pulse placed: the rest is zeros
+    {
+        uint32_t p = 2 * (uint32_t)k + 1;                                      // n == 2
         s = -(int)(i >= p);
         i -= p & (uint32_t)s;
         k0 = k;
         k = (int)((i + 1) >> 1);
         if (k) i -= 2 * (uint32_t)k - 1;
-        val = (k0 - k + s) ^ s;
+        int val = (k0 - k + s) ^ s;
         OG_PUT(val)
-        s = -(int)i;                                    // n == 1
+        s = -(int)i;                                                            // n == 1
         val = (k + s) ^ s;
         OG_PUT(val)
     }
@@ -191,29 +169,30 @@ OG_DEV void og_exp_rotation(float *x, int xs, int len, int stride, int k, int sp
 #else
 #define OG_PVQ_STAMP(k) {}
 #endif
-OG_DEV uint32_t og_pvq_leaf(const uint32_t *U, const uint16_t *row, const OgCeltLeaf &lf, int spread, float *x, int xs, int16_t *dbg,
+OG_DEV uint32_t og_pvq_leaf(const uint32_t *U2, const OgCeltLeaf &lf, int spread, float *x, int xs, int16_t *dbg,
                             uint64_t *stamps /* profiling aid, may be null */)
 {
     OG_PVQ_STAMP(0)
     const int Bl = 1 << (lf.meta & OG_L_LOGB_MASK);
     int cm;
-    const uint32_t yy = og_cwrsi(U, row, lf.n, lf.k, lf.index, x, xs, Bl, &cm, dbg);
+    const uint32_t yy = og_cwrsi(U2, lf.n, lf.k, lf.index, x, xs, Bl, &cm, dbg);
     OG_PVQ_STAMP(1)
     const float g = lf.gain / sqrtf((float)yy);
     for (int i = 0; i < lf.n; i++) x[i * xs] *= g;
+    OG_PVQ_STAMP(2)
     og_exp_rotation(x, xs, lf.n, Bl, lf.k, spread);
     return (uint32_t)cm << lf.cmshift;
 }
 
 // K1 body for one lane.  xl = this lane's vector storage (element stride xs), at least lf.n elements.
 OG_DEV void og_pvq_lane(const OgLeafRef ref, const OgCeltHdr *hdr, const OgCeltLeaf *leaves, uint32_t nframes, void *work,
-                        const uint32_t *U, const uint16_t *row, float *xl, int xs, int16_t *dbg_pulses, uint64_t *stamps)
+                        const uint32_t *U2, float *xl, int xs, int16_t *dbg_pulses, uint64_t *stamps)
 {
     const OgCeltLeaf lf = leaves[ref.leaf];
     const int ch = (lf.meta & OG_L_CH_Y) ? 1 : 0;
     const int spread = hdr[ref.frame].spread;
     int16_t *dbg = dbg_pulses ? dbg_pulses + (size_t)ref.frame * 1920 + ch * 960 + lf.pos : nullptr;
-    const uint32_t cm = og_pvq_leaf(U, row, lf, spread, xl, xs, dbg, stamps);
+    const uint32_t cm = og_pvq_leaf(U2, lf, spread, xl, xs, dbg, stamps);
     float *dst = og_work_coef(work, ref.frame) + ch * 960 + lf.pos;
     for (int i = 0; i < lf.n; i++) dst[i] = xl[i * xs];
     OG_ATOMIC_OR(og_work_cm(work, ref.frame) + ch * 24 + lf.band, cm);

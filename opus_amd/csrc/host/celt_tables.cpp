@@ -38,6 +38,11 @@ void og_fill_celt_tables(OgCeltTables *t)
     for (int i = 0; i < 32; i++) k.hadamard[i] = i < 30 ? CELT_HADAMARD_ORDERY[i] : 0;
     for (int i = 0; i < 1272; i++) t->pvq_u[i] = CELT_PVQ_U[i];
     for (int i = 0; i < 16; i++) t->pvq_row[i] = i < 15 ? CELT_PVQ_U_ROW[i] : 0;
+    for (int lo = 0; lo < 15; lo++)
+        for (int hi = 0; hi < 177; hi++) {
+            const int idx = CELT_PVQ_U_ROW[lo] + hi, end = lo < 14 ? CELT_PVQ_U_ROW[lo + 1] + lo + 1 : 1272;
+            t->pvq_u2[lo * 177 + hi] = (hi >= lo && idx < end) ? CELT_PVQ_U[idx] : 0xFFFFFFFFu;
+        }
     for (int lm = 0; lm < 4; lm++)
         for (int j = 0; j < 960; j++) {
             int b = 255;

@@ -22,7 +22,7 @@ extern "C" int emu_launch_celt(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, u
             if (!lf.k || (lf.meta & OG_L_N1)) continue;
             float x[176];
             OgLeafRef ref = {hdr[f].leaf_begin + l, f};
-            og_pvq_lane(ref, hdr, leaves, nframes, work.data(), T.pvq_u, T.pvq_row, x, 1, dbg ? dbg->pulses : nullptr, nullptr);
+            og_pvq_lane(ref, hdr, leaves, nframes, work.data(), T.pvq_u2, x, 1, dbg ? dbg->pulses : nullptr, nullptr);
         }
     for (uint32_t f = 0; f < nframes; f++) og_plan_frame(hdr, leaves, nframes, f, &T, work.data());
     for (uint32_t f = 0; f < nframes; f++) {
@@ -60,4 +60,19 @@ extern "C" void emu_plan_stats(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, u
     int mc = 0;
     for (int l = 0; l <= OG_MAXLEVEL; l++) if (P->lvl_maxcnt[l] > mc) mc = P->lvl_maxcnt[l];
     out[6] = mc; out[7] = hdr[f].nleaves;
+}
+
+// The kernel's cwrsi alone (celt_pvq.h), for known-answer and exhaustive comparisons with the oracle's.
+extern "C" uint32_t emu_cwrsi(int n, int k, uint32_t i, int blocks, int32_t *y, int32_t *cm)
+{
+    static OgCeltTables T;
+    static bool init = false;
+    if (!init) { og_fill_celt_tables(&T); init = true; }
+    float x[176];
+    int16_t p[176];
+    int m = 0;
+    const uint32_t yy = og_cwrsi(T.pvq_u2, n, k, i, x, 1, blocks, &m, p);
+    for (int j = 0; j < n; j++) y[j] = p[j];
+    *cm = m;
+    return yy;
 }

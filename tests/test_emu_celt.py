@@ -69,3 +69,47 @@ def test_emu_synthetic(emu, payload):
     pk = synth.celt_fb_stereo_packets(range(6), 25, payload)
     for s in range(6):
         _run(emu, [pk[s, f].tobytes() for f in range(25)], 2)
+
+
+def test_kernel_cwrsi_kats_and_exhaustive(emu):
+    """the kernel's branch-uniform cwrsi (celt_pvq.h) against the reference's known answers (celt/decoder.rs:2414-2434),
+    the oracle on every index of small codebooks, and on random indices of large ones (incl. the largest, V < 2^32)"""
+    L = orc.lib()
+    emu.emu_cwrsi.restype = C.c_uint32
+    emu.emu_cwrsi.argtypes = [C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
+
+    def both(n, k, i, blocks=1):
+        y, cm = (C.c_int32 * n)(), C.c_int32()
+        norm = emu.emu_cwrsi(n, k, i, blocks, y, C.byref(cm))
+        ry = (C.c_int * n)()
+        rnorm = L.orc_cwrsi(n, k, i, ry)
+        assert norm == rnorm and list(y) == list(ry), (n, k, i, list(y), list(ry))
+        if blocks > 1:
+            assert cm.value == L.orc_extract_collapse_mask(ry, n, blocks), (n, k, i)
+        return list(y), norm
+
+    for kat in orc.kats()["cwrsi"]:
+        y, norm = both(kat["n"], kat["k"], kat["i"])
+        assert y == kat["y"] and norm == kat["norm"]
+    for n in range(2, 8):
+        for k in range(1, 7):
+            for i in range(L.orc_pvq_v(n, k)):
+                both(n, k, i, 2 if n % 2 == 0 else 1)
+    rng = np.random.default_rng(7)
+    row = [0, 176, 351, 525, 698, 870, 1041, 1131, 1178, 1207, 1226, 1240, 1248, 1254, 1257, 1272 - 15]   # celt/decoder.rs:410-413
+
+    def in_table(a, b):                                 # is U(a, b) tabulated, i.e. does the codebook fit 32 bits
+        lo, hi = min(a, b), max(a, b)
+        return lo <= 14 and row[lo] + hi < row[lo + 1] + lo + 1
+
+    big = []
+    for n in (2, 3, 4, 5, 6, 7, 8, 9, 11, 12, 16, 18, 22, 24, 32, 36, 44, 48, 64, 72, 88, 96, 144, 176):
+        kmax = max(k for k in range(1, 177) if in_table(n, k) and in_table(n, k + 1))
+        big += [(n, kmax), (n, max(1, kmax // 2)), (n, 1)]
+    tested = 0
+    for n, k in big:
+        tested += 1
+        v = L.orc_pvq_v(n, k)
+        for i in [0, 1, v - 1, v - 2, v // 2] + [int(t) for t in rng.integers(0, v, 60)]:
+            both(n, k, i, 8 if n % 8 == 0 else 1)
+    assert tested >= 8
