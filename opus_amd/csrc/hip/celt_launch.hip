@@ -27,12 +27,26 @@ __global__ __launch_bounds__(WGS) void og_pvq_kernel(const OgLeafRef *__restrict
         og_pvq_lane(refs[g], hdr, leaves, nframes, work, U2, x + (threadIdx.x >> 6) * (NMAX * 64) + (threadIdx.x & 63), 64, dbg_pulses, stamps);
 }
 
-// Band plan: one lane per frame (celt_plan.h).
+// Band plan: one lane per frame (celt_plan.h).  The serial per-lane code is a chain of dependent loads, so what it reads
+// sits in LDS: the workgroup's 64 headers (copied in coalesced; a lane's header is 167 dwords from its neighbour's, an
+// odd stride, so the lanes' reads fall on distinct banks), the small constant tables, and a byte row of scratch per lane.
 __global__ __launch_bounds__(64) void og_plan_kernel(const OgCeltHdr *__restrict__ hdr, const OgCeltLeaf *__restrict__ leaves,
                                                      uint32_t nframes, const OgCeltTables *__restrict__ T, void *work)
 {
-    const uint32_t f = blockIdx.x * 64 + threadIdx.x;
-    if (f < nframes) og_plan_frame(hdr, leaves, nframes, f, T, work);
+    static_assert(sizeof(OgCeltHdr) % 4 == 0, "headers are copied as dwords");
+    __shared__ uint32_t hs[64 * sizeof(OgCeltHdr) / 4];
+    __shared__ OgCeltConst K;
+    __shared__ uint32_t la[184], lc[184];
+    __shared__ uint8_t tl[44 * 64];
+    const uint32_t f0 = blockIdx.x * 64, nf = nframes - f0 < 64 ? nframes - f0 : 64;
+    const uint32_t *src = (const uint32_t *)(hdr + f0);
+    for (uint32_t p = threadIdx.x; p < nf * (sizeof(OgCeltHdr) / 4); p += 64) hs[p] = src[p];
+    for (int p = threadIdx.x; p < (int)(sizeof(OgCeltConst) / 4); p += 64) ((uint32_t *)&K)[p] = ((const uint32_t *)&T->k)[p];
+    for (int p = threadIdx.x; p < 184; p += 64) { la[p] = T->lcg_a[p]; lc[p] = T->lcg_c[p]; }
+    __syncthreads();
+    const uint32_t f = f0 + threadIdx.x;
+    if (f < nframes)
+        og_plan_frame((const OgCeltHdr *)hs + threadIdx.x, leaves, f, K, la, lc, work, tl + threadIdx.x, 64);
 }
 
 __global__ __launch_bounds__(OG_WG, 4) void og_celt_kernel(const OgCeltHdr *__restrict__ hdr, uint32_t nframes, uint32_t frames_per_group,

@@ -82,11 +82,10 @@ OG_DEV void og_make_xform(int n, int B, int tf_change, OgXform *t, int *recombin
 
 // Everything here is per-lane serial code on global memory.  coef_row: the frame's K1 output (the signs of the
 // one-bin bands are added to it); cm_row: K1's collapse masks [buffer][24].
-OG_DEV void og_band_plan(const OgCeltHdr *h, const OgCeltLeaf *lv, const OgCeltTables *T, const uint32_t *cm_row, float *coef_row,
-                         OgBandPlan *P)
+// K, la, lc: the small constant tables (LDS copies in the kernel); tl[t * ts]: 42 bytes of scratch private to the lane.
+OG_DEV void og_band_plan(const OgCeltHdr *h, const OgCeltLeaf *lv, const OgCeltConst &K, const uint32_t *la, const uint32_t *lc,
+                         const uint32_t *cm_row, float *coef_row, OgBandPlan *P, uint8_t *tl, int ts)
 {
-    const OgCeltConst &K = T->k;
-    const uint32_t *la = T->lcg_a, *lc = T->lcg_c;
     const int lm = h->lm, M = 1 << lm, start = h->start, end = h->end;
     const int C = (h->flags & OG_F_STEREO) ? 2 : 1;
     const int B = (h->flags & OG_F_TRANSIENT) ? M : 1;
@@ -107,7 +106,11 @@ OG_DEV void og_band_plan(const OgCeltHdr *h, const OgCeltLeaf *lv, const OgCeltT
             t.boff = t.n = t.n0p = t.ops = 0; t.lowpos = 0;
             t.flags = t.hm = t.slog = t.rctd = t.level = 0; t.norm_row = 0xFF;
         }
-        if (silence || i < start || i >= end) { P->task[2 * i] = tk[0]; P->task[2 * i + 1] = tk[1]; continue; }
+        if (silence || i < start || i >= end) {
+            P->task[2 * i] = tk[0]; P->task[2 * i + 1] = tk[1];
+            tl[(2 * i) * ts] = tl[(2 * i + 1) * ts] = 0xFF;
+            continue;
+        }
         const OgCeltBand bd = h->band[i];
         const int n = M * K.width[i], boff = M * K.ebands[i];
         const bool dual = (bd.flags & OG_B_DUAL) != 0;
@@ -220,6 +223,8 @@ OG_DEV void og_band_plan(const OgCeltHdr *h, const OgCeltLeaf *lv, const OgCeltT
         col1[i] = (uint8_t)(dual ? cm[1] : C == 1 ? cm[0] : (cm[0] | cm[1]));
         P->task[2 * i] = tk[0];
         P->task[2 * i + 1] = tk[1];
+        for (int slot = 0; slot < 2; slot++)            // level of the active tasks, kept where the sort below reads it cheaply
+            tl[(2 * i + slot) * ts] = (tk[slot].flags & OG_T_ACTIVE) ? tk[slot].level : 0xFF;
     }
     for (int i = 0; i < 24; i++) {
         P->collapse[0][i] = i < 21 ? col0[i] : 0;
@@ -250,11 +255,11 @@ OG_DEV void og_band_plan(const OgCeltHdr *h, const OgCeltLeaf *lv, const OgCeltT
     uint8_t tcur[OG_MAXLEVEL + 3];
     for (int l = 0; l <= OG_MAXLEVEL + 2; l++) tcur[l] = 0;
     for (int t = 0; t < 42; t++)
-        if (P->task[t].flags & OG_T_ACTIVE) tcur[P->task[t].level + 1]++;
+        if (tl[t * ts] != 0xFF) tcur[tl[t * ts] + 1]++;
     for (int l = 0; l <= OG_MAXLEVEL + 1; l++) tcur[l + 1] = (uint8_t)(tcur[l + 1] + tcur[l]);
     for (int l = 0; l <= OG_MAXLEVEL + 2; l++) P->task_start[l] = tcur[l];
     for (int t = 0; t < 42; t++)
-        if (P->task[t].flags & OG_T_ACTIVE) P->order[tcur[P->task[t].level]++] = (uint8_t)t;
+        if (tl[t * ts] != 0xFF) P->order[tcur[tl[t * ts]]++] = (uint8_t)t;
     P->pad2_[0] = P->pad2_[1] = P->pad2_[2] = 0;
 }
 
@@ -270,10 +275,11 @@ OG_DEV OgBandPlan *og_work_plan(void *work, uint32_t frame)
     return (OgBandPlan *)((char *)work + (size_t)frame * OG_WORK_STRIDE + 1920 * 4 + 48 * 4);
 }
 
-// The plan of frame f: consumes (and re-zeroes) K1's collapse masks.
-OG_DEV void og_plan_frame(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, uint32_t nframes, uint32_t f, const OgCeltTables *T, void *work)
+// The plan of frame f: consumes (and re-zeroes) K1's collapse masks.  h = the frame's header (the kernel passes an LDS copy).
+OG_DEV void og_plan_frame(const OgCeltHdr *h, const OgCeltLeaf *leaves, uint32_t f, const OgCeltConst &K, const uint32_t *la,
+                          const uint32_t *lc, void *work, uint8_t *tl, int ts)
 {
     uint32_t *cm = og_work_cm(work, f);
-    og_band_plan(hdr + f, leaves + hdr[f].leaf_begin, T, cm, og_work_coef(work, f), og_work_plan(work, f));
+    og_band_plan(h, leaves + h->leaf_begin, K, la, lc, cm, og_work_coef(work, f), og_work_plan(work, f), tl, ts);
     for (int i = 0; i < 48; i++) cm[i] = 0;
 }
