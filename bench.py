@@ -3,10 +3,13 @@
 synthetic CELT-only fullband 48 kHz stereo 20 ms frames, 4096 streams per MI355X (weak scaling over GPUs).
 
 A step = one pass of the hot path over one batch: the next T consecutive 20 ms frames (default T = 8, 160 ms of
-audio) of each of the 4096 streams, one opusgpu_launch_celt call through the C ABI (layer 3b: the K1 PVQ kernels over
-all 4096*T frames' leaves, then the K2+K3 kernel, one workgroup per stream walking its T frames in time order).
-Inputs (side-info records, pre-parsed by the host layer) are resident in HBM before the timed region; PCM and decoder
-state stay in HBM.  --frames-per-step 1 gives the one-frame-per-call figure.  Prints ONE JSON line on rank 0.
+audio) of each of the 4096 streams through the C ABI (layer 3b): opusgpu_launch_celt_pvq (the K1 PVQ kernels over all
+4096*T frames' leaves + the band-plan kernel) and opusgpu_launch_celt_frames (the K2+K3 kernel, one workgroup per stream
+walking its T frames in time order), issued as one opusgpu_launch_celt call per step on one stream.  --pipeline issues
+the two halves separately and lets the first half of step k+1 (which touches no decoder state) run on its own stream and
+scratch buffer while the frame kernel of step k is still busy (measured: no gain on MI355X, the frame kernel's workgroups
+hold all of the LDS, so the other kernels only get on a CU when it drains).  Inputs (side-info records, pre-parsed by the host layer) are resident in HBM before the timed region; PCM and
+decoder state stay in HBM.  --frames-per-step 1 gives the one-frame-per-call figure.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import ctypes as C
@@ -35,6 +38,8 @@ def parse_args():
     ap.add_argument("--frames-per-step", type=int, default=8, help="consecutive frames of every stream decoded per step")
     ap.add_argument("--streams", type=int, default=STREAMS_PER_GPU, help="streams per GPU (BASELINE: 4096)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="overlap the first half (K1 + plan) of step k+1 with the frame kernel of step k on two streams")
     return ap.parse_args()
 
 
@@ -147,29 +152,49 @@ def main():
     parser.close()
 
     state = torch.zeros(S * C.sizeof(A.CeltState), dtype=torch.uint8, device=dev)
-    work = torch.zeros(lib.opusgpu_celt_work_bytes(S * T), dtype=torch.uint8, device=dev)  # K1 -> K2 scratch (kept zero)
+    # K1 -> plan -> frame-kernel scratch (kept zero by the kernels); two of them so that consecutive steps can overlap
+    works = [torch.zeros(lib.opusgpu_celt_work_bytes(S * T), dtype=torch.uint8, device=dev) for _ in range(2)]
     stride = T * 960 * 2
     pcm = torch.zeros(S * stride, dtype=torch.float32, device=dev)
-    stream = torch.cuda.current_stream(dev)
-    sp = C.c_void_p(stream.cuda_stream)
+    # the first half is short and on the critical path of the next frame kernel: its stream ranks first for free CU slots
+    s_pvq, s_frm = torch.cuda.Stream(dev, priority=-1), torch.cuda.Stream(dev)
+    p_pvq, p_frm = C.c_void_p(s_pvq.cuda_stream), C.c_void_p(s_frm.cuda_stream)
+    ready = [torch.cuda.Event() for _ in range(nsteps)]
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nsteps)]
 
-    def step(f):
-        rc = lib.opusgpu_launch_celt(hdr_dev[f].data_ptr(), leaf_dev[f].data_ptr(), S * T, T, ref_dev[f].data_ptr(), ref_classes[f],
-                                     work.data_ptr(), state.data_ptr(), pcm.data_ptr(), stride, None, sp)
+    def check(rc):
         if rc:
             raise RuntimeError(lib.opusgpu_last_error().decode())
 
+    def step(f):
+        """step f; the frame kernel is bracketed by ev[f] on the stream it runs on"""
+        w = works[f % 2]
+        if (not a.pipeline):
+            ev[f][0].record(s_frm)
+            check(lib.opusgpu_launch_celt(hdr_dev[f].data_ptr(), leaf_dev[f].data_ptr(), S * T, T, ref_dev[f].data_ptr(), ref_classes[f],
+                                          w.data_ptr(), state.data_ptr(), pcm.data_ptr(), stride, None, p_frm))
+            ev[f][1].record(s_frm)
+            return
+        if f >= 2:
+            s_pvq.wait_event(ev[f - 2][1])              # the scratch buffer is free once frames(f-2) has consumed it
+        check(lib.opusgpu_launch_celt_pvq(hdr_dev[f].data_ptr(), leaf_dev[f].data_ptr(), S * T, ref_dev[f].data_ptr(), ref_classes[f],
+                                          w.data_ptr(), None, p_pvq))
+        ready[f].record(s_pvq)
+        s_frm.wait_event(ready[f])
+        ev[f][0].record(s_frm)
+        check(lib.opusgpu_launch_celt_frames(hdr_dev[f].data_ptr(), S * T, T, w.data_ptr(), state.data_ptr(), pcm.data_ptr(), stride,
+                                             None, p_frm))
+        ev[f][1].record(s_frm)
+
+    torch.cuda.synchronize(dev)
     for f in range(W):
         step(f)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
     for k in range(K):
-        ev[k][0].record(stream)
         step(W + k)
-        ev[k][1].record(stream)
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
@@ -177,10 +202,11 @@ def main():
     elapsed = sharding.max_over_ranks(elapsed, dev)
     assert bool(torch.isfinite(pcm).all())
 
-    kernel_ms = [e0.elapsed_time(e1) for e0, e1 in ev]
+    kernel_ms = [e0.elapsed_time(e1) for e0, e1 in ev[W:]]
     avg_kernel_s = sum(kernel_ms) / K / 1e3
     avg_alg = sum(alg_bytes[W:]) / K
     achieved = avg_alg / avg_kernel_s / 1e9
+    step_achieved = avg_alg / (elapsed / K) / 1e9           # the same bytes over the whole step (all kernels)
     traffic = None
     tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")      # HBM bytes per launch from a rocprofv3 --pmc pass
     if os.path.exists(tp):
@@ -201,12 +227,15 @@ def main():
             "config": {"workload": "BASELINE configs[1]: synthetic CELT-only FB 48 kHz stereo 20 ms frames (TOC 0xFC + "
                                    f"{PAYLOAD} random payload bytes), {S} streams per GPU, {T} consecutive frames per stream per step",
                        "streams_per_gpu": S, "frame_ms": 20, "frames_per_stream_per_step": T, "payload_bytes": PAYLOAD,
-                       "parallelism": f"streams sharded over {world} GPU(s), no collective"},
+                       "parallelism": f"streams sharded over {world} GPU(s), no collective",
+                       "pipelined": bool(a.pipeline)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "kernel": "og_celt_kernel (K2+K3) preceded by the og_pvq_kernel (K1) size classes; one launch = both",
+                         "kernel": ("one opusgpu_launch_celt call (K1 classes + plan + og_celt_kernel)" if (not a.pipeline) else
+                                    "og_celt_kernel (K2+K3), the dominant kernel; K1 + plan of the next step overlap it"),
                          "avg_launch_us": round(avg_kernel_s * 1e6, 2),
-                         "algorithmic_bytes_per_launch": int(avg_alg)},
+                         "algorithmic_bytes_per_launch": int(avg_alg),
+                         "whole_step": {"achieved": round(step_achieved, 2), "frac": round(step_achieved / HBM_PEAK_GBS, 5)}},
             "host_parse": {"value": round(S * nframes * FRAME_S / t_parse, 1), "unit": "audio-s/s",
                            "note": "packets -> side-info on the host threads (untimed in `value`)",
                            "mean_leaves_per_frame": round(sum(nleaves) / (S * nframes), 1)},

@@ -209,6 +209,14 @@ uint32_t opusgpu_sort_pvq_leaves(const OgCeltHdr *hdr, uint32_t nframes, const O
 int opusgpu_launch_celt(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, uint32_t nframes, uint32_t frames_per_group,
                         const OgLeafRef *refs, const uint32_t class_counts[4], void *work, OgCeltState *state, float *pcm,
                         size_t pcm_stride_floats, const OgCeltDebug *debug /* host struct, may be NULL */, void *stream);
+/* The same launch in its two halves, for callers that pipeline consecutive batches: the first half (K1 + plan) only
+ * writes `work` and touches no decoder state, so batch k+1's first half may run on another stream -- with its own
+ * `work` buffer -- while batch k's frame kernel is still running; the frame kernels of a stream's batches must stay in
+ * order (they carry the decoder state).  bench.py runs this way.  opusgpu_launch_celt = both halves on one stream. */
+int opusgpu_launch_celt_pvq(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, uint32_t nframes, const OgLeafRef *refs,
+                            const uint32_t class_counts[4], void *work, const OgCeltDebug *debug, void *stream);
+int opusgpu_launch_celt_frames(const OgCeltHdr *hdr, uint32_t nframes, uint32_t frames_per_group, void *work, OgCeltState *state,
+                               float *pcm, size_t pcm_stride_floats, const OgCeltDebug *debug, void *stream);
 
 /* SILK: K4 LTP + LPC synthesis with one lane per (stream, channel) over struct-of-arrays state (replaces
  * silk/decoder.rs:1775-1898), then K5 + K6: stereo unmix / mono copy (silk/decoder.rs:2012-2061, :2104-2113) and the

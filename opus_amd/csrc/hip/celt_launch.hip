@@ -27,26 +27,28 @@ __global__ __launch_bounds__(WGS) void og_pvq_kernel(const OgLeafRef *__restrict
         og_pvq_lane(refs[g], hdr, leaves, nframes, work, U2, x + (threadIdx.x >> 6) * (NMAX * 64) + (threadIdx.x & 63), 64, dbg_pulses, stamps);
 }
 
-// Band plan: one lane per frame (celt_plan.h).  The serial per-lane code is a chain of dependent loads, so what it reads
-// sits in LDS: the workgroup's 64 headers (copied in coalesced; a lane's header is 167 dwords from its neighbour's, an
-// odd stride, so the lanes' reads fall on distinct banks), the small constant tables, and a byte row of scratch per lane.
+// Band plan: one lane per frame (celt_plan.h), OG_PLAN_FPW frames per wavefront.  The per-lane code is one long serial
+// chain, so what it reads and indexes sits in LDS: the workgroup's headers (copied in coalesced; a lane's header is 167
+// dwords from its neighbour's, an odd stride, so the lanes' reads fall on distinct banks), the small constant tables, and
+// a row of scratch cells per lane for the arrays it indexes at run time.
+#define OG_PLAN_FPW 64
 __global__ __launch_bounds__(64) void og_plan_kernel(const OgCeltHdr *__restrict__ hdr, const OgCeltLeaf *__restrict__ leaves,
                                                      uint32_t nframes, const OgCeltTables *__restrict__ T, void *work)
 {
     static_assert(sizeof(OgCeltHdr) % 4 == 0, "headers are copied as dwords");
-    __shared__ uint32_t hs[64 * sizeof(OgCeltHdr) / 4];
+    __shared__ uint32_t hs[OG_PLAN_FPW * sizeof(OgCeltHdr) / 4];
     __shared__ OgCeltConst K;
     __shared__ uint32_t la[184], lc[184];
-    __shared__ uint8_t tl[44 * 64];
-    const uint32_t f0 = blockIdx.x * 64, nf = nframes - f0 < 64 ? nframes - f0 : 64;
+    __shared__ uint16_t sc[OG_PLAN_SCRATCH * OG_PLAN_FPW];
+    const uint32_t f0 = blockIdx.x * OG_PLAN_FPW, nf = nframes - f0 < OG_PLAN_FPW ? nframes - f0 : OG_PLAN_FPW;
     const uint32_t *src = (const uint32_t *)(hdr + f0);
     for (uint32_t p = threadIdx.x; p < nf * (sizeof(OgCeltHdr) / 4); p += 64) hs[p] = src[p];
     for (int p = threadIdx.x; p < (int)(sizeof(OgCeltConst) / 4); p += 64) ((uint32_t *)&K)[p] = ((const uint32_t *)&T->k)[p];
     for (int p = threadIdx.x; p < 184; p += 64) { la[p] = T->lcg_a[p]; lc[p] = T->lcg_c[p]; }
     __syncthreads();
     const uint32_t f = f0 + threadIdx.x;
-    if (f < nframes)
-        og_plan_frame((const OgCeltHdr *)hs + threadIdx.x, leaves, f, K, la, lc, work, tl + threadIdx.x, 64);
+    if (threadIdx.x < OG_PLAN_FPW && f < nframes)
+        og_plan_frame((const OgCeltHdr *)hs + threadIdx.x, leaves, f, K, la, lc, work, OgLaneScratch{sc + threadIdx.x, OG_PLAN_FPW});
 }
 
 __global__ __launch_bounds__(OG_WG, 4) void og_celt_kernel(const OgCeltHdr *__restrict__ hdr, uint32_t nframes, uint32_t frames_per_group,
@@ -104,8 +106,10 @@ static int ctx_for_device(int device, DevCtx **out)
         hipError_t e = hipMalloc(&dev, sizeof(OgCeltTables));
         if (e == hipSuccess) e = hipMemcpy(dev, host, sizeof(OgCeltTables), hipMemcpyHostToDevice);
         delete host;
+        int prio_lo = 0, prio_hi = 0;                    // K1 is short and on the critical path: its streams rank first
+        if (e == hipSuccess) e = hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
         for (int k = 0; k < 3 && e == hipSuccess; k++) {
-            e = hipStreamCreateWithFlags(&c.side[k], hipStreamNonBlocking);
+            e = hipStreamCreateWithPriority(&c.side[k], hipStreamNonBlocking, prio_hi);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&c.join[k], hipEventDisableTiming);
         }
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c.fork, hipEventDisableTiming);
@@ -140,12 +144,11 @@ int opusgpu_init(int device)
 
 size_t opusgpu_celt_work_bytes(uint32_t nframes) { return OG_WORK_BYTES(nframes); }
 
-int opusgpu_launch_celt(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, uint32_t nframes, uint32_t frames_per_group,
-                        const OgLeafRef *refs, const uint32_t class_counts[4], void *work, OgCeltState *state, float *pcm,
-                        size_t pcm_stride_floats, const OgCeltDebug *debug, void *stream)
+int opusgpu_launch_celt_pvq(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, uint32_t nframes, const OgLeafRef *refs,
+                            const uint32_t class_counts[4], void *work, const OgCeltDebug *debug, void *stream)
 {
     if (nframes == 0) return OPUSGPU_OK;
-    if (!hdr || !leaves || !state || !pcm || !work || frames_per_group == 0 || !class_counts) return OPUSGPU_BAD_ARG;
+    if (!hdr || !leaves || !work || !class_counts) return OPUSGPU_BAD_ARG;
     const uint32_t nrefs = class_counts[0] + class_counts[1] + class_counts[2] + class_counts[3];
     if (nrefs && !refs) return OPUSGPU_BAD_ARG;
     int device = 0;
@@ -192,12 +195,39 @@ int opusgpu_launch_celt(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, uint32_t
         }
         for (int k = 0; k < used; k++) OG_HIP(hipStreamWaitEvent(st, ctx->join[k], 0));
     }
-    const uint32_t groups = (nframes + frames_per_group - 1) / frames_per_group;
-    hipLaunchKernelGGL(og_plan_kernel, dim3((nframes + 63) / 64), dim3(64), 0, st, hdr, leaves, nframes, T, work);
-    hipLaunchKernelGGL(og_celt_kernel, dim3(groups), dim3(OG_WG), 0, st, hdr, nframes, frames_per_group, T, work, state, pcm,
-                       pcm_stride_floats, dbg);
+    hipLaunchKernelGGL(og_plan_kernel, dim3((nframes + OG_PLAN_FPW - 1) / OG_PLAN_FPW), dim3(64), 0, st, hdr, leaves, nframes, T, work);
     OG_HIP(hipGetLastError());
     return OPUSGPU_OK;
+}
+
+int opusgpu_launch_celt_frames(const OgCeltHdr *hdr, uint32_t nframes, uint32_t frames_per_group, void *work, OgCeltState *state,
+                               float *pcm, size_t pcm_stride_floats, const OgCeltDebug *debug, void *stream)
+{
+    if (nframes == 0) return OPUSGPU_OK;
+    if (!hdr || !state || !pcm || !work || frames_per_group == 0) return OPUSGPU_BAD_ARG;
+    int device = 0;
+    OG_HIP(hipGetDevice(&device));
+    const OgCeltTables *T;
+    int rc = og::celt_tables_for_device(device, &T);
+    if (rc) return rc;
+    OgCeltDebug dbg = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (debug) dbg = *debug;
+    const uint32_t groups = (nframes + frames_per_group - 1) / frames_per_group;
+    hipLaunchKernelGGL(og_celt_kernel, dim3(groups), dim3(OG_WG), 0, (hipStream_t)stream, hdr, nframes, frames_per_group, T, work,
+                       state, pcm, pcm_stride_floats, dbg);
+    OG_HIP(hipGetLastError());
+    return OPUSGPU_OK;
+}
+
+int opusgpu_launch_celt(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, uint32_t nframes, uint32_t frames_per_group,
+                        const OgLeafRef *refs, const uint32_t class_counts[4], void *work, OgCeltState *state, float *pcm,
+                        size_t pcm_stride_floats, const OgCeltDebug *debug, void *stream)
+{
+    if (nframes == 0) return OPUSGPU_OK;
+    if (!state || !pcm || frames_per_group == 0) return OPUSGPU_BAD_ARG;
+    int rc = opusgpu_launch_celt_pvq(hdr, leaves, nframes, refs, class_counts, work, debug, stream);
+    if (rc) return rc;
+    return opusgpu_launch_celt_frames(hdr, nframes, frames_per_group, work, state, pcm, pcm_stride_floats, debug, stream);
 }
 
 }  // extern "C"

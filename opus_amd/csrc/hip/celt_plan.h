@@ -82,16 +82,26 @@ OG_DEV void og_make_xform(int n, int B, int tf_change, OgXform *t, int *recombin
 
 // Everything here is per-lane serial code on global memory.  coef_row: the frame's K1 output (the signs of the
 // one-bin bands are added to it); cm_row: K1's collapse masks [buffer][24].
-// K, la, lc: the small constant tables (LDS copies in the kernel); tl[t * ts]: 42 bytes of scratch private to the lane.
+// K, la, lc: the small constant tables (LDS copies in the kernel).  sc: OG_PLAN_SCRATCH cells private to the lane: the
+// small per-band / per-level arrays are indexed with run-time indices, which in registers costs a chain of selects per
+// access (it was most of this code's instructions); in LDS it is one access.
+struct OgLaneScratch {                // u16 cells, cell i at p[i * stride] (lane-interleaved in the kernel, stride 1 on the CPU)
+    uint16_t *p;
+    int stride;
+    OG_MEMBER uint16_t &operator[](int i) const { return p[i * stride]; }
+    OG_MEMBER OgLaneScratch at(int o) const { OgLaneScratch r = {p + o * stride, stride}; return r; }
+};
+#define OG_PLAN_SCRATCH 184
 OG_DEV void og_band_plan(const OgCeltHdr *h, const OgCeltLeaf *lv, const OgCeltConst &K, const uint32_t *la, const uint32_t *lc,
-                         const uint32_t *cm_row, float *coef_row, OgBandPlan *P, uint8_t *tl, int ts)
+                         const uint32_t *cm_row, float *coef_row, OgBandPlan *P, OgLaneScratch sc)
 {
+    const OgLaneScratch tl = sc.at(0), blevel = sc.at(44), col0 = sc.at(65), col1 = sc.at(86), maxcnt = sc.at(107),
+                        cursor = sc.at(131), tcur = sc.at(157);
     const int lm = h->lm, M = 1 << lm, start = h->start, end = h->end;
     const int C = (h->flags & OG_F_STEREO) ? 2 : 1;
     const int B = (h->flags & OG_F_TRANSIENT) ? M : 1;
     const int nleaves = h->nleaves < OG_MAXLEAF ? h->nleaves : OG_MAXLEAF;
     const int norm_offset = M * K.ebands[start < 21 ? start : 20];
-    uint8_t blevel[21], col0[21], col1[21], maxcnt[OG_MAXLEVEL + 1];
     for (int i = 0; i < 21; i++) blevel[i] = col0[i] = col1[i] = 0;
     for (int l = 0; l <= OG_MAXLEVEL; l++) maxcnt[l] = 0;
     uint32_t seed = h->seed;
@@ -108,7 +118,7 @@ OG_DEV void og_band_plan(const OgCeltHdr *h, const OgCeltLeaf *lv, const OgCeltC
         }
         if (silence || i < start || i >= end) {
             P->task[2 * i] = tk[0]; P->task[2 * i + 1] = tk[1];
-            tl[(2 * i) * ts] = tl[(2 * i + 1) * ts] = 0xFF;
+            tl[2 * i] = tl[2 * i + 1] = 0xFF;
             continue;
         }
         const OgCeltBand bd = h->band[i];
@@ -224,7 +234,7 @@ OG_DEV void og_band_plan(const OgCeltHdr *h, const OgCeltLeaf *lv, const OgCeltC
         P->task[2 * i] = tk[0];
         P->task[2 * i + 1] = tk[1];
         for (int slot = 0; slot < 2; slot++)            // level of the active tasks, kept where the sort below reads it cheaply
-            tl[(2 * i + slot) * ts] = (tk[slot].flags & OG_T_ACTIVE) ? tk[slot].level : 0xFF;
+            tl[2 * i + slot] = (tk[slot].flags & OG_T_ACTIVE) ? tk[slot].level : 0xFF;
     }
     for (int i = 0; i < 24; i++) {
         P->collapse[0][i] = i < 21 ? col0[i] : 0;
@@ -233,10 +243,9 @@ OG_DEV void og_band_plan(const OgCeltHdr *h, const OgCeltLeaf *lv, const OgCeltC
     P->seed_out = seed;
     P->nops = (uint16_t)nops; P->merge_cnt = (uint16_t)merge_cnt;
     P->nlevels = (uint8_t)maxlvl; P->merge_level = (uint8_t)merge_level;
-    for (int l = 0; l <= OG_MAXLEVEL; l++) P->lvl_maxcnt[l] = maxcnt[l];
+    for (int l = 0; l <= OG_MAXLEVEL; l++) P->lvl_maxcnt[l] = (uint8_t)maxcnt[l];
     P->pad_[0] = P->pad_[1] = 0;
     // counting sort of the ops by level (stable)
-    uint16_t cursor[OG_MAXLEVEL + 2];
     for (int l = 0; l <= OG_MAXLEVEL + 1; l++) cursor[l] = 0;
     for (int j = 0; j < nops; j++) cursor[P->op_decode[j].level + 1]++;
     for (int l = 0; l <= OG_MAXLEVEL; l++) cursor[l + 1] = (uint16_t)(cursor[l + 1] + cursor[l]);
@@ -252,14 +261,13 @@ OG_DEV void og_band_plan(const OgCeltHdr *h, const OgCeltLeaf *lv, const OgCeltC
         }
     }
     // counting sort of the active tasks by level (stable: band order inside a level)
-    uint8_t tcur[OG_MAXLEVEL + 3];
     for (int l = 0; l <= OG_MAXLEVEL + 2; l++) tcur[l] = 0;
     for (int t = 0; t < 42; t++)
-        if (tl[t * ts] != 0xFF) tcur[tl[t * ts] + 1]++;
-    for (int l = 0; l <= OG_MAXLEVEL + 1; l++) tcur[l + 1] = (uint8_t)(tcur[l + 1] + tcur[l]);
-    for (int l = 0; l <= OG_MAXLEVEL + 2; l++) P->task_start[l] = tcur[l];
+        if (tl[t] != 0xFF) tcur[tl[t] + 1]++;
+    for (int l = 0; l <= OG_MAXLEVEL + 1; l++) tcur[l + 1] = (uint16_t)(tcur[l + 1] + tcur[l]);
+    for (int l = 0; l <= OG_MAXLEVEL + 2; l++) P->task_start[l] = (uint8_t)tcur[l];
     for (int t = 0; t < 42; t++)
-        if (tl[t * ts] != 0xFF) P->order[tcur[tl[t * ts]]++] = (uint8_t)t;
+        if (tl[t] != 0xFF) P->order[tcur[tl[t]]++] = (uint8_t)t;
     P->pad2_[0] = P->pad2_[1] = P->pad2_[2] = 0;
 }
 
@@ -277,9 +285,9 @@ OG_DEV OgBandPlan *og_work_plan(void *work, uint32_t frame)
 
 // The plan of frame f: consumes (and re-zeroes) K1's collapse masks.  h = the frame's header (the kernel passes an LDS copy).
 OG_DEV void og_plan_frame(const OgCeltHdr *h, const OgCeltLeaf *leaves, uint32_t f, const OgCeltConst &K, const uint32_t *la,
-                          const uint32_t *lc, void *work, uint8_t *tl, int ts)
+                          const uint32_t *lc, void *work, OgLaneScratch sc)
 {
     uint32_t *cm = og_work_cm(work, f);
-    og_band_plan(h, leaves + h->leaf_begin, K, la, lc, cm, og_work_coef(work, f), og_work_plan(work, f), tl, ts);
+    og_band_plan(h, leaves + h->leaf_begin, K, la, lc, cm, og_work_coef(work, f), og_work_plan(work, f), sc);
     for (int i = 0; i < 48; i++) cm[i] = 0;
 }

@@ -15,6 +15,7 @@
 #if defined(__HIP__)
 #include <hip/hip_runtime.h>
 #define OG_DEV __device__ __forceinline__
+#define OG_MEMBER __device__ __forceinline__
 #define OG_LANES_BEGIN(tid) { const int tid = (int)threadIdx.x; {
 #define OG_LANES_END } } __syncthreads();
 #define OG_ATOMIC_OR(p, v) atomicOr((p), (v))
@@ -38,6 +39,7 @@
 #else
 #include <math.h>
 #define OG_DEV static inline
+#define OG_MEMBER inline
 #define OG_LANES_BEGIN(tid) for (int tid = 0; tid < OG_WG; tid++) { {
 #define OG_LANES_END } }
 #define OG_ATOMIC_OR(p, v) (*(p) |= (v))

@@ -25,8 +25,8 @@ extern "C" int emu_launch_celt(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, u
             og_pvq_lane(ref, hdr, leaves, nframes, work.data(), T.pvq_u2, x, 1, dbg ? dbg->pulses : nullptr, nullptr);
         }
     for (uint32_t f = 0; f < nframes; f++) {
-        uint8_t tl[44];
-        og_plan_frame(hdr + f, leaves, f, T.k, T.lcg_a, T.lcg_c, work.data(), tl, 1);
+        uint16_t sc[OG_PLAN_SCRATCH];
+        og_plan_frame(hdr + f, leaves, f, T.k, T.lcg_a, T.lcg_c, work.data(), OgLaneScratch{sc, 1});
     }
     for (uint32_t f = 0; f < nframes; f++) {
         std::memset(&L, 0xA5, sizeof L);               // LDS starts undefined on the device
@@ -49,8 +49,8 @@ extern "C" void emu_plan_stats(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, u
     static bool init = false;
     if (!init) { og_fill_celt_tables(&T); init = true; }
     std::vector<float> work(OG_WORK_BYTES(f + 1) / 4 + 4, 0.f);
-    uint8_t tl[44];
-    og_plan_frame(hdr + f, leaves, f, T.k, T.lcg_a, T.lcg_c, work.data(), tl, 1);
+    uint16_t sc[OG_PLAN_SCRATCH];
+    og_plan_frame(hdr + f, leaves, f, T.k, T.lcg_a, T.lcg_c, work.data(), OgLaneScratch{sc, 1});
     const OgBandPlan *P = og_work_plan(work.data(), f);
     out[0] = P->nlevels; out[1] = P->nops; out[2] = P->merge_level;
     int xf0 = 0, xfn = 0, act = 0;

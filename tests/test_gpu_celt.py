@@ -162,3 +162,69 @@ def test_full_size_properties():
             a, b = dec.read(s), dec.read(s + ns // 2)
             assert np.array_equal(a, b)
             check_pcm(refs[s].decode(pk[s]), a, f"stream {s} frame {f}")
+
+
+def test_pipelined_halves_match_single_call():
+    """opusgpu_launch_celt_pvq / _frames on two streams with two scratch buffers (the way bench.py overlaps consecutive
+    batches) give bit-identical PCM to the one-call launch on one stream"""
+    import torch
+    lib = A.load()
+    dev = torch.device("cuda:0")
+    S, T, steps = 96, 4, 5
+    pk = synth.celt_fb_stereo_packets(range(S), T * steps, 160)
+    parser = BatchDecoder(S, 2, 0)
+    HS = C.sizeof(A.CeltHdr)
+    ups = []
+    for k in range(steps):
+        hb_all = np.zeros((S, T, HS), np.uint8)
+        parts, off = [], 0
+        for t in range(T):
+            assert not any(parser.send([pk[s, k * T + t].tobytes() for s in range(S)]))
+            celt, leaves, _ = parser.sideinfo()
+            hb = np.frombuffer(celt, dtype=np.uint8).reshape(S, HS).copy()
+            hb[:, A.CeltHdr.leaf_begin.offset:A.CeltHdr.leaf_begin.offset + 4].view(np.uint32)[:] += off
+            hb[:, A.CeltHdr.pcm_off.offset:A.CeltHdr.pcm_off.offset + 4].view(np.uint32)[:] = t * 960
+            hb_all[:, t] = hb
+            parts.append(np.frombuffer(leaves, dtype=np.uint8).copy())
+            off += len(leaves)
+        ups.append((np.ascontiguousarray(hb_all.reshape(S * T, HS)), np.concatenate(parts)))
+    stride = T * 960 * 2
+
+    def run(pipelined):
+        cl = [CeltLaunch(S * T), CeltLaunch(S * T)]
+        state = torch.zeros(S * C.sizeof(A.CeltState), dtype=torch.uint8, device=dev)
+        pcm = torch.zeros((steps, S * stride), dtype=torch.float32, device=dev)
+        s1, s2 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+        done = [torch.cuda.Event() for _ in range(steps)]
+        keep = []
+        torch.cuda.synchronize()
+        for k, (hb, lb) in enumerate(ups):
+            c = cl[k % 2]
+            up = c.upload(hb, lb, S * T)
+            keep.append(up)
+            torch.cuda.synchronize()            # uploads ran on the default stream
+            if not pipelined:
+                c.launch(up, state, pcm[k], stride, None, C.c_void_p(s2.cuda_stream), frames_per_group=T)
+                continue
+            if k >= 2:
+                s1.wait_event(done[k - 2])
+            rc = lib.opusgpu_launch_celt_pvq(up["hdr"].data_ptr(), up["leaves"].data_ptr(), S * T, up["refs"].data_ptr(), up["classes"],
+                                             c.work.data_ptr(), None, C.c_void_p(s1.cuda_stream))
+            assert rc == 0, lib.opusgpu_last_error()
+            ready = torch.cuda.Event()
+            ready.record(s1)
+            s2.wait_event(ready)
+            rc = lib.opusgpu_launch_celt_frames(up["hdr"].data_ptr(), S * T, T, c.work.data_ptr(), state.data_ptr(), pcm[k].data_ptr(),
+                                                stride, None, C.c_void_p(s2.cuda_stream))
+            assert rc == 0, lib.opusgpu_last_error()
+            done[k].record(s2)
+        torch.cuda.synchronize()
+        return pcm.cpu().numpy()
+
+    a, b = run(False), run(True)
+    assert np.array_equal(a, b)
+    ref = orc.Decoder(2)                                # and stream 0 against the oracle
+    for k in range(steps):
+        for t in range(T):
+            r = ref.decode(pk[0, k * T + t].tobytes())
+            check_pcm(r, a[k][t * 1920:(t + 1) * 1920].reshape(960, 2), f"step {k} frame {t}")
