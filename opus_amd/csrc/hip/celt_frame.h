@@ -44,6 +44,7 @@ struct alignas(16) OgCeltLds {
     uint8_t bin2band[960];
     float mrg[OG_WG / 64][2][64];     // stereo merge partial sums, per wave
     float gband[2][24];               // denormalisation gains
+    float window[120];                // TDAC / comb cross-fade window (copy of OgCeltTables')
     OgCeltHdr hdr;                    // the frame's side-info, staged once (uniform control code reads it from LDS)
     float red[4];
     float carry[OG_WG / 64][64];      // de-emphasis carries; per-wave partial sums during the band walk
@@ -537,6 +538,7 @@ OG_DEV void og_celt_frame(const OgCeltHdr *hg, const OgBandPlan *plan, const OgC
     }
     for (int p = tid; p < (int)(sizeof(OgCeltConst) / 4); p += OG_WG) ((uint32_t *)&L.k)[p] = ((const uint32_t *)&T->k)[p];
     for (int p = tid; p < 184; p += OG_WG) { L.lcg_a[p] = T->lcg_a[p]; L.lcg_c[p] = T->lcg_c[p]; }
+    for (int p = tid; p < 120; p += OG_WG) L.window[p] = T->window[p];
     for (int p = tid; p < 960 / 4; p += OG_WG) ((uint32_t *)L.bin2band)[p] = ((const uint32_t *)T->bin2band[lm0])[p];
     // K1's output for this frame: shaped PVQ coefficients (zero elsewhere).  The scratch row is handed back zero-filled
     // for the next launch.
@@ -677,7 +679,7 @@ OG_DEV void og_celt_frame(const OgCeltHdr *hg, const OgBandPlan *plan, const OgC
         const int ch = q >= B * 60, r = q - ch * (B * 60), b = og_div(r, 1.f / 60.f), i = r - b * 60;
         float *o = &L.v.out[ch][OG_HIST + NB * b];
         const float x1 = o[119 - i], x2 = o[i];
-        const float w1 = T->window[i], w2 = T->window[119 - i];
+        const float w1 = L.window[i], w2 = L.window[119 - i];
         o[i] = w2 * x2 - w1 * x1;
         o[119 - i] = w1 * x2 + w2 * x1;
     }
@@ -715,11 +717,12 @@ OG_DEV void og_celt_frame(const OgCeltHdr *hg, const OgBandPlan *plan, const OgC
         const int ch = w;
         float *y0 = &L.v.out[ch][OG_HIST];
         if (pf_on) {
-            og_wave_comb_filter(y0, h->pf_period[0], h->pf_period[1], 120, pg0, pg1, h->pf_tapset[0], h->pf_tapset[1], T->window, L.k.pf_taps);
+            og_wave_comb_filter(y0, h->pf_period[0], h->pf_period[1], 120, pg0, pg1, h->pf_tapset[0], h->pf_tapset[1], L.window, L.k.pf_taps);
             if (lm != 0)
                 og_wave_comb_filter(y0 + 120, h->pf_period[1], h->pf_period[2], N - 120, pg1, pg2, h->pf_tapset[1], h->pf_tapset[2],
-                                    T->window, L.k.pf_taps);
+                                    L.window, L.k.pf_taps);
         }
+        if (w == 0) OG_STAMP(20)
         OG_WAVE_BEGIN(l)
         if (l < nl) {
             const float *y = y0 + l * Lc;
@@ -744,6 +747,7 @@ OG_DEV void og_celt_frame(const OgCeltHdr *hg, const OgBandPlan *plan, const OgC
         OG_WAVE_END
     }
     OG_WAVES_END
+    OG_STAMP(21)
     float *pcm = pcm_base + (size_t)h->stream * pcm_stride + (size_t)h->pcm_off * CC;
     const bool accum = (h->flags & OG_F_ACCUM) != 0;
     const bool vec = (((uintptr_t)pcm) & 15) == 0;      // 16-byte stores when the caller's row allows it

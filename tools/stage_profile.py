@@ -43,11 +43,16 @@ for f in range(NF):
         bd = np.diff(bb, axis=1).astype(np.float64)
         okb = ok & (bd >= 0).all(axis=1)
         band_tot = band_tot + bd[okb].mean(axis=0) if "band_tot" in dir() else bd[okb].mean(axis=0)
+        tail = np.stack([c[:, 7], c[:, 20], c[:, 21], c[:, 8]], axis=1)      # comb | de-emphasis | stores
+        td = np.diff(tail, axis=1).astype(np.float64)
+        okt = ok & (td >= 0).all(axis=1) & (c[:, 20] > 0)
+        tail_tot = tail_tot + td[okt].mean(axis=0) if "tail_tot" in dir() else td[okt].mean(axis=0)
         span = c[:, 8].max() - c[:, 0].min()
         print("denorm apply region clk", (c[:, 10] - c[:, 9]).mean())
 for n, v in zip(names, tot / (NF - 1)):
     print(f"{n:14s} {v:12.0f} clk  {100 * v / tot.sum() * (NF - 1):5.1f}%")
 print("mean per-frame total", tot.sum() / (NF - 1), "clk; launch span (last frame)", span, "clk")
+print("tail (comb filter, de-emphasis, PCM + state stores) mean clk:", " ".join(f"{v:.0f}" for v in tail_tot / (NF - 1)))
 print("band phase (-, level 0, fill levels, merges) mean clk:", " ".join(f"{v:.0f}" for v in band_tot / (NF - 1)))
 k1 = cyc_all[S * 64:].view(177, 4096, 4).cpu().numpy()
 for nmax in (176, 64, 24, 8):
