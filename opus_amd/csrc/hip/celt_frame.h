@@ -186,31 +186,92 @@ template <class T> OG_DEV T og_uniform(const T &v)     // load a wave-uniform re
 template <class T> OG_DEV T og_uniform(const T &v) { return v; }
 #endif
 
-// The transform of one quant_band call, by one wave (inside an OG_WAVES section; the task record is wave-uniform, so
-// its fields sit in scalar registers and the lanes only do the gather):
-//   PRE:  lb_all <- Haar steps + deinterleave_hadamard of the folding source (celt/decoder.rs:1708-1768);
-//   !PRE: tmp_all <- interleave_hadamard + the Haar steps that undo time-division and recombination (:1994-2019).
+// The transform of one quant_band call: the Haar steps of tf recombination / time-division (celt/decoder.rs:453-466,
+// :1708-1740, :1994-2019) are butterflies on the index bits `hm` (celt_plan.h) and commute; the Hadamard (de)interleave
+// (:472-538) is a permutation.  The pieces below each produce elements first, first + step, ... of the task for the
+// calling lane (a whole wave: first = lane, step = 64, task record in scalar registers; a 16-lane group: first = lane & 15,
+// step = 16); the caller separates them with wave-level fences.  Everything happens in the task's slice of tmp_all:
+//   PRE  (lowband copy):  load source -> butterflies -> lb_all[deinterleave(p)] = scale * tmp[p]
+//   POST (decoded band):  load X[interleave(p)] -> butterflies -> og_task_finish (scale, copy back, lowband_out)
 template <bool PRE>
-OG_DEV void og_task_xform(OgCeltLds &L, const OgTask tk, int slot)
+OG_DEV void og_xf_load(OgCeltLds &L, const OgTask tk, int slot, int first, int step)
 {
-    const int n = tk.n, rc = tk.rctd & 15, td = tk.rctd >> 4, m = rc + td, hm = tk.hm;
-    const int cnt = hm ? 1 << m : 1, sh = hm ? __builtin_ctz((unsigned)hm) : 0;
-    const int slog = tk.slog, n0p = tk.n0p, had = (tk.flags & OG_T_LONG) != 0;
-    const float scale = hm ? (m & 1 ? 0.70710678118654752440f : 1.f) / (float)(1 << (m >> 1)) : 1.f;
+    const int n = tk.n, slog = tk.slog, n0p = tk.n0p, had = (tk.flags & OG_T_LONG) != 0;
     const float *src = PRE ? &L.u.norm[0][0] + ((tk.flags & OG_T_LB_ROW1) ? 800 : 0) + tk.lowpos : &L.X[0][0] + slot * 960 + tk.boff;
-    float *dst = (PRE ? L.v.b.lb_all : L.v.b.tmp_all) + slot * 960 + tk.boff;
-    OG_WAVE_BEGIN(lane)
-    for (int p = lane; p < n; p += 64) {
-        const int base = p & ~hm, ph = (p >> sh) & (cnt - 1);
-        float acc = 0.f;
-        for (int j = 0; j < cnt; j++) {
-            const int sidx = base | (j << sh);
-            const float v = src[PRE ? sidx : og_reorder(slog, n0p, had, sidx)];
-            acc += (__builtin_popcount((unsigned)(ph & j)) & 1) ? -v : v;
-        }
-        dst[PRE ? og_reorder(slog, n0p, had, p) : p] = acc * scale;
+    float *tmp = L.v.b.tmp_all + slot * 960 + tk.boff;
+    for (int p = first; p < n; p += step) tmp[p] = src[PRE ? p : og_reorder(slog, n0p, had, p)];
+}
+
+OG_DEV void og_xf_bfly(OgCeltLds &L, const OgTask tk, int slot, int bit, int first, int step)   // unscaled Haar step on index bit `bit`
+{
+    float *tmp = L.v.b.tmp_all + slot * 960 + tk.boff;
+    const int half = tk.n >> 1, low = (1 << bit) - 1;
+    for (int q = first; q < half; q += step) {
+        const int i0 = ((q & ~low) << 1) | (q & low), i1 = i0 | (1 << bit);
+        const float a = tmp[i0], c = tmp[i1];
+        tmp[i0] = a + c;
+        tmp[i1] = a - c;
     }
+}
+
+OG_DEV float og_xf_scale(const OgTask tk)               // 2^(-m/2) for the m butterflies
+{
+    const int m = (tk.rctd & 15) + (tk.rctd >> 4);
+    return tk.hm ? (m & 1 ? 0.70710678118654752440f : 1.f) / (float)(1 << (m >> 1)) : 1.f;
+}
+
+OG_DEV void og_xf_store_pre(OgCeltLds &L, const OgTask tk, int slot, int first, int step)
+{
+    const int n = tk.n, slog = tk.slog, n0p = tk.n0p, had = (tk.flags & OG_T_LONG) != 0;
+    const float *tmp = L.v.b.tmp_all + slot * 960 + tk.boff;
+    float *lb = L.v.b.lb_all + slot * 960 + tk.boff;
+    const float scale = og_xf_scale(tk);
+    for (int p = first; p < n; p += step) lb[og_reorder(slog, n0p, had, p)] = tmp[p] * scale;
+}
+
+// the s-th butterfly bit of a task, -1 when it has fewer (tf changes are at most 3 steps: celt/decoder.rs:221-226)
+OG_DEV int og_xf_bit(const OgTask tk, int s)
+{
+    unsigned hm = tk.hm;
+    for (int k = 0; k < s; k++) hm &= hm - 1;
+    return hm ? __builtin_ctz(hm) : -1;
+}
+
+template <bool PRE>
+OG_DEV void og_task_xform(OgCeltLds &L, const OgTask tk, int slot)     // by one wave, inside an OG_WAVES section
+{
+    OG_WAVE_BEGIN(lane)
+    og_xf_load<PRE>(L, tk, slot, lane, 64);
     OG_WAVE_END
+    for (int s = 0; s < 8; s++) {
+        const int bit = og_xf_bit(tk, s);
+        if (bit < 0) break;
+        OG_WAVE_BEGIN(lane)
+        og_xf_bfly(L, tk, slot, bit, lane, 64);
+        OG_WAVE_END
+    }
+    if (PRE) {
+        OG_WAVE_BEGIN(lane)
+        og_xf_store_pre(L, tk, slot, lane, 64);
+        OG_WAVE_END
+    }
+}
+
+// scale + copy-back of a transformed task, and lowband_out = sqrt(N0) * x (celt/decoder.rs:2021-2028)
+OG_DEV void og_task_finish(OgCeltLds &L, const OgTask tk, int slot, int norm_offset, int first, int step)
+{
+    const bool xf = (tk.hm | tk.slog) != 0;
+    if (!xf && tk.norm_row == 0xFF) return;
+    const int n = tk.n;
+    float *x = &L.X[0][0] + slot * 960 + tk.boff;
+    const float *t = L.v.b.tmp_all + slot * 960 + tk.boff;
+    float *nr = tk.norm_row != 0xFF ? &L.u.norm[tk.norm_row == 0xFF ? 0 : tk.norm_row][tk.boff - norm_offset] : nullptr;
+    const float sq = sqrtf((float)n), scale = og_xf_scale(tk);
+    for (int p = first; p < n; p += step) {
+        float v;
+        if (xf) { v = t[p] * scale; x[p] = v; } else v = x[p];
+        if (nr) nr[p] = sq * v;
+    }
 }
 
 // One live fill leaf (celt/decoder.rs:1633-1661 + renormalize_vector :788-794), by wave w alone: n <= 176, at most
@@ -271,7 +332,6 @@ OG_DEV void og_celt_bands(OgBandCtx &c)
     const int lm = c.lm, M = 1 << lm, start = h->start, end = h->end;
     const int C = (h->flags & OG_F_STEREO) ? 2 : 1;
     const int norm_offset = M * L.k.ebands[start];
-    float *Xf = &L.X[0][0];
 
     OG_STAMP_TO(c.cycles, 16)
     const int nlevels = (int)OG_U32(PL->nlevels), merge_level = (int)OG_U32(PL->merge_level);
@@ -282,6 +342,43 @@ OG_DEV void og_celt_bands(OgBandCtx &c)
             for (int p = tid; p < cnt; p += OG_WG) L.u.norm[0][p] = 0.5f * (L.u.norm[0][p] + L.u.norm[1][p]);
             OG_LANES_END
         }
+        if (lvl == 0) {
+            // every call without fill leaves (most of the frame): a call per 16-lane group, largest first, so that the 42
+            // calls take three rounds per wave instead of ten
+            OG_WAVES_BEGIN(w)
+            const int t0 = (int)OG_U32(PL->task_start[0]), t1 = (int)OG_U32(PL->task_start[1]);
+            for (int base = 0; base < t1 - t0; base += 4 * (OG_WG / 64)) {
+                OG_WAVE_BEGIN(lane)
+                const int k = base + 4 * w + (lane >> 4);
+                if (k < t1 - t0) {
+                    const int id = PL->order[t1 - 1 - k];
+                    const OgTask tk = tasks[id];
+                    if (tk.hm | tk.slog) og_xf_load<false>(L, tk, id & 1, lane & 15, 16);
+                }
+                OG_WAVE_END
+                for (int s = 0; s < (int)OG_U32(PL->lvl_maxcnt[0]); s++) {       // lvl_maxcnt[0] = most butterflies of a level-0 call
+                    OG_WAVE_BEGIN(lane)
+                    const int k = base + 4 * w + (lane >> 4);
+                    if (k < t1 - t0) {
+                        const int id = PL->order[t1 - 1 - k];
+                        const OgTask tk = tasks[id];
+                        const int bit = og_xf_bit(tk, s);
+                        if (bit >= 0) og_xf_bfly(L, tk, id & 1, bit, lane & 15, 16);
+                    }
+                    OG_WAVE_END
+                }
+                OG_WAVE_BEGIN(lane)
+                const int k = base + 4 * w + (lane >> 4);
+                if (k < t1 - t0) {
+                    const int id = PL->order[t1 - 1 - k];
+                    og_task_finish(L, tasks[id], id & 1, norm_offset, lane & 15, 16);
+                }
+                OG_WAVE_END
+            }
+            OG_WAVES_END
+            OG_STAMP_TO(c.cycles, 17)
+            continue;
+        }
         OG_WAVES_BEGIN(w)
         const int t1 = (int)OG_U32(PL->task_start[lvl + 1]);
         for (int ti = (int)OG_U32(PL->task_start[lvl]) + w; ti < t1; ti += OG_WG / 64) {
@@ -290,22 +387,10 @@ OG_DEV void og_celt_bands(OgBandCtx &c)
             if (tk.flags & OG_T_NEED_LB) og_task_xform<true>(L, tk, slot);
             const int k0 = tk.ops & 1023, k1 = k0 + (tk.ops >> 10);
             for (int k = k0; k < k1; k++) og_fill_op(c, k, w);
-            const bool xf = (tk.hm | tk.slog) != 0;
-            if (xf) og_task_xform<false>(L, tk, slot);
-            if (xf || tk.norm_row != 0xFF) {            // copy-back + lowband_out = sqrt(N0) * x (celt/decoder.rs:2021-2028)
-                const int n = tk.n;
-                float *x = Xf + slot * 960 + tk.boff;
-                const float *t = L.v.b.tmp_all + slot * 960 + tk.boff;
-                float *nr = tk.norm_row != 0xFF ? &L.u.norm[tk.norm_row][tk.boff - norm_offset] : nullptr;
-                const float sq = sqrtf((float)n);
-                OG_WAVE_BEGIN(lane)
-                for (int p = lane; p < n; p += 64) {
-                    float v;
-                    if (xf) { v = t[p]; x[p] = v; } else v = x[p];
-                    if (nr) nr[p] = sq * v;
-                }
-                OG_WAVE_END
-            }
+            if (tk.hm | tk.slog) og_task_xform<false>(L, tk, slot);
+            OG_WAVE_BEGIN(lane)
+            og_task_finish(L, tk, slot, norm_offset, lane, 64);
+            OG_WAVE_END
         }
         OG_WAVES_END
         if (lvl == 0) OG_STAMP_TO(c.cycles, 17)

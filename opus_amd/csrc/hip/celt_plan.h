@@ -41,7 +41,7 @@ struct alignas(16) OgBandPlan {
     uint32_t seed_out;
     uint16_t nops, merge_cnt;         // live fill leaves; norm bins below the dual -> intensity switch
     uint8_t nlevels, merge_level;     // highest level in use; level the switch precedes (0xFF = none)
-    uint8_t lvl_maxcnt[OG_MAXLEVEL + 1];   // per level: largest 2^m of its tasks' transforms (0 = no transform at all)
+    uint8_t lvl_maxcnt[OG_MAXLEVEL + 1];   // per level: the most Haar butterflies (0..3) any of its tasks has
     uint8_t pad_[2];
     uint16_t op_start[OG_MAXLEVEL + 2];    // ops of level l: op[op_start[l]] .. op[op_start[l + 1]]
     uint8_t order[44];                // active task ids sorted by level (band order inside a level)
@@ -226,7 +226,7 @@ OG_DEV void og_band_plan(const OgCeltHdr *h, const OgCeltLeaf *lv, const OgCeltC
         for (int slot = 0; slot < 2; slot++) {          // transform sizes per level (non-fill tasks are level 0)
             const OgTask &t = tk[slot];
             if (!(t.flags & OG_T_ACTIVE) || t.n == 1) continue;
-            const int cnt = (t.hm || t.slog) ? 1 << ((t.rctd & 15) + (t.rctd >> 4)) : 0;
+            const int cnt = (t.rctd & 15) + (t.rctd >> 4);      // Haar butterflies of the call
             if (cnt > maxcnt[t.level]) maxcnt[t.level] = (uint8_t)cnt;
         }
         col0[i] = (uint8_t)(dual || C == 1 ? cm[0] : (cm[0] | cm[1]));
