@@ -347,32 +347,32 @@ OG_DEV void og_celt_bands(OgBandCtx &c)
             // calls take three rounds per wave instead of ten
             OG_WAVES_BEGIN(w)
             const int t0 = (int)OG_U32(PL->task_start[0]), t1 = (int)OG_U32(PL->task_start[1]);
+            const int maxb = (int)OG_U32(PL->lvl_maxcnt[0]);        // most butterflies of a level-0 call
             for (int base = 0; base < t1 - t0; base += 4 * (OG_WG / 64)) {
+                OG_WAVE_VAR(OgTask, tkv);                           // the group's task: fetched once per round
+                OG_WAVE_VAR(int, slotv);
                 OG_WAVE_BEGIN(lane)
                 const int k = base + 4 * w + (lane >> 4);
+                OgTask tk;
+                tk.boff = tk.n = tk.n0p = tk.lowpos = tk.ops = 0; tk.flags = tk.hm = tk.slog = tk.rctd = tk.level = 0; tk.norm_row = 0xFF;
+                int slot = 0;
                 if (k < t1 - t0) {
                     const int id = PL->order[t1 - 1 - k];
-                    const OgTask tk = tasks[id];
-                    if (tk.hm | tk.slog) og_xf_load<false>(L, tk, id & 1, lane & 15, 16);
+                    tk = tasks[id];
+                    slot = id & 1;
+                    if (tk.hm | tk.slog) og_xf_load<false>(L, tk, slot, lane & 15, 16);
                 }
+                OG_WV(tkv) = tk;
+                OG_WV(slotv) = slot;
                 OG_WAVE_END
-                for (int s = 0; s < (int)OG_U32(PL->lvl_maxcnt[0]); s++) {       // lvl_maxcnt[0] = most butterflies of a level-0 call
+                for (int s = 0; s < maxb; s++) {
                     OG_WAVE_BEGIN(lane)
-                    const int k = base + 4 * w + (lane >> 4);
-                    if (k < t1 - t0) {
-                        const int id = PL->order[t1 - 1 - k];
-                        const OgTask tk = tasks[id];
-                        const int bit = og_xf_bit(tk, s);
-                        if (bit >= 0) og_xf_bfly(L, tk, id & 1, bit, lane & 15, 16);
-                    }
+                    const int bit = og_xf_bit(OG_WV(tkv), s);
+                    if (bit >= 0) og_xf_bfly(L, OG_WV(tkv), OG_WV(slotv), bit, lane & 15, 16);
                     OG_WAVE_END
                 }
                 OG_WAVE_BEGIN(lane)
-                const int k = base + 4 * w + (lane >> 4);
-                if (k < t1 - t0) {
-                    const int id = PL->order[t1 - 1 - k];
-                    og_task_finish(L, tasks[id], id & 1, norm_offset, lane & 15, 16);
-                }
+                og_task_finish(L, OG_WV(tkv), OG_WV(slotv), norm_offset, lane & 15, 16);     // n = 0 for lanes without a task
                 OG_WAVE_END
             }
             OG_WAVES_END
@@ -403,24 +403,30 @@ OG_DEV void og_celt_bands(OgBandCtx &c)
         OG_WAVES_BEGIN(w)
         for (int i0 = start + 4 * w; i0 < end; i0 += 4 * (OG_WG / 64)) {
             float *pa = L.mrg[w][0], *pb = L.mrg[w][1];
+            OG_WAVE_VAR(OgCeltBand, bdv);                            // the group's band: fetched once
+            OG_WAVE_VAR(int, nv);                                    // its width, 0 = nothing to merge
+            OG_WAVE_VAR(int, offv);
             OG_WAVE_BEGIN(lane)
             const int i = i0 + (lane >> 4), l = lane & 15;
             float a = 0.f, b = 0.f;
-            if (i < end && (h->band[i].flags & OG_B_JOINT)) {
-                const int n = M * L.k.width[i];
-                const float *x = L.X[0] + M * L.k.ebands[i], *y = L.X[1] + M * L.k.ebands[i];
+            OgCeltBand bd = h->band[i < end ? i : start];
+            int n = 0, off = 0;
+            if (i < end && (bd.flags & OG_B_JOINT)) {
+                n = M * L.k.width[i];
+                off = M * L.k.ebands[i];
+                const float *x = L.X[0] + off, *y = L.X[1] + off;
                 if (n > 2)
                     for (int p = l; p < n; p += 16) { a += x[p] * y[p]; b += y[p] * y[p]; }
             }
+            OG_WV(bdv) = bd; OG_WV(nv) = n; OG_WV(offv) = off;
             pa[lane] = a; pb[lane] = b;
             OG_WAVE_END
             OG_WAVE_BEGIN(lane)
-            const int i = i0 + (lane >> 4), l = lane & 15;
+            const int l = lane & 15, n = OG_WV(nv);
             const float xy = og_group16_sum(pa, lane), yy = og_group16_sum(pb, lane);
-            if (i < end && (h->band[i].flags & OG_B_JOINT)) {
-                const OgCeltBand bd = h->band[i];
-                const int n = M * L.k.width[i];
-                float *x = L.X[0] + M * L.k.ebands[i], *y = L.X[1] + M * L.k.ebands[i];
+            if (n) {
+                const OgCeltBand bd = OG_WV(bdv);
+                float *x = L.X[0] + OG_WV(offv), *y = L.X[1] + OG_WV(offv);
                 const float mid = (1.f / 32768) * bd.imid, side = (1.f / 32768) * bd.iside;
                 const float inv = (bd.flags & OG_B_INV) ? -1.f : 1.f;
                 if (n == 2) {

@@ -36,6 +36,10 @@
 #define OG_WAVE_BEGIN(lane) { const int lane = (int)(threadIdx.x & 63); {
 #define OG_WAVE_END } } __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
 #define OG_U32(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+// A per-lane value that lives across several OG_WAVE regions of one OG_WAVES section (a register on the GPU): declare it
+// with OG_WAVE_VAR outside the regions, use it as OG_WV(name) inside them (the region's lane variable must be `lane`).
+#define OG_WAVE_VAR(T, name) T name
+#define OG_WV(name) name
 #else
 #include <math.h>
 #define OG_DEV static inline
@@ -52,4 +56,6 @@
 #define OG_U32(x) ((uint32_t)(x))
 #define OG_WAVE_BEGIN(lane) for (int lane = 0; lane < 64; lane++) { {
 #define OG_WAVE_END } }
+#define OG_WAVE_VAR(T, name) T name[64]
+#define OG_WV(name) name[lane]
 #endif
