@@ -21,34 +21,43 @@
 struct alignas(16) OgF4 { float x, y, z, w; };
 
 #ifndef OG_LDS_OPS
-#define OG_LDS_OPS 48                 // fill ops staged in LDS per frame (C2 frames carry ~5); the rest stay in HBM
+#define OG_LDS_OPS 16                 // fill ops staged in LDS per frame (C2 frames carry ~5); the rest stay in HBM
 #endif
 
+// 31.1 KB: five workgroups per CU (LDS is allotted in 1280-byte granules: 25 of them).  Buffers with disjoint lifetimes
+// share storage.  The 16 KB time buffer `out` is [history | frame + IMDCT tail] per channel; while the comb filter is
+// not running, the history parts hold, one after the other, the folding source `norm` (band walk) and the FFT pong
+// buffer, and the frame parts hold the bounce buffer of the band transforms and the IMDCT twiddles.
 struct alignas(16) OgCeltLds {
     float X[2][960];                  // coefficients (bands) -> MDCT bins -> FFT ping buffer -> de-emphasised PCM
+    float out[2][OG_OUTLEN];          // per channel: [OG_HIST history | frame | tail]
     union {
-        float norm[2][800];           // folding source (celt/decoder.rs `norm_mid`/`norm_side`)
-        OgCf A[2][480];               // FFT pong buffer
-    } u;
-    union {
-        float out[2][OG_OUTLEN];      // [history | frame | tail] time-domain buffer
-        struct {                      // band-walk lifetime (the time buffer is idle until denormalisation)
-            float lb_all[2 * 960];    // transformed copies of the folding sources, laid out like X
-            float tmp_all[2 * 960];   // bounce buffer of the fused reorder
+        struct {                      // band-walk lifetime
+            uint32_t lcg_a[184], lcg_c[184];                      // noise-seed jump tables (copy of OgCeltTables')
+            alignas(16) uint32_t plan_head[OG_PLAN_HEAD_BYTES / 4];   // OgBandPlan up to (not including) .op
+            OgFillOp ops[OG_LDS_OPS];
+            union {
+                float lb[OG_WG / 64][176];                        // per wave: transformed copy of its task's folding source
+                float mrg[OG_WG / 64][2][64];                     // per wave: stereo merge partial sums
+            } s;
         } b;
-    } v;
+        struct {                      // from denormalisation on
+            OgCf W[480];              // FFT twiddles
+            uint8_t bin2band[960];
+            float carry[2][64];       // de-emphasis carries
+        } t;
+    } w;
     OgCeltConst k;                    // LDS copy of the small constant tables
-    uint32_t lcg_a[184], lcg_c[184];  // noise-seed jump tables (copy of OgCeltTables')
-    alignas(16) uint32_t plan_head[OG_PLAN_HEAD_BYTES / 4];   // OgBandPlan up to (not including) .op
-    OgFillOp ops[OG_LDS_OPS];
-    uint8_t bin2band[960];
-    float mrg[OG_WG / 64][2][64];     // stereo merge partial sums, per wave
     float gband[2][24];               // denormalisation gains
     float window[120];                // TDAC / comb cross-fade window (copy of OgCeltTables')
     OgCeltHdr hdr;                    // the frame's side-info, staged once (uniform control code reads it from LDS)
     float red[4];
-    float carry[OG_WG / 64][64];      // de-emphasis carries; per-wave partial sums during the band walk
 };
+// views into `out` (see above)
+OG_DEV float *og_norm(OgCeltLds &L, int row) { return &L.out[row][0]; }                 // folding source row (800 used)
+OG_DEV float *og_tmp(OgCeltLds &L, int slot) { return &L.out[slot][OG_HIST]; }          // bounce buffer of channel buffer `slot` (960)
+OG_DEV float *og_part(OgCeltLds &L, int w) { return &L.out[w >> 1][800 + 64 * (w & 1)]; }   // wave w's 64 partial sums (band walk)
+#define OG_A_CHS (OG_OUTLEN / 2)      // channel stride of the FFT pong buffer, in complex elements
 
 #include "celt_pvq.h"
 
@@ -190,21 +199,21 @@ template <class T> OG_DEV T og_uniform(const T &v) { return v; }
 // :1708-1740, :1994-2019) are butterflies on the index bits `hm` (celt_plan.h) and commute; the Hadamard (de)interleave
 // (:472-538) is a permutation.  The pieces below each produce elements first, first + step, ... of the task for the
 // calling lane (a whole wave: first = lane, step = 64, task record in scalar registers; a 16-lane group: first = lane & 15,
-// step = 16); the caller separates them with wave-level fences.  Everything happens in the task's slice of tmp_all:
-//   PRE  (lowband copy):  load source -> butterflies -> lb_all[deinterleave(p)] = scale * tmp[p]
+// step = 16); the caller separates them with wave-level fences.  Everything happens in the task's slice of the bounce buffer (og_tmp):
+//   PRE  (lowband copy):  load source -> butterflies -> lb[deinterleave(p)] = scale * tmp[p] (lb: the wave's lowband buffer)
 //   POST (decoded band):  load X[interleave(p)] -> butterflies -> og_task_finish (scale, copy back, lowband_out)
 template <bool PRE>
 OG_DEV void og_xf_load(OgCeltLds &L, const OgTask tk, int slot, int first, int step)
 {
     const int n = tk.n, slog = tk.slog, n0p = tk.n0p, had = (tk.flags & OG_T_LONG) != 0;
-    const float *src = PRE ? &L.u.norm[0][0] + ((tk.flags & OG_T_LB_ROW1) ? 800 : 0) + tk.lowpos : &L.X[0][0] + slot * 960 + tk.boff;
-    float *tmp = L.v.b.tmp_all + slot * 960 + tk.boff;
+    const float *src = PRE ? og_norm(L, (tk.flags & OG_T_LB_ROW1) ? 1 : 0) + tk.lowpos : &L.X[0][0] + slot * 960 + tk.boff;
+    float *tmp = og_tmp(L, slot) + tk.boff;
     for (int p = first; p < n; p += step) tmp[p] = src[PRE ? p : og_reorder(slog, n0p, had, p)];
 }
 
 OG_DEV void og_xf_bfly(OgCeltLds &L, const OgTask tk, int slot, int bit, int first, int step)   // unscaled Haar step on index bit `bit`
 {
-    float *tmp = L.v.b.tmp_all + slot * 960 + tk.boff;
+    float *tmp = og_tmp(L, slot) + tk.boff;
     const int half = tk.n >> 1, low = (1 << bit) - 1;
     for (int q = first; q < half; q += step) {
         const int i0 = ((q & ~low) << 1) | (q & low), i1 = i0 | (1 << bit);
@@ -220,11 +229,10 @@ OG_DEV float og_xf_scale(const OgTask tk)               // 2^(-m/2) for the m bu
     return tk.hm ? (m & 1 ? 0.70710678118654752440f : 1.f) / (float)(1 << (m >> 1)) : 1.f;
 }
 
-OG_DEV void og_xf_store_pre(OgCeltLds &L, const OgTask tk, int slot, int first, int step)
+OG_DEV void og_xf_store_pre(OgCeltLds &L, const OgTask tk, int slot, float *lb, int first, int step)
 {
     const int n = tk.n, slog = tk.slog, n0p = tk.n0p, had = (tk.flags & OG_T_LONG) != 0;
-    const float *tmp = L.v.b.tmp_all + slot * 960 + tk.boff;
-    float *lb = L.v.b.lb_all + slot * 960 + tk.boff;
+    const float *tmp = og_tmp(L, slot) + tk.boff;
     const float scale = og_xf_scale(tk);
     for (int p = first; p < n; p += step) lb[og_reorder(slog, n0p, had, p)] = tmp[p] * scale;
 }
@@ -238,7 +246,7 @@ OG_DEV int og_xf_bit(const OgTask tk, int s)
 }
 
 template <bool PRE>
-OG_DEV void og_task_xform(OgCeltLds &L, const OgTask tk, int slot)     // by one wave, inside an OG_WAVES section
+OG_DEV void og_task_xform(OgCeltLds &L, const OgTask tk, int slot, float *lb)     // by one wave, inside an OG_WAVES section
 {
     OG_WAVE_BEGIN(lane)
     og_xf_load<PRE>(L, tk, slot, lane, 64);
@@ -252,7 +260,7 @@ OG_DEV void og_task_xform(OgCeltLds &L, const OgTask tk, int slot)     // by one
     }
     if (PRE) {
         OG_WAVE_BEGIN(lane)
-        og_xf_store_pre(L, tk, slot, lane, 64);
+        og_xf_store_pre(L, tk, slot, lb, lane, 64);
         OG_WAVE_END
     }
 }
@@ -264,8 +272,8 @@ OG_DEV void og_task_finish(OgCeltLds &L, const OgTask tk, int slot, int norm_off
     if (!xf && tk.norm_row == 0xFF) return;
     const int n = tk.n;
     float *x = &L.X[0][0] + slot * 960 + tk.boff;
-    const float *t = L.v.b.tmp_all + slot * 960 + tk.boff;
-    float *nr = tk.norm_row != 0xFF ? &L.u.norm[tk.norm_row == 0xFF ? 0 : tk.norm_row][tk.boff - norm_offset] : nullptr;
+    const float *t = og_tmp(L, slot) + tk.boff;
+    float *nr = tk.norm_row != 0xFF ? og_norm(L, tk.norm_row) + (tk.boff - norm_offset) : nullptr;
     const float sq = sqrtf((float)n), scale = og_xf_scale(tk);
     for (int p = first; p < n; p += step) {
         float v;
@@ -276,13 +284,13 @@ OG_DEV void og_task_finish(OgCeltLds &L, const OgTask tk, int slot, int norm_off
 
 // One live fill leaf (celt/decoder.rs:1633-1661 + renormalize_vector :788-794), by wave w alone: n <= 176, at most
 // three coefficients per lane, no workgroup barrier.  Ops of one level touch disjoint coefficients.
-OG_DEV void og_fill_op(OgBandCtx &c, int k, int w)
+OG_DEV void og_fill_op(OgBandCtx &c, int k, int w, int task_pos)     // task_pos: slot * 960 + first bin of the op's task
 {
     OgCeltLds &L = *c.L;
-    const OgFillOp op = k < OG_LDS_OPS ? og_uniform(L.ops[k]) : og_uniform(c.plan->op[k]);
-    float *xl = &L.X[0][0] + op.pos, *part = L.carry[w];
-    const float *lbl = L.v.b.lb_all + op.pos;
-    const uint32_t *la = L.lcg_a, *lc = L.lcg_c;
+    const OgFillOp op = k < OG_LDS_OPS ? og_uniform(L.w.b.ops[k]) : og_uniform(c.plan->op[k]);
+    float *xl = &L.X[0][0] + op.pos, *part = og_part(L, w);
+    const float *lbl = L.w.b.s.lb[w] + ((int)op.pos - task_pos);
+    const uint32_t *la = L.w.b.lcg_a, *lc = L.w.b.lcg_c;
     const int nn = op.n;
     const uint32_t s0 = op.seed;
     if (!(op.flags & OG_OP_FOLD)) {                     // noise (celt/decoder.rs:1644-1651)
@@ -327,8 +335,8 @@ OG_DEV void og_celt_bands(OgBandCtx &c)
 {
     const OgCeltHdr *h = c.h;
     OgCeltLds &L = *c.L;
-    const OgBandPlan *PL = (const OgBandPlan *)L.plan_head;      // head fields only
-    const OgTask *tasks = (const OgTask *)L.plan_head;
+    const OgBandPlan *PL = (const OgBandPlan *)L.w.b.plan_head;      // head fields only
+    const OgTask *tasks = (const OgTask *)L.w.b.plan_head;
     const int lm = c.lm, M = 1 << lm, start = h->start, end = h->end;
     const int C = (h->flags & OG_F_STEREO) ? 2 : 1;
     const int norm_offset = M * L.k.ebands[start];
@@ -339,7 +347,7 @@ OG_DEV void og_celt_bands(OgBandCtx &c)
         if (lvl == merge_level) {                       // dual -> intensity switch (celt/decoder.rs:2133-2138)
             const int cnt = PL->merge_cnt;
             OG_LANES_BEGIN(tid)
-            for (int p = tid; p < cnt; p += OG_WG) L.u.norm[0][p] = 0.5f * (L.u.norm[0][p] + L.u.norm[1][p]);
+            for (int p = tid; p < cnt; p += OG_WG) L.out[0][p] = 0.5f * (L.out[0][p] + L.out[1][p]);
             OG_LANES_END
         }
         if (lvl == 0) {
@@ -384,10 +392,10 @@ OG_DEV void og_celt_bands(OgBandCtx &c)
         for (int ti = (int)OG_U32(PL->task_start[lvl]) + w; ti < t1; ti += OG_WG / 64) {
             const int id = (int)OG_U32(PL->order[ti]), slot = id & 1;
             const OgTask tk = og_uniform(tasks[id]);
-            if (tk.flags & OG_T_NEED_LB) og_task_xform<true>(L, tk, slot);
+            if (tk.flags & OG_T_NEED_LB) og_task_xform<true>(L, tk, slot, L.w.b.s.lb[w]);
             const int k0 = tk.ops & 1023, k1 = k0 + (tk.ops >> 10);
-            for (int k = k0; k < k1; k++) og_fill_op(c, k, w);
-            if (tk.hm | tk.slog) og_task_xform<false>(L, tk, slot);
+            for (int k = k0; k < k1; k++) og_fill_op(c, k, w, slot * 960 + tk.boff);
+            if (tk.hm | tk.slog) og_task_xform<false>(L, tk, slot, nullptr);
             OG_WAVE_BEGIN(lane)
             og_task_finish(L, tk, slot, norm_offset, lane, 64);
             OG_WAVE_END
@@ -402,7 +410,7 @@ OG_DEV void og_celt_bands(OgBandCtx &c)
     if (C == 2) {
         OG_WAVES_BEGIN(w)
         for (int i0 = start + 4 * w; i0 < end; i0 += 4 * (OG_WG / 64)) {
-            float *pa = L.mrg[w][0], *pb = L.mrg[w][1];
+            float *pa = L.w.b.s.mrg[w][0], *pb = L.w.b.s.mrg[w][1];
             OG_WAVE_VAR(OgCeltBand, bdv);                            // the group's band: fetched once
             OG_WAVE_VAR(int, nv);                                    // its width, 0 = nothing to merge
             OG_WAVE_VAR(int, offv);
@@ -469,7 +477,7 @@ OG_DEV void og_anti_collapse(OgBandCtx &c)
     const OgCeltHdr *h = c.h;
     OgCeltLds &L = *c.L;
     const int lm = c.lm, C = (h->flags & OG_F_STEREO) ? 2 : 1;
-    const uint32_t *la = c.L->lcg_a, *lc = c.L->lcg_c;
+    const uint32_t *la = c.L->w.b.lcg_a, *lc = c.L->w.b.lcg_c;
     for (int i = h->start; i < h->end; i++) {
         const int n0 = L.k.width[i];
         const int depth = h->pulses_depth[i];
@@ -483,7 +491,7 @@ OG_DEV void og_anti_collapse(OgBandCtx &c)
             if (r > thresh) r = thresh;
             r *= sqrt_1;
             float *x = L.X[ch] + (L.k.ebands[i] << lm);
-            const int mask = ((const OgBandPlan *)L.plan_head)->collapse[ch][i];
+            const int mask = ((const OgBandPlan *)L.w.b.plan_head)->collapse[ch][i];
             bool renorm = false;
             for (int k = 0; k < (1 << lm); k++) {
                 if (mask & (1 << k)) continue;
@@ -511,10 +519,10 @@ OG_DEV OgCf og_cmul(OgCf a, OgCf b) { OgCf r; r.r = a.r * b.r - a.i * b.i; r.i =
 OG_DEV int og_div(int q, float inv_d) { return (int)(((float)q + 0.5f) * inv_d); }
 
 // One Stockham stage of radix R over nch*blocks transforms of size n; transform b of channel ch starts at
-// ch*480 + b*n.  Ns = product of the radices already done: a power of two for R = 2, 3, 4 (stage order 4,4,2,3,5)
+// ch*schs + b*n in src and ch*dchs + b*n in dst.  Ns = product of the radices already done: a power of two for R = 2, 3, 4 (stage order 4,4,2,3,5)
 // and n/5 for the final R = 5 stage, so the position inside the sub-transform never needs a division.
 template <int R>
-OG_DEV void og_wg_fft_stage(const OgCf *src, OgCf *dst, int n, int nch, int blocks, int Ns, const OgCf *W)
+OG_DEV void og_wg_fft_stage(const OgCf *src, OgCf *dst, int schs, int dchs, int n, int nch, int blocks, int Ns, const OgCf *W)
 {
     const int per = n / R, total = nch * blocks * per, wstep = 480 / (Ns * R);
     const float inv_per = 1.f / (float)per;
@@ -523,7 +531,7 @@ OG_DEV void og_wg_fft_stage(const OgCf *src, OgCf *dst, int n, int nch, int bloc
     for (int q = tid; q < total; q += OG_WG) {
         const int tt = og_div(q, inv_per), j = q - tt * per;
         const int ch = tt >> bsh, b = tt & (blocks - 1);
-        const int base = ch * 480 + b * n;
+        const int base = ch * schs + b * n, obase = ch * dchs + b * n;
         const int k = R == 5 ? j : (j & (Ns - 1));
         const int j0 = (j - k) * R + k;
         OgCf v[R];
@@ -532,7 +540,7 @@ OG_DEV void og_wg_fft_stage(const OgCf *src, OgCf *dst, int n, int nch, int bloc
             v[r] = src[base + j + r * per];
             if (r) v[r] = og_cmul(v[r], W[k * r * wstep]);
         }
-        OgCf *o = dst + base + j0;
+        OgCf *o = dst + obase + j0;
         if (R == 2) {
             o[0].r = v[0].r + v[1].r; o[0].i = v[0].i + v[1].i;
             o[Ns].r = v[0].r - v[1].r; o[Ns].i = v[0].i - v[1].i;
@@ -571,7 +579,7 @@ OG_DEV void og_wg_fft_stage(const OgCf *src, OgCf *dst, int n, int nch, int bloc
 }
 
 // RFC 6716 celt.c comb_filter, in place, for one channel by one wave (inside an OG_WAVES section): y points at the
-// channel's sample 0 inside L.v.out.  The recursion reaches back >= 13 samples, so `step` samples are independent at a
+// channel's sample 0 inside L.out.  The recursion reaches back >= 13 samples, so `step` samples are independent at a
 // time; the steps are ordered by the wave's own LDS ordering, no workgroup barrier.
 OG_DEV void og_wave_comb_filter(float *y, int T0, int T1, int n, float g0, float g1, int tap0, int tap1,
                                 const float *window, const float (*taps)[4])
@@ -623,21 +631,20 @@ OG_DEV void og_celt_frame(const OgCeltHdr *hg, const OgBandPlan *plan, const OgC
         uint32_t *dst = (uint32_t *)&L.hdr;
         for (int p = tid; p < (int)(sizeof(OgCeltHdr) / 4); p += OG_WG) dst[p] = src[p];
         const uint32_t *ps = (const uint32_t *)plan;    // head, then the first fill ops
-        for (int p = tid; p < OG_PLAN_HEAD_BYTES / 4; p += OG_WG) L.plan_head[p] = ps[p];
-        uint32_t *od = (uint32_t *)L.ops;
+        for (int p = tid; p < OG_PLAN_HEAD_BYTES / 4; p += OG_WG) L.w.b.plan_head[p] = ps[p];
+        uint32_t *od = (uint32_t *)L.w.b.ops;
         for (int p = tid; p < OG_LDS_OPS * 4; p += OG_WG) od[p] = ps[OG_PLAN_HEAD_BYTES / 4 + p];
     }
     for (int p = tid; p < (int)(sizeof(OgCeltConst) / 4); p += OG_WG) ((uint32_t *)&L.k)[p] = ((const uint32_t *)&T->k)[p];
-    for (int p = tid; p < 184; p += OG_WG) { L.lcg_a[p] = T->lcg_a[p]; L.lcg_c[p] = T->lcg_c[p]; }
+    for (int p = tid; p < 184; p += OG_WG) { L.w.b.lcg_a[p] = T->lcg_a[p]; L.w.b.lcg_c[p] = T->lcg_c[p]; }
     for (int p = tid; p < 120; p += OG_WG) L.window[p] = T->window[p];
-    for (int p = tid; p < 960 / 4; p += OG_WG) ((uint32_t *)L.bin2band)[p] = ((const uint32_t *)T->bin2band[lm0])[p];
     // K1's output for this frame: shaped PVQ coefficients (zero elsewhere).  The scratch row is handed back zero-filled
     // for the next launch.
     for (int p = tid; p < 2 * 960 / 4; p += OG_WG) {    // 16 bytes per lane
         ((OgF4 *)&L.X[0][0])[p] = ((const OgF4 *)coef_row)[p];
         ((OgF4 *)coef_row)[p] = OgF4{0.f, 0.f, 0.f, 0.f};
     }
-    for (int p = tid; p < 2 * 800; p += OG_WG) (&L.u.norm[0][0])[p] = 0.f;
+    for (int p = tid; p < 2 * 800; p += OG_WG) L.out[p >= 800][p >= 800 ? p - 800 : p] = 0.f;
     OG_LANES_END
     const OgCeltHdr *h = &L.hdr;
     const int lm = h->lm, M = 1 << lm, N = 120 << lm;
@@ -656,18 +663,21 @@ OG_DEV void og_celt_frame(const OgCeltHdr *hg, const OgBandPlan *plan, const OgC
         if (dbg_norm || dbg_collapse) {
             OG_LANES_BEGIN(tid)
             if (dbg_norm) for (int p = tid; p < 2 * 960; p += OG_WG) dbg_norm[p] = (&L.X[0][0])[p];
-            if (dbg_collapse && tid < 42) dbg_collapse[tid] = ((const OgBandPlan *)L.plan_head)->collapse[tid / 21][tid % 21];
+            if (dbg_collapse && tid < 42) dbg_collapse[tid] = ((const OgBandPlan *)L.w.b.plan_head)->collapse[tid / 21][tid % 21];
             OG_LANES_END
         }
         OG_STAMP(3)
         if (h->flags & OG_F_ANTICOLLAPSE) og_anti_collapse(c);
     }
     OG_STAMP(4)
+    OG_BARRIER                                          // the uniform reads of the band-walk tables above are done in every wave
+                                                        // before the twiddles below replace them
 
-    // ---- phase 4: denormalise (RFC 6716 4.3.6) + channel up/down-mix into MDCT bins; the same two regions stage the
-    //      FFT twiddles and this block size's IMDCT twiddles into the (currently idle) history part of the time buffer
+    // ---- phase 4: denormalise (RFC 6716 4.3.6) + channel up/down-mix into MDCT bins; the first region also stages the
+    //      FFT twiddles and the bin -> band map over the (now dead) band-walk tables, and this block size's IMDCT twiddles
+    //      into the (idle) frame part of channel 0's time buffer
     const int B = transient ? M : 1, NB = N / B, n4 = NB >> 1;
-    OgCf *ldsW = (OgCf *)&L.v.out[0][0], *ldsTw = (OgCf *)&L.v.out[1][0];
+    OgCf *ldsW = L.w.t.W, *ldsTw = (OgCf *)&L.out[0][OG_HIST];
     OG_LANES_BEGIN(tid)
     for (int t = tid; t < 48; t += OG_WG) {             // per-(channel, band) gains 2^(E + mean), zero outside [start, end)
         const int ch = t >= 24, b = t - 24 * ch;
@@ -679,6 +689,7 @@ OG_DEV void og_celt_frame(const OgCeltHdr *hg, const OgBandPlan *plan, const OgC
         L.gband[ch][b] = g;
     }
     for (int p = tid; p < 960; p += OG_WG) ((float *)ldsW)[p] = ((const float *)T->fft_w)[p];
+    for (int p = tid; p < 960 / 4; p += OG_WG) ((uint32_t *)L.w.t.bin2band)[p] = ((const uint32_t *)T->bin2band[lm0])[p];
     for (int p = tid; p < 2 * n4; p += OG_WG) ((float *)ldsTw)[p] = ((const float *)(T->tw + (n4 - 60)))[p];
     OG_LANES_END
     OG_STAMP(9)
@@ -688,7 +699,7 @@ OG_DEV void og_celt_frame(const OgCeltHdr *hg, const OgBandPlan *plan, const OgC
 #pragma unroll
     for (int k = 0; k < 4; k++) {                       // loads first (independent), then arithmetic: the LDS latencies overlap
         const int j = tid + k * OG_WG < 960 ? tid + k * OG_WG : 959;
-        bb[k] = L.bin2band[j];
+        bb[k] = L.w.t.bin2band[j];
         x0[k] = L.X[0][j];
         x1[k] = L.X[1][j];
     }
@@ -715,10 +726,11 @@ OG_DEV void og_celt_frame(const OgCeltHdr *hg, const OgBandPlan *plan, const OgC
     }
 
     OG_STAMP(5)
-    // ---- phase 5 (K3): IMDCT.  B blocks of NB bins, interleaved with stride B in X.
+    // ---- phase 5 (K3): IMDCT.  B blocks of NB bins, interleaved with stride B in X.  The FFT ping-pongs between the
+    //      history parts of the time buffer (channel stride OG_A_CHS) and X (channel stride 480).
     const OgCf *tw = ldsTw;
     const float inv_n4 = 1.f / (float)n4;
-    OgCf *bufA = &L.u.A[0][0], *bufB = (OgCf *)&L.X[0][0];
+    OgCf *bufA = (OgCf *)&L.out[0][0], *bufB = (OgCf *)&L.X[0][0];
     OG_LANES_BEGIN(tid)
     for (int q = tid; q < CC * (N >> 1); q += OG_WG) {                       // pre-twiddle
         const int ch = q >= (N >> 1), r = q - ch * (N >> 1), b = og_div(r, inv_n4), i = r - b * n4;
@@ -727,9 +739,19 @@ OG_DEV void og_celt_frame(const OgCeltHdr *hg, const OgBandPlan *plan, const OgC
         OgCf z;
         z.r = x1 * w.r + x2 * w.i;
         z.i = x2 * w.r - x1 * w.i;
-        bufA[ch * 480 + b * n4 + i] = z;
+        bufA[ch * OG_A_CHS + b * n4 + i] = z;
     }
     OG_LANES_END
+    // comb post-filter parameters (RFC 6716 4.3.7.1): sets [0] old, [1] current, [2] new
+    const float pg0 = 0.09375f * h->pf_gain_q[0], pg1 = 0.09375f * h->pf_gain_q[1], pg2 = 0.09375f * h->pf_gain_q[2];
+    const uint32_t pos0 = reset ? 0u : st->pos;
+    const bool pf_on = pg0 != 0.f || pg1 != 0.f || (lm != 0 && pg2 != 0.f);
+    int reach = 0;                                      // history samples the comb filter reads
+    if (pf_on) {
+        for (int k = 0; k < 3; k++) { int t = h->pf_period[k] < 15 ? 15 : h->pf_period[k]; if (t > reach) reach = t; }
+        reach += 2;
+        if (reach > OG_HIST) reach = OG_HIST;
+    }
     {
         int radix[5], ns = 0;                           // 60 * 2^lm = 4 * 4^a * 2^b * 3 * 5
         int rem = n4 / 15;
@@ -739,36 +761,74 @@ OG_DEV void og_celt_frame(const OgCeltHdr *hg, const OgBandPlan *plan, const OgC
         radix[ns++] = 5;
         int Ns = 1;
         OgCf *src = bufA, *dst = bufB;
+        int schs = OG_A_CHS, dchs = 480;
         for (int s = 0; s < ns; s++) {
             switch (radix[s]) {
-            case 4: og_wg_fft_stage<4>(src, dst, n4, CC, B, Ns, ldsW); break;
-            case 2: og_wg_fft_stage<2>(src, dst, n4, CC, B, Ns, ldsW); break;
-            case 3: og_wg_fft_stage<3>(src, dst, n4, CC, B, Ns, ldsW); break;
-            default: og_wg_fft_stage<5>(src, dst, n4, CC, B, Ns, ldsW); break;
+            case 4: og_wg_fft_stage<4>(src, dst, schs, dchs, n4, CC, B, Ns, ldsW); break;
+            case 2: og_wg_fft_stage<2>(src, dst, schs, dchs, n4, CC, B, Ns, ldsW); break;
+            case 3: og_wg_fft_stage<3>(src, dst, schs, dchs, n4, CC, B, Ns, ldsW); break;
+            default: og_wg_fft_stage<5>(src, dst, schs, dchs, n4, CC, B, Ns, ldsW); break;
             }
             Ns *= radix[s];
             OgCf *t = src; src = dst; dst = t;
+            const int ts = schs; schs = dchs; dchs = ts;
         }
-        // `src` now holds the spectrum; load state + post-twiddle into the time buffer
+        // `src` now holds the spectrum.  Post-twiddle into registers (the twiddles sit where the samples go), then, past
+        // the barrier, into the time buffer; the same region fetches the stream's state: the previous frame's tail and,
+        // into the history part (the FFT is done with it), the samples the comb filter reaches back to.
+        struct OgPost { float r[4], i[4]; };
+        OG_LANE_VAR(OgPost, pv);
         OG_LANES_BEGIN(tid)
-        for (int q = tid; q < CC * 60; q += OG_WG) {                         // previous frame's tail
-            const int ch = q / 60, i = q - ch * 60;
-            L.v.out[ch][OG_HIST + i] = reset ? 0.f : st->overlap[ch][i];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int q = tid + j * OG_WG;
+            OG_LV(pv).r[j] = OG_LV(pv).i[j] = 0.f;
+            if (q < CC * (N >> 1)) {
+                const int ch = q >= (N >> 1), r = q - ch * (N >> 1), b = og_div(r, inv_n4), k = r - b * n4;
+                const OgCf Z = src[ch * schs + b * n4 + k], w = tw[k];
+                OG_LV(pv).r[j] = Z.r * w.r + Z.i * w.i;
+                OG_LV(pv).i[j] = Z.i * w.r - Z.r * w.i;
+            }
         }
-        for (int q = tid; q < CC * (N >> 1); q += OG_WG) {
-            const int ch = q >= (N >> 1), r = q - ch * (N >> 1), b = og_div(r, inv_n4), k = r - b * n4;
-            const OgCf Z = src[ch * 480 + b * n4 + k], w = tw[k];
-            const float vr = Z.r * w.r + Z.i * w.i, vi = Z.i * w.r - Z.r * w.i;
-            float *D = &L.v.out[ch][OG_HIST + NB * b + 60];
-            D[2 * k] = vi;
-            D[NB - 1 - 2 * k] = -vr;
+        OG_LANES_END
+        OG_LANES_BEGIN(tid)
+        float hv[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {                    // CC * reach <= 2048 = 8 per lane
+            const int q = tid + j * OG_WG;
+            hv[j] = 0.f;
+            if (q < CC * reach && !reset) {
+                const int ch = q >= reach, d = q - ch * reach + 1;
+                hv[j] = st->hist[ch][(pos0 - (uint32_t)d) & 1023u];
+            }
+        }
+        float ov = 0.f;
+        if (tid < CC * 60 && !reset) ov = st->overlap[tid >= 60][tid >= 60 ? tid - 60 : tid];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int q = tid + j * OG_WG;
+            if (q < CC * (N >> 1)) {
+                const int ch = q >= (N >> 1), r = q - ch * (N >> 1), b = og_div(r, inv_n4), k = r - b * n4;
+                float *D = &L.out[ch][OG_HIST + NB * b + 60];
+                D[2 * k] = OG_LV(pv).i[j];
+                D[NB - 1 - 2 * k] = -OG_LV(pv).r[j];
+            }
+        }
+        if (tid < CC * 60) L.out[tid >= 60][OG_HIST + (tid >= 60 ? tid - 60 : tid)] = ov;    // previous frame's tail
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int q = tid + j * OG_WG;
+            if (q < CC * reach) {
+                const int ch = q >= reach, d = q - ch * reach + 1;
+                L.out[ch][OG_HIST - d] = hv[j];
+            }
         }
         OG_LANES_END
     }
     OG_LANES_BEGIN(tid)
     for (int q = tid; q < CC * B * 60; q += OG_WG) {                         // TDAC mirror (RFC 6716 mdct.c)
         const int ch = q >= B * 60, r = q - ch * (B * 60), b = og_div(r, 1.f / 60.f), i = r - b * 60;
-        float *o = &L.v.out[ch][OG_HIST + NB * b];
+        float *o = &L.out[ch][OG_HIST + NB * b];
         const float x1 = o[119 - i], x2 = o[i];
         const float w1 = L.window[i], w2 = L.window[119 - i];
         o[i] = w2 * x2 - w1 * x1;
@@ -777,23 +837,6 @@ OG_DEV void og_celt_frame(const OgCeltHdr *hg, const OgBandPlan *plan, const OgC
     OG_LANES_END
 
     OG_STAMP(6)
-    // ---- phase 6: comb post-filter (RFC 6716 4.3.7.1); parameter sets [0] old, [1] current, [2] new
-    const float pg0 = 0.09375f * h->pf_gain_q[0], pg1 = 0.09375f * h->pf_gain_q[1], pg2 = 0.09375f * h->pf_gain_q[2];
-    const uint32_t pos0 = reset ? 0u : st->pos;
-    if (pg0 != 0.f || pg1 != 0.f || (lm != 0 && pg2 != 0.f)) {
-        int reach = 0;
-        for (int k = 0; k < 3; k++) { int t = h->pf_period[k] < 15 ? 15 : h->pf_period[k]; if (t > reach) reach = t; }
-        reach += 2;
-        if (reach > OG_HIST) reach = OG_HIST;
-        OG_LANES_BEGIN(tid)
-        for (int q = tid; q < CC * reach; q += OG_WG) {
-            const int ch = q / reach, d = q - ch * reach + 1;
-            L.v.out[ch][OG_HIST - d] = reset ? 0.f : st->hist[ch][(pos0 - (uint32_t)d) & 1023u];
-        }
-        OG_LANES_END
-    }
-    const bool pf_on = pg0 != 0.f || pg1 != 0.f || (lm != 0 && pg2 != 0.f);
-
     OG_STAMP(7)
     // ---- phases 6b + 7: comb filter, then de-emphasis t[j] = y[j] + 0.85 t[j-1] as a blocked scan (N/15 lanes x 15
     //      samples: an odd chunk length keeps the lanes' LDS accesses on distinct banks), one wave per channel with no workgroup barrier in between; then coalesced PCM + state write-back
@@ -806,7 +849,7 @@ OG_DEV void og_celt_frame(const OgCeltHdr *hg, const OgBandPlan *plan, const OgC
     OG_WAVES_BEGIN(w)
     if (w < CC) {
         const int ch = w;
-        float *y0 = &L.v.out[ch][OG_HIST];
+        float *y0 = &L.out[ch][OG_HIST];
         if (pf_on) {
             og_wave_comb_filter(y0, h->pf_period[0], h->pf_period[1], 120, pg0, pg1, h->pf_tapset[0], h->pf_tapset[1], L.window, L.k.pf_taps);
             if (lm != 0)
@@ -819,7 +862,7 @@ OG_DEV void og_celt_frame(const OgCeltHdr *hg, const OgBandPlan *plan, const OgC
             const float *y = y0 + l * Lc;
             float m = 0.f, t = 0.f;
             for (int j = 0; j < Lc; j++) { t = y[j] + m; m = coef * t; }
-            L.carry[ch][l] = m;                         // chunk's own contribution to the running memory
+            L.w.t.carry[ch][l] = m;                         // chunk's own contribution to the running memory
         }
         OG_WAVE_END
         // carry-in of chunk l = sum over earlier chunks q of carry[q] * coef^(Lc*(l-1-q)) (+ the stream's memory); terms
@@ -829,7 +872,7 @@ OG_DEV void og_celt_frame(const OgCeltHdr *hg, const OgBandPlan *plan, const OgC
         if (l < nl) {
             const int q0 = l > reach ? l - reach : 0;
             float m = (reset || q0 > 0) ? 0.f : st->deemph[ch];
-            for (int q = q0; q < l; q++) m = m * aL + L.carry[ch][q];
+            for (int q = q0; q < l; q++) m = m * aL + L.w.t.carry[ch][q];
             const float *y = y0 + l * Lc;
             float *t = tbuf + ch * 960 + l * Lc;
             for (int j = 0; j < Lc; j++) { const float v = y[j] + m; m = coef * v; t[j] = v; }
@@ -867,11 +910,11 @@ OG_DEV void og_celt_frame(const OgCeltHdr *hg, const OgBandPlan *plan, const OgC
     // history ring: pos0 and N are multiples of 8, so groups of four samples never straddle the wrap
     for (int q = tid; q < CC * (N >> 2); q += OG_WG) {
         const int ch = q >= (N >> 2), i = 4 * (q - ch * (N >> 2));
-        *(OgF4 *)&st->hist[ch][(pos0 + (uint32_t)i) & 1023u] = *(const OgF4 *)&L.v.out[ch][OG_HIST + i];
+        *(OgF4 *)&st->hist[ch][(pos0 + (uint32_t)i) & 1023u] = *(const OgF4 *)&L.out[ch][OG_HIST + i];
     }
     for (int q = tid; q < CC * 15; q += OG_WG) {
         const int ch = q >= 15, i = 4 * (q - ch * 15);
-        *(OgF4 *)&st->overlap[ch][i] = *(const OgF4 *)&L.v.out[ch][OG_HIST + N + i];
+        *(OgF4 *)&st->overlap[ch][i] = *(const OgF4 *)&L.out[ch][OG_HIST + N + i];
     }
     if (reset)                                          // forget the ring's older samples
         for (int q = tid; q < CC * ((1024 - N) >> 2); q += OG_WG) {

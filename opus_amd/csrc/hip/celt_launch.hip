@@ -51,7 +51,7 @@ __global__ __launch_bounds__(64) void og_plan_kernel(const OgCeltHdr *__restrict
         og_plan_frame((const OgCeltHdr *)hs + threadIdx.x, leaves, f, K, la, lc, work, OgLaneScratch{sc + threadIdx.x, OG_PLAN_FPW});
 }
 
-__global__ __launch_bounds__(OG_WG, 4) void og_celt_kernel(const OgCeltHdr *__restrict__ hdr, uint32_t nframes, uint32_t frames_per_group,
+__global__ __launch_bounds__(OG_WG) __attribute__((amdgpu_waves_per_eu(5, 5))) void og_celt_kernel(const OgCeltHdr *__restrict__ hdr, uint32_t nframes, uint32_t frames_per_group,
                                                            const OgCeltTables *__restrict__ T, void *work, OgCeltState *state,
                                                            float *pcm, size_t pcm_stride, OgCeltDebug dbg)
 {

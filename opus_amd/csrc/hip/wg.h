@@ -40,6 +40,9 @@
 // with OG_WAVE_VAR outside the regions, use it as OG_WV(name) inside them (the region's lane variable must be `lane`).
 #define OG_WAVE_VAR(T, name) T name
 #define OG_WV(name) name
+// The same for a value that lives across OG_LANES regions (the regions' lane variable must be `tid`).
+#define OG_LANE_VAR(T, name) T name
+#define OG_LV(name) name
 #else
 #include <math.h>
 #define OG_DEV static inline
@@ -58,4 +61,6 @@
 #define OG_WAVE_END } }
 #define OG_WAVE_VAR(T, name) T name[64]
 #define OG_WV(name) name[lane]
+#define OG_LANE_VAR(T, name) T name[OG_WG]
+#define OG_LV(name) name[tid]
 #endif
