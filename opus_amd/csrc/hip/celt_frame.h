@@ -24,13 +24,12 @@ struct alignas(16) OgF4 { float x, y, z, w; };
 #define OG_LDS_OPS 16                 // fill ops staged in LDS per frame (C2 frames carry ~5); the rest stay in HBM
 #endif
 
-// 31.1 KB: five workgroups per CU (LDS is allotted in 1280-byte granules: 25 of them).  Buffers with disjoint lifetimes
-// share storage.  The 16 KB time buffer `out` is [history | frame + IMDCT tail] per channel; while the comb filter is
-// not running, the history parts hold, one after the other, the folding source `norm` (band walk) and the FFT pong
-// buffer, and the frame parts hold the bounce buffer of the band transforms and the IMDCT twiddles.
+// 21.9 KB: seven workgroups per CU (LDS is allotted in 1280-byte granules: 18 of them).  Buffers with disjoint
+// lifetimes share storage: `R` holds the folding source `norm` + the waves' partial sums during the band walk and the
+// FFT pong buffer afterwards; the band-walk tables give way to the FFT twiddles.
 struct alignas(16) OgCeltLds {
-    float X[2][960];                  // coefficients (bands) -> MDCT bins -> FFT ping buffer -> de-emphasised PCM
-    float out[2][OG_OUTLEN];          // per channel: [OG_HIST history | frame | tail]
+    float X[2][960];                  // coefficients (bands) -> MDCT bins -> FFT ping buffer -> samples before the window
+    float R[1920];                    // norm[2][800] | part[4][64]   ->   FFT pong buffer [2][480] complex
     union {
         struct {                      // band-walk lifetime
             uint32_t lcg_a[184], lcg_c[184];                      // noise-seed jump tables (copy of OgCeltTables')
@@ -49,15 +48,12 @@ struct alignas(16) OgCeltLds {
     } w;
     OgCeltConst k;                    // LDS copy of the small constant tables
     float gband[2][24];               // denormalisation gains
-    float window[120];                // TDAC / comb cross-fade window (copy of OgCeltTables')
     OgCeltHdr hdr;                    // the frame's side-info, staged once (uniform control code reads it from LDS)
     float red[4];
 };
-// views into `out` (see above)
-OG_DEV float *og_norm(OgCeltLds &L, int row) { return &L.out[row][0]; }                 // folding source row (800 used)
-OG_DEV float *og_tmp(OgCeltLds &L, int slot) { return &L.out[slot][OG_HIST]; }          // bounce buffer of channel buffer `slot` (960)
-OG_DEV float *og_part(OgCeltLds &L, int w) { return &L.out[w >> 1][800 + 64 * (w & 1)]; }   // wave w's 64 partial sums (band walk)
-#define OG_A_CHS (OG_OUTLEN / 2)      // channel stride of the FFT pong buffer, in complex elements
+// views into R (band-walk lifetime)
+OG_DEV float *og_norm(OgCeltLds &L, int row) { return L.R + 800 * row; }                // folding source row (celt/decoder.rs `norm_mid` / `norm_side`)
+OG_DEV float *og_part(OgCeltLds &L, int w) { return L.R + 1600 + 64 * w; }              // wave w's 64 partial sums
 
 #include "celt_pvq.h"
 
@@ -197,29 +193,43 @@ template <class T> OG_DEV T og_uniform(const T &v) { return v; }
 
 // The transform of one quant_band call: the Haar steps of tf recombination / time-division (celt/decoder.rs:453-466,
 // :1708-1740, :1994-2019) are butterflies on the index bits `hm` (celt_plan.h) and commute; the Hadamard (de)interleave
-// (:472-538) is a permutation.  The pieces below each produce elements first, first + step, ... of the task for the
-// calling lane (a whole wave: first = lane, step = 64, task record in scalar registers; a 16-lane group: first = lane & 15,
-// step = 16); the caller separates them with wave-level fences.  Everything happens in the task's slice of the bounce buffer (og_tmp):
-//   PRE  (lowband copy):  load source -> butterflies -> lb[deinterleave(p)] = scale * tmp[p] (lb: the wave's lowband buffer)
-//   POST (decoded band):  load X[interleave(p)] -> butterflies -> og_task_finish (scale, copy back, lowband_out)
-template <bool PRE>
-OG_DEV void og_xf_load(OgCeltLds &L, const OgTask tk, int slot, int first, int step)
+// (:472-538) is a permutation.  Both run in place -- the permutation through registers (every element is read before
+// any is written; K elements per lane) -- on the decoded band itself (POST: interleave, butterflies, then og_task_finish
+// scales and emits lowband_out) or on the wave's copy of the folding source (PRE: butterflies, then scale + deinterleave).
+// The pieces below each handle elements first, first + step, ... of the task for the calling lane (a whole wave:
+// first = lane, step = 64, K = 3, task record in scalar registers; a 16-lane group: first = lane & 15, step = 16, K = 11);
+// the caller separates them with wave-level fences.
+template <int K> struct OgXr { float v[K]; };
+
+template <int K, bool PRE>
+OG_DEV void og_xf_perm_read(const float *buf, const OgTask tk, float scale, int first, int step, OgXr<K> &r)
 {
     const int n = tk.n, slog = tk.slog, n0p = tk.n0p, had = (tk.flags & OG_T_LONG) != 0;
-    const float *src = PRE ? og_norm(L, (tk.flags & OG_T_LB_ROW1) ? 1 : 0) + tk.lowpos : &L.X[0][0] + slot * 960 + tk.boff;
-    float *tmp = og_tmp(L, slot) + tk.boff;
-    for (int p = first; p < n; p += step) tmp[p] = src[PRE ? p : og_reorder(slog, n0p, had, p)];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const int p = first + k * step;
+        r.v[k] = p < n ? (PRE ? buf[p] * scale : buf[og_reorder(slog, n0p, had, p)]) : 0.f;
+    }
+}
+template <int K, bool PRE>
+OG_DEV void og_xf_perm_write(float *buf, const OgTask tk, int first, int step, const OgXr<K> &r)
+{
+    const int n = tk.n, slog = tk.slog, n0p = tk.n0p, had = (tk.flags & OG_T_LONG) != 0;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const int p = first + k * step;
+        if (p < n) buf[PRE ? og_reorder(slog, n0p, had, p) : p] = r.v[k];
+    }
 }
 
-OG_DEV void og_xf_bfly(OgCeltLds &L, const OgTask tk, int slot, int bit, int first, int step)   // unscaled Haar step on index bit `bit`
+OG_DEV void og_xf_bfly(float *buf, const OgTask tk, int bit, int first, int step)   // unscaled Haar step on index bit `bit`
 {
-    float *tmp = og_tmp(L, slot) + tk.boff;
     const int half = tk.n >> 1, low = (1 << bit) - 1;
     for (int q = first; q < half; q += step) {
         const int i0 = ((q & ~low) << 1) | (q & low), i1 = i0 | (1 << bit);
-        const float a = tmp[i0], c = tmp[i1];
-        tmp[i0] = a + c;
-        tmp[i1] = a - c;
+        const float a = buf[i0], c = buf[i1];
+        buf[i0] = a + c;
+        buf[i1] = a - c;
     }
 }
 
@@ -227,14 +237,6 @@ OG_DEV float og_xf_scale(const OgTask tk)               // 2^(-m/2) for the m bu
 {
     const int m = (tk.rctd & 15) + (tk.rctd >> 4);
     return tk.hm ? (m & 1 ? 0.70710678118654752440f : 1.f) / (float)(1 << (m >> 1)) : 1.f;
-}
-
-OG_DEV void og_xf_store_pre(OgCeltLds &L, const OgTask tk, int slot, float *lb, int first, int step)
-{
-    const int n = tk.n, slog = tk.slog, n0p = tk.n0p, had = (tk.flags & OG_T_LONG) != 0;
-    const float *tmp = og_tmp(L, slot) + tk.boff;
-    const float scale = og_xf_scale(tk);
-    for (int p = first; p < n; p += step) lb[og_reorder(slog, n0p, had, p)] = tmp[p] * scale;
 }
 
 // the s-th butterfly bit of a task, -1 when it has fewer (tf changes are at most 3 steps: celt/decoder.rs:221-226)
@@ -245,39 +247,55 @@ OG_DEV int og_xf_bit(const OgTask tk, int s)
     return hm ? __builtin_ctz(hm) : -1;
 }
 
+// by one wave, inside an OG_WAVES section.  PRE: lb = the wave's lowband buffer, filled from the folding source here.
 template <bool PRE>
-OG_DEV void og_task_xform(OgCeltLds &L, const OgTask tk, int slot, float *lb)     // by one wave, inside an OG_WAVES section
+OG_DEV void og_task_xform(OgCeltLds &L, const OgTask tk, int slot, float *lb)
 {
-    OG_WAVE_BEGIN(lane)
-    og_xf_load<PRE>(L, tk, slot, lane, 64);
-    OG_WAVE_END
+    float *buf = PRE ? lb : &L.X[0][0] + slot * 960 + tk.boff;
+    OG_WAVE_VAR(OgXr<3>, rv);
+    if (PRE) {
+        const float *src = og_norm(L, (tk.flags & OG_T_LB_ROW1) ? 1 : 0) + tk.lowpos;
+        OG_WAVE_BEGIN(lane)
+        for (int p = lane; p < tk.n; p += 64) buf[p] = src[p];
+        OG_WAVE_END
+    } else if (tk.slog) {
+        OG_WAVE_BEGIN(lane)
+        og_xf_perm_read<3, false>(buf, tk, 1.f, lane, 64, OG_WV(rv));
+        OG_WAVE_END
+        OG_WAVE_BEGIN(lane)
+        og_xf_perm_write<3, false>(buf, tk, lane, 64, OG_WV(rv));
+        OG_WAVE_END
+    }
     for (int s = 0; s < 8; s++) {
         const int bit = og_xf_bit(tk, s);
         if (bit < 0) break;
         OG_WAVE_BEGIN(lane)
-        og_xf_bfly(L, tk, slot, bit, lane, 64);
+        og_xf_bfly(buf, tk, bit, lane, 64);
         OG_WAVE_END
     }
     if (PRE) {
+        const float scale = og_xf_scale(tk);
         OG_WAVE_BEGIN(lane)
-        og_xf_store_pre(L, tk, slot, lb, lane, 64);
+        og_xf_perm_read<3, true>(buf, tk, scale, lane, 64, OG_WV(rv));
+        OG_WAVE_END
+        OG_WAVE_BEGIN(lane)
+        og_xf_perm_write<3, true>(buf, tk, lane, 64, OG_WV(rv));
         OG_WAVE_END
     }
 }
 
-// scale + copy-back of a transformed task, and lowband_out = sqrt(N0) * x (celt/decoder.rs:2021-2028)
+// scale of a transformed task (in place), and lowband_out = sqrt(N0) * x (celt/decoder.rs:2021-2028)
 OG_DEV void og_task_finish(OgCeltLds &L, const OgTask tk, int slot, int norm_offset, int first, int step)
 {
-    const bool xf = (tk.hm | tk.slog) != 0;
+    const bool xf = tk.hm != 0;                         // a pure reorder has scale 1
     if (!xf && tk.norm_row == 0xFF) return;
     const int n = tk.n;
     float *x = &L.X[0][0] + slot * 960 + tk.boff;
-    const float *t = og_tmp(L, slot) + tk.boff;
     float *nr = tk.norm_row != 0xFF ? og_norm(L, tk.norm_row) + (tk.boff - norm_offset) : nullptr;
     const float sq = sqrtf((float)n), scale = og_xf_scale(tk);
     for (int p = first; p < n; p += step) {
-        float v;
-        if (xf) { v = t[p] * scale; x[p] = v; } else v = x[p];
+        float v = x[p];
+        if (xf) { v = v * scale; x[p] = v; }
         if (nr) nr[p] = sq * v;
     }
 }
@@ -347,7 +365,7 @@ OG_DEV void og_celt_bands(OgBandCtx &c)
         if (lvl == merge_level) {                       // dual -> intensity switch (celt/decoder.rs:2133-2138)
             const int cnt = PL->merge_cnt;
             OG_LANES_BEGIN(tid)
-            for (int p = tid; p < cnt; p += OG_WG) L.out[0][p] = 0.5f * (L.out[0][p] + L.out[1][p]);
+            for (int p = tid; p < cnt; p += OG_WG) L.R[p] = 0.5f * (L.R[p] + L.R[800 + p]);
             OG_LANES_END
         }
         if (lvl == 0) {
@@ -359,6 +377,7 @@ OG_DEV void og_celt_bands(OgBandCtx &c)
             for (int base = 0; base < t1 - t0; base += 4 * (OG_WG / 64)) {
                 OG_WAVE_VAR(OgTask, tkv);                           // the group's task: fetched once per round
                 OG_WAVE_VAR(int, slotv);
+                OG_WAVE_VAR(OgXr<11>, rv);                          // the in-place reorder's elements in flight
                 OG_WAVE_BEGIN(lane)
                 const int k = base + 4 * w + (lane >> 4);
                 OgTask tk;
@@ -368,15 +387,19 @@ OG_DEV void og_celt_bands(OgBandCtx &c)
                     const int id = PL->order[t1 - 1 - k];
                     tk = tasks[id];
                     slot = id & 1;
-                    if (tk.hm | tk.slog) og_xf_load<false>(L, tk, slot, lane & 15, 16);
+                    if (tk.slog) og_xf_perm_read<11, false>(&L.X[0][0] + slot * 960 + tk.boff, tk, 1.f, lane & 15, 16, OG_WV(rv));
                 }
                 OG_WV(tkv) = tk;
                 OG_WV(slotv) = slot;
                 OG_WAVE_END
+                OG_WAVE_BEGIN(lane)
+                if (OG_WV(tkv).slog)
+                    og_xf_perm_write<11, false>(&L.X[0][0] + OG_WV(slotv) * 960 + OG_WV(tkv).boff, OG_WV(tkv), lane & 15, 16, OG_WV(rv));
+                OG_WAVE_END
                 for (int s = 0; s < maxb; s++) {
                     OG_WAVE_BEGIN(lane)
                     const int bit = og_xf_bit(OG_WV(tkv), s);
-                    if (bit >= 0) og_xf_bfly(L, OG_WV(tkv), OG_WV(slotv), bit, lane & 15, 16);
+                    if (bit >= 0) og_xf_bfly(&L.X[0][0] + OG_WV(slotv) * 960 + OG_WV(tkv).boff, OG_WV(tkv), bit, lane & 15, 16);
                     OG_WAVE_END
                 }
                 OG_WAVE_BEGIN(lane)
@@ -614,10 +637,13 @@ OG_DEV void og_wave_comb_filter(float *y, int T0, int T1, int n, float g0, float
 }
 
 // ------------------------------------------------------------------------------------------------
-// The whole frame.  Uniform arguments; every lane of the workgroup calls it.
-// `dbg` pointers are already offset to this frame (any may be null).
-OG_DEV void og_celt_frame(const OgCeltHdr *hg, const OgBandPlan *plan, const OgCeltTables *T, OgCeltState *states,
-                          float *pcm_base, size_t pcm_stride, OgCeltLds &L, const OgCeltDebug &dbg, float *coef_row)
+// First half of a frame (stateless: any number of frames of a stream can be in flight): band walk, anti-collapse,
+// denormalisation and the IMDCT up to its post-twiddle.  coef_row holds K1's coefficients on entry and the frame's
+// time-domain samples before the TDAC window on exit ([channel][960], N used per channel; row 1 is left alone for
+// mono output).  Uniform arguments; every lane of the workgroup calls it.  `dbg` pointers are already offset to this
+// frame (any may be null).
+OG_DEV void og_celt_spectrum(const OgCeltHdr *hg, const OgBandPlan *plan, const OgCeltTables *T, OgCeltLds &L, const OgCeltDebug &dbg,
+                             float *coef_row)
 {
     float *dbg_norm = dbg.norm, *dbg_freq = dbg.freq;
     uint8_t *dbg_collapse = dbg.collapse;
@@ -637,21 +663,14 @@ OG_DEV void og_celt_frame(const OgCeltHdr *hg, const OgBandPlan *plan, const OgC
     }
     for (int p = tid; p < (int)(sizeof(OgCeltConst) / 4); p += OG_WG) ((uint32_t *)&L.k)[p] = ((const uint32_t *)&T->k)[p];
     for (int p = tid; p < 184; p += OG_WG) { L.w.b.lcg_a[p] = T->lcg_a[p]; L.w.b.lcg_c[p] = T->lcg_c[p]; }
-    for (int p = tid; p < 120; p += OG_WG) L.window[p] = T->window[p];
-    // K1's output for this frame: shaped PVQ coefficients (zero elsewhere).  The scratch row is handed back zero-filled
-    // for the next launch.
-    for (int p = tid; p < 2 * 960 / 4; p += OG_WG) {    // 16 bytes per lane
-        ((OgF4 *)&L.X[0][0])[p] = ((const OgF4 *)coef_row)[p];
-        ((OgF4 *)coef_row)[p] = OgF4{0.f, 0.f, 0.f, 0.f};
-    }
-    for (int p = tid; p < 2 * 800; p += OG_WG) L.out[p >= 800][p >= 800 ? p - 800 : p] = 0.f;
+    // K1's output for this frame: shaped PVQ coefficients (zero elsewhere)
+    for (int p = tid; p < 2 * 960 / 4; p += OG_WG) ((OgF4 *)&L.X[0][0])[p] = ((const OgF4 *)coef_row)[p];      // 16 bytes per lane
+    for (int p = tid; p < 2 * 800; p += OG_WG) L.R[p] = 0.f;
     OG_LANES_END
     const OgCeltHdr *h = &L.hdr;
     const int lm = h->lm, M = 1 << lm, N = 120 << lm;
     const int C = (h->flags & OG_F_STEREO) ? 2 : 1, CC = (h->flags & OG_F_OUT_STEREO) ? 2 : 1;
     const bool transient = (h->flags & OG_F_TRANSIENT) != 0, silence = (h->flags & OG_F_SILENCE) != 0;
-    OgCeltState *st = states + h->stream;
-    const bool reset = (h->flags & OG_F_RESET) != 0;
 
     OG_STAMP(1)
     if (!silence) {
@@ -674,10 +693,13 @@ OG_DEV void og_celt_frame(const OgCeltHdr *hg, const OgBandPlan *plan, const OgC
                                                         // before the twiddles below replace them
 
     // ---- phase 4: denormalise (RFC 6716 4.3.6) + channel up/down-mix into MDCT bins; the first region also stages the
-    //      FFT twiddles and the bin -> band map over the (now dead) band-walk tables, and this block size's IMDCT twiddles
-    //      into the (idle) frame part of channel 0's time buffer
+    //      FFT twiddles and the bin -> band map over the (now dead) band-walk tables and fetches the lane's IMDCT pre / post
+    //      twiddles (the same for both: work item q of either pass has the same bin index) into registers
     const int B = transient ? M : 1, NB = N / B, n4 = NB >> 1;
-    OgCf *ldsW = L.w.t.W, *ldsTw = (OgCf *)&L.out[0][OG_HIST];
+    OgCf *ldsW = L.w.t.W;
+    const float inv_n4 = 1.f / (float)n4;
+    struct OgTw4 { OgCf w[4]; };
+    OG_LANE_VAR(OgTw4, twr);
     OG_LANES_BEGIN(tid)
     for (int t = tid; t < 48; t += OG_WG) {             // per-(channel, band) gains 2^(E + mean), zero outside [start, end)
         const int ch = t >= 24, b = t - 24 * ch;
@@ -690,7 +712,15 @@ OG_DEV void og_celt_frame(const OgCeltHdr *hg, const OgBandPlan *plan, const OgC
     }
     for (int p = tid; p < 960; p += OG_WG) ((float *)ldsW)[p] = ((const float *)T->fft_w)[p];
     for (int p = tid; p < 960 / 4; p += OG_WG) ((uint32_t *)L.w.t.bin2band)[p] = ((const uint32_t *)T->bin2band[lm0])[p];
-    for (int p = tid; p < 2 * n4; p += OG_WG) ((float *)ldsTw)[p] = ((const float *)(T->tw + (n4 - 60)))[p];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int q = tid + j * OG_WG;
+        OG_LV(twr).w[j] = OgCf{0.f, 0.f};
+        if (q < CC * (N >> 1)) {
+            const int ch = q >= (N >> 1), r = q - ch * (N >> 1), b = og_div(r, inv_n4), i = r - b * n4;
+            OG_LV(twr).w[j] = T->tw[(n4 - 60) + i];
+        }
+    }
     OG_LANES_END
     OG_STAMP(9)
     OG_LANES_BEGIN(tid)
@@ -727,31 +757,23 @@ OG_DEV void og_celt_frame(const OgCeltHdr *hg, const OgBandPlan *plan, const OgC
 
     OG_STAMP(5)
     // ---- phase 5 (K3): IMDCT.  B blocks of NB bins, interleaved with stride B in X.  The FFT ping-pongs between the
-    //      history parts of the time buffer (channel stride OG_A_CHS) and X (channel stride 480).
-    const OgCf *tw = ldsTw;
-    const float inv_n4 = 1.f / (float)n4;
-    OgCf *bufA = (OgCf *)&L.out[0][0], *bufB = (OgCf *)&L.X[0][0];
+    //      R and X.
+    OgCf *bufA = (OgCf *)L.R, *bufB = (OgCf *)&L.X[0][0];
     OG_LANES_BEGIN(tid)
-    for (int q = tid; q < CC * (N >> 1); q += OG_WG) {                       // pre-twiddle
-        const int ch = q >= (N >> 1), r = q - ch * (N >> 1), b = og_div(r, inv_n4), i = r - b * n4;
-        const float x1 = L.X[ch][(2 * i) * B + b], x2 = L.X[ch][(NB - 1 - 2 * i) * B + b];
-        const OgCf w = tw[i];
-        OgCf z;
-        z.r = x1 * w.r + x2 * w.i;
-        z.i = x2 * w.r - x1 * w.i;
-        bufA[ch * OG_A_CHS + b * n4 + i] = z;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {                                            // pre-twiddle
+        const int q = tid + j * OG_WG;
+        if (q < CC * (N >> 1)) {
+            const int ch = q >= (N >> 1), r = q - ch * (N >> 1), b = og_div(r, inv_n4), i = r - b * n4;
+            const float x1 = L.X[ch][(2 * i) * B + b], x2 = L.X[ch][(NB - 1 - 2 * i) * B + b];
+            const OgCf w = OG_LV(twr).w[j];
+            OgCf z;
+            z.r = x1 * w.r + x2 * w.i;
+            z.i = x2 * w.r - x1 * w.i;
+            bufA[ch * 480 + b * n4 + i] = z;
+        }
     }
     OG_LANES_END
-    // comb post-filter parameters (RFC 6716 4.3.7.1): sets [0] old, [1] current, [2] new
-    const float pg0 = 0.09375f * h->pf_gain_q[0], pg1 = 0.09375f * h->pf_gain_q[1], pg2 = 0.09375f * h->pf_gain_q[2];
-    const uint32_t pos0 = reset ? 0u : st->pos;
-    const bool pf_on = pg0 != 0.f || pg1 != 0.f || (lm != 0 && pg2 != 0.f);
-    int reach = 0;                                      // history samples the comb filter reads
-    if (pf_on) {
-        for (int k = 0; k < 3; k++) { int t = h->pf_period[k] < 15 ? 15 : h->pf_period[k]; if (t > reach) reach = t; }
-        reach += 2;
-        if (reach > OG_HIST) reach = OG_HIST;
-    }
     {
         int radix[5], ns = 0;                           // 60 * 2^lm = 4 * 4^a * 2^b * 3 * 5
         int rem = n4 / 15;
@@ -761,7 +783,7 @@ OG_DEV void og_celt_frame(const OgCeltHdr *hg, const OgBandPlan *plan, const OgC
         radix[ns++] = 5;
         int Ns = 1;
         OgCf *src = bufA, *dst = bufB;
-        int schs = OG_A_CHS, dchs = 480;
+        int schs = 480, dchs = 480;
         for (int s = 0; s < ns; s++) {
             switch (radix[s]) {
             case 4: og_wg_fft_stage<4>(src, dst, schs, dchs, n4, CC, B, Ns, ldsW); break;
@@ -773,9 +795,8 @@ OG_DEV void og_celt_frame(const OgCeltHdr *hg, const OgBandPlan *plan, const OgC
             OgCf *t = src; src = dst; dst = t;
             const int ts = schs; schs = dchs; dchs = ts;
         }
-        // `src` now holds the spectrum.  Post-twiddle into registers (the twiddles sit where the samples go), then, past
-        // the barrier, into the time buffer; the same region fetches the stream's state: the previous frame's tail and,
-        // into the history part (the FFT is done with it), the samples the comb filter reaches back to.
+        // `src` now holds the spectrum.  Post-twiddle into registers, past the barrier into X in time order (either FFT
+        // buffer may be the source), then out to the frame's scratch row in 16-byte pieces.
         struct OgPost { float r[4], i[4]; };
         OG_LANE_VAR(OgPost, pv);
         OG_LANES_BEGIN(tid)
@@ -785,48 +806,84 @@ OG_DEV void og_celt_frame(const OgCeltHdr *hg, const OgBandPlan *plan, const OgC
             OG_LV(pv).r[j] = OG_LV(pv).i[j] = 0.f;
             if (q < CC * (N >> 1)) {
                 const int ch = q >= (N >> 1), r = q - ch * (N >> 1), b = og_div(r, inv_n4), k = r - b * n4;
-                const OgCf Z = src[ch * schs + b * n4 + k], w = tw[k];
+                const OgCf Z = src[ch * schs + b * n4 + k], w = OG_LV(twr).w[j];
                 OG_LV(pv).r[j] = Z.r * w.r + Z.i * w.i;
                 OG_LV(pv).i[j] = Z.i * w.r - Z.r * w.i;
             }
         }
         OG_LANES_END
         OG_LANES_BEGIN(tid)
-        float hv[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) {                    // CC * reach <= 2048 = 8 per lane
-            const int q = tid + j * OG_WG;
-            hv[j] = 0.f;
-            if (q < CC * reach && !reset) {
-                const int ch = q >= reach, d = q - ch * reach + 1;
-                hv[j] = st->hist[ch][(pos0 - (uint32_t)d) & 1023u];
-            }
-        }
-        float ov = 0.f;
-        if (tid < CC * 60 && !reset) ov = st->overlap[tid >= 60][tid >= 60 ? tid - 60 : tid];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int q = tid + j * OG_WG;
             if (q < CC * (N >> 1)) {
                 const int ch = q >= (N >> 1), r = q - ch * (N >> 1), b = og_div(r, inv_n4), k = r - b * n4;
-                float *D = &L.out[ch][OG_HIST + NB * b + 60];
+                float *D = &L.X[ch][NB * b];
                 D[2 * k] = OG_LV(pv).i[j];
                 D[NB - 1 - 2 * k] = -OG_LV(pv).r[j];
             }
         }
-        if (tid < CC * 60) L.out[tid >= 60][OG_HIST + (tid >= 60 ? tid - 60 : tid)] = ov;    // previous frame's tail
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const int q = tid + j * OG_WG;
-            if (q < CC * reach) {
-                const int ch = q >= reach, d = q - ch * reach + 1;
-                L.out[ch][OG_HIST - d] = hv[j];
-            }
-        }
         OG_LANES_END
     }
+    OG_STAMP(11)
     OG_LANES_BEGIN(tid)
-    for (int q = tid; q < CC * B * 60; q += OG_WG) {                         // TDAC mirror (RFC 6716 mdct.c)
+    for (int q = tid; q < CC * (N >> 2); q += OG_WG) {
+        const int ch = q >= (N >> 2), i = q - ch * (N >> 2);
+        ((OgF4 *)coef_row)[ch * 240 + i] = ((const OgF4 *)&L.X[ch][0])[i];
+    }
+    OG_LANES_END
+    OG_STAMP(13)
+}
+
+// ------------------------------------------------------------------------------------------------
+// Second half of a frame, in stream order: TDAC window + overlap-add (RFC 6716 mdct.c), comb post-filter (4.3.7.1),
+// de-emphasis, PCM and state write-back.  A workgroup of OG_WGT lanes, one wavefront per channel for the recursive
+// parts.  h: the frame's header in global memory (uniform reads).  coef_row: og_celt_spectrum's output; handed back
+// zero-filled (the contract of the scratch rows between launches).
+struct alignas(16) OgTailLds {
+    float out[2][OG_OUTLEN];          // per channel: [OG_HIST history | frame | tail]
+    float window[120];
+    float taps[3][4];
+    float carry[2][64];               // de-emphasis carries
+};
+
+OG_DEV void og_celt_tail(const OgCeltHdr *h, OgCeltState *states, float *pcm_base, size_t pcm_stride, OgTailLds &L,
+                         const OgCeltDebug &dbg, float *coef_row)
+{
+    const int lm = h->lm & 3, M = 1 << lm, N = 120 << lm;
+    const uint32_t flags = h->flags;
+    const int CC = (flags & OG_F_OUT_STEREO) ? 2 : 1;
+    const bool transient = (flags & OG_F_TRANSIENT) != 0, reset = (flags & OG_F_RESET) != 0;
+    const int B = transient ? M : 1, NB = N / B;
+    OgCeltState *st = states + h->stream;
+    // comb post-filter parameters (RFC 6716 4.3.7.1): sets [0] old, [1] current, [2] new
+    const float pg0 = 0.09375f * h->pf_gain_q[0], pg1 = 0.09375f * h->pf_gain_q[1], pg2 = 0.09375f * h->pf_gain_q[2];
+    const uint32_t pos0 = reset ? 0u : st->pos;
+    const bool pf_on = pg0 != 0.f || pg1 != 0.f || (lm != 0 && pg2 != 0.f);
+    int reach = 0;                                      // history samples the comb filter reads
+    if (pf_on) {
+        for (int k = 0; k < 3; k++) { int t = h->pf_period[k] < 15 ? 15 : h->pf_period[k]; if (t > reach) reach = t; }
+        reach += 2;
+        if (reach > OG_HIST) reach = OG_HIST;
+    }
+    OG_STAMP(12)
+    OG_TLANES_BEGIN(tid)
+    for (int q = tid; q < CC * (N >> 2); q += OG_WGT) {                      // the frame, before the window
+        const int ch = q >= (N >> 2), i = q - ch * (N >> 2);
+        *(OgF4 *)&L.out[ch][OG_HIST + 60 + 4 * i] = ((const OgF4 *)coef_row)[ch * 240 + i];
+    }
+    for (int q = tid; q < CC * 60; q += OG_WGT) {                            // previous frame's tail
+        const int ch = q >= 60, i = q - ch * 60;
+        L.out[ch][OG_HIST + i] = reset ? 0.f : st->overlap[ch][i];
+    }
+    for (int q = tid; q < CC * reach; q += OG_WGT) {                         // what the comb filter reaches back to
+        const int ch = q >= reach, d = q - ch * reach + 1;
+        L.out[ch][OG_HIST - d] = reset ? 0.f : st->hist[ch][(pos0 - (uint32_t)d) & 1023u];
+    }
+    OG_TLANES_END
+    OG_TLANES_BEGIN(tid)
+    for (int q = tid; q < 2 * 960 / 4; q += OG_WGT) ((OgF4 *)coef_row)[q] = OgF4{0.f, 0.f, 0.f, 0.f};
+    for (int q = tid; q < CC * B * 60; q += OG_WGT) {                        // TDAC mirror (RFC 6716 mdct.c)
         const int ch = q >= B * 60, r = q - ch * (B * 60), b = og_div(r, 1.f / 60.f), i = r - b * 60;
         float *o = &L.out[ch][OG_HIST + NB * b];
         const float x1 = o[119 - i], x2 = o[i];
@@ -834,94 +891,84 @@ OG_DEV void og_celt_frame(const OgCeltHdr *hg, const OgBandPlan *plan, const OgC
         o[i] = w2 * x2 - w1 * x1;
         o[119 - i] = w1 * x2 + w2 * x1;
     }
-    OG_LANES_END
+    OG_TLANES_END
 
-    OG_STAMP(6)
     OG_STAMP(7)
-    // ---- phases 6b + 7: comb filter, then de-emphasis t[j] = y[j] + 0.85 t[j-1] as a blocked scan (N/15 lanes x 15
-    //      samples: an odd chunk length keeps the lanes' LDS accesses on distinct banks), one wave per channel with no workgroup barrier in between; then coalesced PCM + state write-back
+    // ---- comb filter, state write-back, then de-emphasis t[j] = y[j] + 0.85 t[j-1] in place as a blocked scan (N/15
+    //      lanes x 15 samples: an odd chunk length keeps the lanes' LDS accesses on distinct banks): one wave per channel,
+    //      no workgroup barrier in between
     const float coef = 0.85000610f;
     const int Lc = 15, nl = N / Lc;                     // 8 << lm lanes
-    float *tbuf = &L.X[0][0];                           // [2][960], free since the FFT finished... (bufB may hold
-                                                        // the spectrum when the stage count is odd; it was consumed above)
     float aL = 1.f;
     for (int j = 0; j < Lc; j++) aL *= coef;            // coef^Lc
-    OG_WAVES_BEGIN(w)
+    OG_TWAVES_BEGIN(w)
     if (w < CC) {
         const int ch = w;
         float *y0 = &L.out[ch][OG_HIST];
         if (pf_on) {
-            og_wave_comb_filter(y0, h->pf_period[0], h->pf_period[1], 120, pg0, pg1, h->pf_tapset[0], h->pf_tapset[1], L.window, L.k.pf_taps);
+            og_wave_comb_filter(y0, h->pf_period[0], h->pf_period[1], 120, pg0, pg1, h->pf_tapset[0], h->pf_tapset[1], L.window, L.taps);
             if (lm != 0)
                 og_wave_comb_filter(y0 + 120, h->pf_period[1], h->pf_period[2], N - 120, pg1, pg2, h->pf_tapset[1], h->pf_tapset[2],
-                                    L.window, L.k.pf_taps);
+                                    L.window, L.taps);
         }
         if (w == 0) OG_STAMP(20)
         OG_WAVE_BEGIN(l)
+        // history ring (post-filtered, before de-emphasis): pos0 and N are multiples of 8, so groups of four samples
+        // never straddle the wrap; then the IMDCT tail for the next frame's overlap-add
+        for (int i = 4 * l; i < N; i += 256) *(OgF4 *)&st->hist[ch][(pos0 + (uint32_t)i) & 1023u] = *(const OgF4 *)&y0[i];
+        if (l < 15) *(OgF4 *)&st->overlap[ch][4 * l] = *(const OgF4 *)&y0[N + 4 * l];
+        if (reset)                                      // forget the ring's older samples
+            for (int i = N + 4 * l; i < 1024; i += 256) *(OgF4 *)&st->hist[ch][i] = OgF4{0.f, 0.f, 0.f, 0.f};
         if (l < nl) {
             const float *y = y0 + l * Lc;
             float m = 0.f, t = 0.f;
             for (int j = 0; j < Lc; j++) { t = y[j] + m; m = coef * t; }
-            L.w.t.carry[ch][l] = m;                         // chunk's own contribution to the running memory
+            L.carry[ch][l] = m;                         // chunk's own contribution to the running memory
         }
         OG_WAVE_END
         // carry-in of chunk l = sum over earlier chunks q of carry[q] * coef^(Lc*(l-1-q)) (+ the stream's memory); terms
-        // more than `reach` chunks back are below 1e-9 of their chunk's value and are dropped
-        const int reach = 128 / Lc + 1;
+        // more than `back` chunks back are below 1e-9 of their chunk's value and are dropped
+        const int back = 128 / Lc + 1;
         OG_WAVE_BEGIN(l)
         if (l < nl) {
-            const int q0 = l > reach ? l - reach : 0;
+            const int q0 = l > back ? l - back : 0;
             float m = (reset || q0 > 0) ? 0.f : st->deemph[ch];
-            for (int q = q0; q < l; q++) m = m * aL + L.w.t.carry[ch][q];
-            const float *y = y0 + l * Lc;
-            float *t = tbuf + ch * 960 + l * Lc;
-            for (int j = 0; j < Lc; j++) { const float v = y[j] + m; m = coef * v; t[j] = v; }
+            for (int q = q0; q < l; q++) m = m * aL + L.carry[ch][q];
+            float *y = y0 + l * Lc;
+            for (int j = 0; j < Lc; j++) { const float v = y[j] + m; m = coef * v; y[j] = v; }
             if (l == nl - 1) st->deemph[ch] = m;
         }
         OG_WAVE_END
     }
-    OG_WAVES_END
+    OG_TWAVES_END
     OG_STAMP(21)
     float *pcm = pcm_base + (size_t)h->stream * pcm_stride + (size_t)h->pcm_off * CC;
-    const bool accum = (h->flags & OG_F_ACCUM) != 0;
+    const bool accum = (flags & OG_F_ACCUM) != 0;
     const bool vec = (((uintptr_t)pcm) & 15) == 0;      // 16-byte stores when the caller's row allows it
-    OG_LANES_BEGIN(tid)
+    const float *t0 = &L.out[0][OG_HIST], *t1 = &L.out[1][OG_HIST];
+    OG_TLANES_BEGIN(tid)
     if (vec) {
         const float k = 1.f / 32768.f;
-        for (int q = tid; q < N * CC / 4; q += OG_WG) {
+        for (int q = tid; q < N * CC / 4; q += OG_WGT) {
             OgF4 v;
             if (CC == 2) {                              // two stereo samples
                 const int j = 2 * q;
-                v = OgF4{tbuf[j] * k, tbuf[960 + j] * k, tbuf[j + 1] * k, tbuf[960 + j + 1] * k};
+                v = OgF4{t0[j] * k, t1[j] * k, t0[j + 1] * k, t1[j + 1] * k};
             } else {
-                const OgF4 u = ((const OgF4 *)tbuf)[q];
+                const OgF4 u = ((const OgF4 *)t0)[q];
                 v = OgF4{u.x * k, u.y * k, u.z * k, u.w * k};
             }
             if (accum) { const OgF4 o = ((const OgF4 *)pcm)[q]; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
             ((OgF4 *)pcm)[q] = v;
         }
     } else {
-        for (int q = tid; q < N * CC; q += OG_WG) {
+        for (int q = tid; q < N * CC; q += OG_WGT) {
             const int j = CC == 2 ? q >> 1 : q, ch = CC == 2 ? q & 1 : 0;
-            const float v = tbuf[ch * 960 + j] * (1.f / 32768.f);
+            const float v = (ch ? t1 : t0)[j] * (1.f / 32768.f);
             pcm[q] = accum ? pcm[q] + v : v;
         }
     }
-    // history ring: pos0 and N are multiples of 8, so groups of four samples never straddle the wrap
-    for (int q = tid; q < CC * (N >> 2); q += OG_WG) {
-        const int ch = q >= (N >> 2), i = 4 * (q - ch * (N >> 2));
-        *(OgF4 *)&st->hist[ch][(pos0 + (uint32_t)i) & 1023u] = *(const OgF4 *)&L.out[ch][OG_HIST + i];
-    }
-    for (int q = tid; q < CC * 15; q += OG_WG) {
-        const int ch = q >= 15, i = 4 * (q - ch * 15);
-        *(OgF4 *)&st->overlap[ch][i] = *(const OgF4 *)&L.out[ch][OG_HIST + N + i];
-    }
-    if (reset)                                          // forget the ring's older samples
-        for (int q = tid; q < CC * ((1024 - N) >> 2); q += OG_WG) {
-            const int ch = q >= ((1024 - N) >> 2), i = 4 * (q - ch * ((1024 - N) >> 2));
-            *(OgF4 *)&st->hist[ch][N + i] = OgF4{0.f, 0.f, 0.f, 0.f};
-        }
     if (tid == 0) st->pos = pos0 + (uint32_t)N;
-    OG_LANES_END
+    OG_TLANES_END
     OG_STAMP(8)
 }

@@ -5,6 +5,7 @@
 #ifndef OG_WG
 #define OG_WG 256                     // 4 wavefronts per frame
 #endif
+#define OG_WGT 128                    // tail kernel: one wavefront per channel
 #define OG_HIST 1024                  // comb filter reaches back period + 2 <= 1024 samples
 #define OG_OUTLEN 2048                // per channel: OG_HIST history + 960 frame + 60 tail (+ 4)
 #define OG_MAXLEAF 704                // 21 bands x 2 channels x 16 partitions, rounded up

@@ -51,24 +51,42 @@ __global__ __launch_bounds__(64) void og_plan_kernel(const OgCeltHdr *__restrict
         og_plan_frame((const OgCeltHdr *)hs + threadIdx.x, leaves, f, K, la, lc, work, OgLaneScratch{sc + threadIdx.x, OG_PLAN_FPW});
 }
 
-__global__ __launch_bounds__(OG_WG) __attribute__((amdgpu_waves_per_eu(5, 5))) void og_celt_kernel(const OgCeltHdr *__restrict__ hdr, uint32_t nframes, uint32_t frames_per_group,
-                                                           const OgCeltTables *__restrict__ T, void *work, OgCeltState *state,
-                                                           float *pcm, size_t pcm_stride, OgCeltDebug dbg)
+// Frame kernels.  og_celt_kernel: one 256-lane workgroup per frame, stateless (band walk .. IMDCT post-twiddle), five
+// workgroups per CU (31 KB of LDS, 96 VGPRs).  og_celt_tail_kernel: one 128-lane workgroup per group of
+// frames_per_group consecutive records (a stream's frames in time order), which it walks in order carrying the stream's
+// state: window + overlap-add, comb filter, de-emphasis, PCM.
+__global__ __launch_bounds__(OG_WG) __attribute__((amdgpu_waves_per_eu(7, 7))) void og_celt_kernel(const OgCeltHdr *__restrict__ hdr, uint32_t nframes,
+                                                                                                   const OgCeltTables *__restrict__ T, void *work,
+                                                                                                   OgCeltDebug dbg)
 {
     __shared__ OgCeltLds L;
+    const uint32_t f = blockIdx.x;
+    if (f >= nframes) return;
+    OgCeltDebug d;
+    d.pulses = nullptr;
+    d.norm = dbg.norm ? dbg.norm + (size_t)f * 1920 : nullptr;
+    d.freq = dbg.freq ? dbg.freq + (size_t)f * 1920 : nullptr;
+    d.collapse = dbg.collapse ? dbg.collapse + (size_t)f * 42 : nullptr;
+    d.cycles = dbg.cycles ? dbg.cycles + (size_t)f * 64 : nullptr;
+    og_celt_spectrum(hdr + f, og_work_plan(work, f), T, L, d, og_work_coef(work, f));
+}
+
+__global__ __launch_bounds__(OG_WGT) void og_celt_tail_kernel(const OgCeltHdr *__restrict__ hdr, uint32_t nframes, uint32_t frames_per_group,
+                                                              const OgCeltTables *__restrict__ T, void *work, OgCeltState *state, float *pcm,
+                                                              size_t pcm_stride, OgCeltDebug dbg)
+{
+    __shared__ OgTailLds L;
+    for (int p = threadIdx.x; p < 120; p += OG_WGT) L.window[p] = T->window[p];
+    if (threadIdx.x < 12) (&L.taps[0][0])[threadIdx.x] = (&T->k.pf_taps[0][0])[threadIdx.x];
+    __syncthreads();
     const uint32_t f0 = blockIdx.x * frames_per_group;
     for (uint32_t t = 0; t < frames_per_group; t++) {
         const uint32_t f = f0 + t;
         if (f >= nframes) break;
-        OgCeltDebug d;
-        d.pulses = nullptr;
-        d.norm = dbg.norm ? dbg.norm + (size_t)f * 1920 : nullptr;
-        d.freq = dbg.freq ? dbg.freq + (size_t)f * 1920 : nullptr;
-        d.collapse = dbg.collapse ? dbg.collapse + (size_t)f * 42 : nullptr;
+        OgCeltDebug d = {nullptr, nullptr, nullptr, nullptr, nullptr};
         d.cycles = dbg.cycles ? dbg.cycles + (size_t)f * 64 : nullptr;
-        og_celt_frame(hdr + f, og_work_plan(work, f), T, state, pcm, pcm_stride, L, d, og_work_coef(work, f));
-        __syncthreads();                                // frame t's state stores before frame t+1's loads
-    }
+        og_celt_tail(hdr + f, state, pcm, pcm_stride, L, d, og_work_coef(work, f));      // ends in a barrier: frame t's state
+    }                                                                                   // stores precede frame t + 1's loads
 }
 
 namespace og {
@@ -213,7 +231,8 @@ int opusgpu_launch_celt_frames(const OgCeltHdr *hdr, uint32_t nframes, uint32_t 
     OgCeltDebug dbg = {nullptr, nullptr, nullptr, nullptr, nullptr};
     if (debug) dbg = *debug;
     const uint32_t groups = (nframes + frames_per_group - 1) / frames_per_group;
-    hipLaunchKernelGGL(og_celt_kernel, dim3(groups), dim3(OG_WG), 0, (hipStream_t)stream, hdr, nframes, frames_per_group, T, work,
+    hipLaunchKernelGGL(og_celt_kernel, dim3(nframes), dim3(OG_WG), 0, (hipStream_t)stream, hdr, nframes, T, work, dbg);
+    hipLaunchKernelGGL(og_celt_tail_kernel, dim3(groups), dim3(OG_WGT), 0, (hipStream_t)stream, hdr, nframes, frames_per_group, T, work,
                        state, pcm, pcm_stride_floats, dbg);
     OG_HIP(hipGetLastError());
     return OPUSGPU_OK;

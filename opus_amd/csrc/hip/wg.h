@@ -19,6 +19,11 @@
 #define OG_LANES_BEGIN(tid) { const int tid = (int)threadIdx.x; {
 #define OG_LANES_END } } __syncthreads();
 #define OG_ATOMIC_OR(p, v) atomicOr((p), (v))
+// the same for the kernels that run OG_WGT-lane workgroups (the CELT tail kernel)
+#define OG_TLANES_BEGIN(tid) { const int tid = (int)threadIdx.x; {
+#define OG_TLANES_END } } __syncthreads();
+#define OG_TWAVES_BEGIN(w) { const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); {
+#define OG_TWAVES_END } } __syncthreads();
 #define OG_LANES_BEGIN_NOSYNC(tid) { const int tid = (int)threadIdx.x; {
 #define OG_LANES_END_NOSYNC } }           /* regions that touch disjoint data; an explicit OG_BARRIER follows the batch */
 // Wavefront-granular sections.  Short dependent chains (a handful of <= 176-element vector steps) cost a full
@@ -50,6 +55,10 @@
 #define OG_LANES_BEGIN(tid) for (int tid = 0; tid < OG_WG; tid++) { {
 #define OG_LANES_END } }
 #define OG_ATOMIC_OR(p, v) (*(p) |= (v))
+#define OG_TLANES_BEGIN(tid) for (int tid = 0; tid < OG_WGT; tid++) { {
+#define OG_TLANES_END } }
+#define OG_TWAVES_BEGIN(w) for (int w = 0; w < OG_WGT / 64; w++) { {
+#define OG_TWAVES_END } }
 #define OG_LANES_BEGIN_NOSYNC(tid) for (int tid = 0; tid < OG_WG; tid++) { {
 #define OG_LANES_END_NOSYNC } }
 #define OG_WAVES_BEGIN(w) for (int w = 0; w < OG_WG / 64; w++) { {

@@ -13,6 +13,7 @@ extern "C" int emu_launch_celt(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, u
     static bool init = false;
     if (!init) { og_fill_celt_tables(&T); init = true; }
     static OgCeltLds L;
+    static OgTailLds Lt;
     (void)frames_per_group;
     // K1: every PVQ leaf of every frame (order is irrelevant to the result), the band plans, then K2+K3 frame by frame
     std::vector<float> work(OG_WORK_BYTES(nframes) / 4 + 4, 0.f);
@@ -36,11 +37,19 @@ extern "C" int emu_launch_celt(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, u
             d.freq = dbg->freq ? dbg->freq + (size_t)f * 1920 : nullptr;
             d.collapse = dbg->collapse ? dbg->collapse + (size_t)f * 42 : nullptr;
         }
-        og_celt_frame(hdr + f, og_work_plan(work.data(), f), &T, state, pcm, pcm_stride, L, d, og_work_coef(work.data(), f));
+        og_celt_spectrum(hdr + f, og_work_plan(work.data(), f), &T, L, d, og_work_coef(work.data(), f));
+    }
+    std::memset(&Lt, 0xA5, sizeof Lt);
+    std::memcpy(Lt.window, T.window, sizeof Lt.window);
+    std::memcpy(Lt.taps, T.k.pf_taps, sizeof Lt.taps);
+    for (uint32_t f = 0; f < nframes; f++) {            // the tail kernel: frames in order
+        OgCeltDebug d = {nullptr, nullptr, nullptr, nullptr, nullptr};
+        og_celt_tail(hdr + f, state, pcm, pcm_stride, Lt, d, og_work_coef(work.data(), f));
     }
     return 0;
 }
 extern "C" size_t emu_lds_bytes(void) { return sizeof(OgCeltLds); }
+extern "C" size_t emu_tail_lds_bytes(void) { return sizeof(OgTailLds); }
 
 // Diagnostic: band-plan statistics of one frame (K1 collapse masks are not needed for levels / op counts).
 extern "C" void emu_plan_stats(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, uint32_t f, int32_t out[8])

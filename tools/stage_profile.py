@@ -22,8 +22,8 @@ parser = BatchDecoder(S, 2, 0)
 cl = CeltLaunch(S)
 state = torch.zeros(S * C.sizeof(A.CeltState), dtype=torch.uint8, device=dev)
 pcm = torch.zeros(S * 1920, dtype=torch.float32, device=dev)
-names = ["init", "pvq", "bands", "anticollapse", "denorm", "imdct", "pf-history", "comb+deemph+store"]
-tot = np.zeros(8)
+names = ["init", "pvq", "bands", "anticollapse", "denorm", "imdct", "row store", "| tail: load+tdac", "comb", "state+deemph", "pcm"]
+tot = np.zeros(11)
 for f in range(NF):
     assert not any(parser.send([pk[s, f].tobytes() for s in range(S)]))
     celt, leaves, _ = parser.sideinfo()
@@ -35,7 +35,10 @@ for f in range(NF):
     torch.cuda.synchronize()
     c = cyc.cpu().numpy()
     if f >= 1:
-        d = np.diff(c[:, :9], axis=1).astype(np.float64)
+        # og_celt_kernel stamps 0..5, 11, 13; og_celt_tail_kernel stamps 12, 7, 20, 21, 8 (another kernel: its own time base)
+        da = np.diff(c[:, [0, 1, 2, 3, 4, 5, 11, 13]], axis=1).astype(np.float64)
+        dt = np.diff(c[:, [12, 7, 20, 21, 8]], axis=1).astype(np.float64)
+        d = np.concatenate([da, dt], axis=1)
         # stamps 2/3 are skipped on silent frames; ignore rows with non-monotonic stamps
         ok = (d >= 0).all(axis=1)
         tot += d[ok].mean(axis=0)
@@ -47,11 +50,12 @@ for f in range(NF):
         td = np.diff(tail, axis=1).astype(np.float64)
         okt = ok & (td >= 0).all(axis=1) & (c[:, 20] > 0)
         tail_tot = tail_tot + td[okt].mean(axis=0) if "tail_tot" in dir() else td[okt].mean(axis=0)
-        span = c[:, 8].max() - c[:, 0].min()
+        span = c[:, 13].max() - c[:, 0].min()
+        span_t = c[:, 8].max() - c[:, 12].min()
         print("denorm apply region clk", (c[:, 10] - c[:, 9]).mean())
 for n, v in zip(names, tot / (NF - 1)):
     print(f"{n:14s} {v:12.0f} clk  {100 * v / tot.sum() * (NF - 1):5.1f}%")
-print("mean per-frame total", tot.sum() / (NF - 1), "clk; launch span (last frame)", span, "clk")
+print("mean per-frame total", tot.sum() / (NF - 1), "clk; launch spans (last frame): spectrum kernel", span, "clk, tail kernel", span_t, "clk")
 print("tail (comb filter, de-emphasis, PCM + state stores) mean clk:", " ".join(f"{v:.0f}" for v in tail_tot / (NF - 1)))
 print("band phase (-, level 0, fill levels, merges) mean clk:", " ".join(f"{v:.0f}" for v in band_tot / (NF - 1)))
 k1 = cyc_all[S * 64:].view(177, 4096, 4).cpu().numpy()
