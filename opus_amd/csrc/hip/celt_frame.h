@@ -845,11 +845,28 @@ struct alignas(16) OgTailLds {
     float window[120];
     float taps[3][4];
     float carry[2][64];               // de-emphasis carries
+    float dm[2];                      // the stream's de-emphasis memory at frame entry
+    float pad_[2];
 };
 
-OG_DEV void og_celt_tail(const OgCeltHdr *h, OgCeltState *states, float *pcm_base, size_t pcm_stride, OgTailLds &L,
-                         const OgCeltDebug &dbg, float *coef_row)
+// the head of OgCeltHdr (everything up to the band arrays): what the tail needs, fetched in one go
+struct OgHdrHead {
+    uint32_t stream, pcm_off, leaf_begin, seed;
+    uint16_t nleaves;
+    uint8_t lm, flags, start, end, spread, intensity;
+    uint16_t pf_period[3];
+    uint8_t pf_gain_q[3], pf_tapset[3];
+};
+static_assert(sizeof(OgHdrHead) == 36 && offsetof(OgCeltHdr, pf_tapset) == offsetof(OgHdrHead, pf_tapset) &&
+              offsetof(OgCeltHdr, flags) == offsetof(OgHdrHead, flags), "OgHdrHead mirrors the start of OgCeltHdr");
+
+struct OgTailCarry { uint32_t stream, pos; int valid; };    // the ring position of the stream the previous frame belonged to
+
+OG_DEV void og_celt_tail(const OgCeltHdr *hg, OgCeltState *states, float *pcm_base, size_t pcm_stride, OgTailLds &L,
+                         const OgCeltDebug &dbg, float *coef_row, OgTailCarry &carry)
 {
+    const OgHdrHead hd = og_uniform(*(const OgHdrHead *)hg);
+    const OgHdrHead *h = &hd;
     const int lm = h->lm & 3, M = 1 << lm, N = 120 << lm;
     const uint32_t flags = h->flags;
     const int CC = (flags & OG_F_OUT_STEREO) ? 2 : 1;
@@ -858,7 +875,8 @@ OG_DEV void og_celt_tail(const OgCeltHdr *h, OgCeltState *states, float *pcm_bas
     OgCeltState *st = states + h->stream;
     // comb post-filter parameters (RFC 6716 4.3.7.1): sets [0] old, [1] current, [2] new
     const float pg0 = 0.09375f * h->pf_gain_q[0], pg1 = 0.09375f * h->pf_gain_q[1], pg2 = 0.09375f * h->pf_gain_q[2];
-    const uint32_t pos0 = reset ? 0u : st->pos;
+    const uint32_t pos0 = reset ? 0u : (carry.valid && carry.stream == h->stream) ? carry.pos : OG_U32(st->pos);
+    carry.stream = h->stream; carry.pos = pos0 + (uint32_t)N; carry.valid = 1;
     const bool pf_on = pg0 != 0.f || pg1 != 0.f || (lm != 0 && pg2 != 0.f);
     int reach = 0;                                      // history samples the comb filter reads
     if (pf_on) {
@@ -866,20 +884,50 @@ OG_DEV void og_celt_tail(const OgCeltHdr *h, OgCeltState *states, float *pcm_bas
         reach += 2;
         if (reach > OG_HIST) reach = OG_HIST;
     }
+    const int hgroups = (reach + 3) >> 2;               // the history is fetched in aligned groups of four samples
     OG_STAMP(12)
     OG_TLANES_BEGIN(tid)
-    for (int q = tid; q < CC * (N >> 2); q += OG_WGT) {                      // the frame, before the window
-        const int ch = q >= (N >> 2), i = q - ch * (N >> 2);
-        *(OgF4 *)&L.out[ch][OG_HIST + 60 + 4 * i] = ((const OgF4 *)coef_row)[ch * 240 + i];
+    // all of the frame's loads first (independent: their latencies overlap), then the LDS stores
+    OgF4 rv[4], hv[4];
+    float ov = 0.f, dm = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {                       // the frame, before the window: CC * N / 4 <= 480 pieces
+        const int q = tid + j * OG_WGT;
+        rv[j] = OgF4{0.f, 0.f, 0.f, 0.f};
+        if (q < CC * (N >> 2)) {
+            const int ch = q >= (N >> 2), i = q - ch * (N >> 2);
+            rv[j] = ((const OgF4 *)coef_row)[ch * 240 + i];
+        }
     }
-    for (int q = tid; q < CC * 60; q += OG_WGT) {                            // previous frame's tail
-        const int ch = q >= 60, i = q - ch * 60;
-        L.out[ch][OG_HIST + i] = reset ? 0.f : st->overlap[ch][i];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {                       // what the comb filter reaches back to: CC * hgroups <= 512 pieces
+        const int q = tid + j * OG_WGT;
+        hv[j] = OgF4{0.f, 0.f, 0.f, 0.f};
+        if (q < CC * hgroups && !reset) {
+            const int ch = q >= hgroups, g = q - ch * hgroups;
+            hv[j] = *(const OgF4 *)&st->hist[ch][(pos0 - 4u * (uint32_t)(g + 1)) & 1023u];     // pos0 is a multiple of 8
+        }
     }
-    for (int q = tid; q < CC * reach; q += OG_WGT) {                         // what the comb filter reaches back to
-        const int ch = q >= reach, d = q - ch * reach + 1;
-        L.out[ch][OG_HIST - d] = reset ? 0.f : st->hist[ch][(pos0 - (uint32_t)d) & 1023u];
+    if (tid < CC * 60 && !reset) ov = st->overlap[tid >= 60][tid >= 60 ? tid - 60 : tid];      // previous frame's tail
+    if (tid < CC && !reset) dm = st->deemph[tid];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int q = tid + j * OG_WGT;
+        if (q < CC * (N >> 2)) {
+            const int ch = q >= (N >> 2), i = q - ch * (N >> 2);
+            *(OgF4 *)&L.out[ch][OG_HIST + 60 + 4 * i] = rv[j];
+        }
     }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int q = tid + j * OG_WGT;
+        if (q < CC * hgroups) {
+            const int ch = q >= hgroups, g = q - ch * hgroups;
+            *(OgF4 *)&L.out[ch][OG_HIST - 4 * (g + 1)] = hv[j];
+        }
+    }
+    if (tid < CC * 60) L.out[tid >= 60][OG_HIST + (tid >= 60 ? tid - 60 : tid)] = ov;
+    if (tid < CC) L.dm[tid] = dm;
     OG_TLANES_END
     OG_TLANES_BEGIN(tid)
     for (int q = tid; q < 2 * 960 / 4; q += OG_WGT) ((OgF4 *)coef_row)[q] = OgF4{0.f, 0.f, 0.f, 0.f};
@@ -932,7 +980,7 @@ OG_DEV void og_celt_tail(const OgCeltHdr *h, OgCeltState *states, float *pcm_bas
         OG_WAVE_BEGIN(l)
         if (l < nl) {
             const int q0 = l > back ? l - back : 0;
-            float m = (reset || q0 > 0) ? 0.f : st->deemph[ch];
+            float m = q0 > 0 ? 0.f : L.dm[ch];          // the stream's de-emphasis memory (0 after a reset)
             for (int q = q0; q < l; q++) m = m * aL + L.carry[ch][q];
             float *y = y0 + l * Lc;
             for (int j = 0; j < Lc; j++) { const float v = y[j] + m; m = coef * v; y[j] = v; }

@@ -42,9 +42,10 @@ extern "C" int emu_launch_celt(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, u
     std::memset(&Lt, 0xA5, sizeof Lt);
     std::memcpy(Lt.window, T.window, sizeof Lt.window);
     std::memcpy(Lt.taps, T.k.pf_taps, sizeof Lt.taps);
+    OgTailCarry carry = {0, 0, 0};
     for (uint32_t f = 0; f < nframes; f++) {            // the tail kernel: frames in order
         OgCeltDebug d = {nullptr, nullptr, nullptr, nullptr, nullptr};
-        og_celt_tail(hdr + f, state, pcm, pcm_stride, Lt, d, og_work_coef(work.data(), f));
+        og_celt_tail(hdr + f, state, pcm, pcm_stride, Lt, d, og_work_coef(work.data(), f), carry);
     }
     return 0;
 }
