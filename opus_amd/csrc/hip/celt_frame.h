@@ -24,15 +24,14 @@ struct alignas(16) OgF4 { float x, y, z, w; };
 #define OG_LDS_OPS 16                 // fill ops staged in LDS per frame (C2 frames carry ~5); the rest stay in HBM
 #endif
 
-// 21.9 KB: seven workgroups per CU (LDS is allotted in 1280-byte granules: 18 of them).  Buffers with disjoint
+// 20.4 KB: eight workgroups per CU (LDS is allotted in 1280-byte granules: 16 of them).  Buffers with disjoint
 // lifetimes share storage: `R` holds the folding source `norm` + the waves' partial sums during the band walk and the
 // FFT pong buffer afterwards; the band-walk tables give way to the FFT twiddles.
 struct alignas(16) OgCeltLds {
     float X[2][960];                  // coefficients (bands) -> MDCT bins -> FFT ping buffer -> samples before the window
-    float R[1920];                    // norm[2][800] | part[4][64]   ->   FFT pong buffer [2][480] complex
+    float R[1920];                    // norm[2][800] | part[4][64]   ->   bin -> band map (denormalisation)   ->   FFT pong buffer [2][480] complex
     union {
         struct {                      // band-walk lifetime
-            uint32_t lcg_a[184], lcg_c[184];                      // noise-seed jump tables (copy of OgCeltTables')
             alignas(16) uint32_t plan_head[OG_PLAN_HEAD_BYTES / 4];   // OgBandPlan up to (not including) .op
             OgFillOp ops[OG_LDS_OPS];
             union {
@@ -42,14 +41,11 @@ struct alignas(16) OgCeltLds {
         } b;
         struct {                      // from denormalisation on
             OgCf W[480];              // FFT twiddles
-            uint8_t bin2band[960];
-            float carry[2][64];       // de-emphasis carries
         } t;
     } w;
-    OgCeltConst k;                    // LDS copy of the small constant tables
+    struct { float emeans[24]; uint8_t ebands[24], width[24]; } k;   // LDS copy of the small constant tables it indexes
     float gband[2][24];               // denormalisation gains
     OgCeltHdr hdr;                    // the frame's side-info, staged once (uniform control code reads it from LDS)
-    float red[4];
 };
 // views into R (band-walk lifetime)
 OG_DEV float *og_norm(OgCeltLds &L, int row) { return L.R + 800 * row; }                // folding source row (celt/decoder.rs `norm_mid` / `norm_side`)
@@ -300,6 +296,26 @@ OG_DEV void og_task_finish(OgCeltLds &L, const OgTask tk, int slot, int norm_off
     }
 }
 
+// The noise generator (celt/decoder.rs:1595-1599, seed' = 1664525 seed + 1013904223) advanced j < 256 steps at once: the
+// 2^k-step maps seed -> a_k seed + c_k (compile-time constants) applied for the set bits of j.  Integer arithmetic mod
+// 2^32: the same value as j single steps.
+struct OgLcgPow { uint32_t a[8], c[8]; };
+constexpr OgLcgPow og_lcg_pows()
+{
+    OgLcgPow p = {};
+    p.a[0] = 1664525u; p.c[0] = 1013904223u;
+    for (int k = 0; k + 1 < 8; k++) { p.a[k + 1] = p.a[k] * p.a[k]; p.c[k + 1] = p.c[k] * (p.a[k] + 1u); }
+    return p;
+}
+OG_DEV uint32_t og_lcg_jump(uint32_t j, uint32_t s)
+{
+    constexpr OgLcgPow P = og_lcg_pows();
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+        if ((j >> k) & 1u) s = P.a[k] * s + P.c[k];
+    return s;
+}
+
 // One live fill leaf (celt/decoder.rs:1633-1661 + renormalize_vector :788-794), by wave w alone: n <= 176, at most
 // three coefficients per lane, no workgroup barrier.  Ops of one level touch disjoint coefficients.
 OG_DEV void og_fill_op(OgBandCtx &c, int k, int w, int task_pos)     // task_pos: slot * 960 + first bin of the op's task
@@ -308,14 +324,13 @@ OG_DEV void og_fill_op(OgBandCtx &c, int k, int w, int task_pos)     // task_pos
     const OgFillOp op = k < OG_LDS_OPS ? og_uniform(L.w.b.ops[k]) : og_uniform(c.plan->op[k]);
     float *xl = &L.X[0][0] + op.pos, *part = og_part(L, w);
     const float *lbl = L.w.b.s.lb[w] + ((int)op.pos - task_pos);
-    const uint32_t *la = L.w.b.lcg_a, *lc = L.w.b.lcg_c;
     const int nn = op.n;
     const uint32_t s0 = op.seed;
     if (!(op.flags & OG_OP_FOLD)) {                     // noise (celt/decoder.rs:1644-1651)
         OG_WAVE_BEGIN(lane)
         float e = 0.f;
         for (int p = lane; p < nn; p += 64) {
-            uint32_t s = la[p + 1] * s0 + lc[p + 1];
+            uint32_t s = og_lcg_jump((uint32_t)p + 1u, s0);
             const float v = (float)((int32_t)s >> 20);
             xl[p] = v;
             e += v * v;
@@ -326,7 +341,7 @@ OG_DEV void og_fill_op(OgBandCtx &c, int k, int w, int task_pos)     // task_pos
         OG_WAVE_BEGIN(lane)
         float e = 0.f;
         for (int p = lane; p < nn; p += 64) {
-            uint32_t s = la[p + 1] * s0 + lc[p + 1];
+            uint32_t s = og_lcg_jump((uint32_t)p + 1u, s0);
             const float v = lbl[p] + ((s & 0x8000) ? 1.f / 256 : -1.f / 256);
             xl[p] = v;
             e += v * v;
@@ -500,7 +515,6 @@ OG_DEV void og_anti_collapse(OgBandCtx &c)
     const OgCeltHdr *h = c.h;
     OgCeltLds &L = *c.L;
     const int lm = c.lm, C = (h->flags & OG_F_STEREO) ? 2 : 1;
-    const uint32_t *la = c.L->w.b.lcg_a, *lc = c.L->w.b.lcg_c;
     for (int i = h->start; i < h->end; i++) {
         const int n0 = L.k.width[i];
         const int depth = h->pulses_depth[i];
@@ -521,11 +535,11 @@ OG_DEV void og_anti_collapse(OgBandCtx &c)
                 const uint32_t s0 = c.seed;
                 OG_LANES_BEGIN(tid)
                 for (int j = tid; j < n0; j += OG_WG) {
-                    uint32_t s = la[j + 1] * s0 + lc[j + 1];
+                    uint32_t s = og_lcg_jump((uint32_t)j + 1u, s0);
                     x[(j << lm) + k] = (s & 0x8000) ? r : -r;
                 }
                 OG_LANES_END
-                c.seed = la[n0] * s0 + lc[n0];
+                c.seed = og_lcg_jump((uint32_t)n0, s0);
                 renorm = true;
             }
             if (renorm) og_wg_renormalize(x, n0 << lm, 1.f);
@@ -661,8 +675,7 @@ OG_DEV void og_celt_spectrum(const OgCeltHdr *hg, const OgBandPlan *plan, const 
         uint32_t *od = (uint32_t *)L.w.b.ops;
         for (int p = tid; p < OG_LDS_OPS * 4; p += OG_WG) od[p] = ps[OG_PLAN_HEAD_BYTES / 4 + p];
     }
-    for (int p = tid; p < (int)(sizeof(OgCeltConst) / 4); p += OG_WG) ((uint32_t *)&L.k)[p] = ((const uint32_t *)&T->k)[p];
-    for (int p = tid; p < 184; p += OG_WG) { L.w.b.lcg_a[p] = T->lcg_a[p]; L.w.b.lcg_c[p] = T->lcg_c[p]; }
+    if (tid < 24) { L.k.emeans[tid] = T->k.emeans[tid]; L.k.ebands[tid] = T->k.ebands[tid]; L.k.width[tid] = T->k.width[tid]; }
     // K1's output for this frame: shaped PVQ coefficients (zero elsewhere)
     for (int p = tid; p < 2 * 960 / 4; p += OG_WG) ((OgF4 *)&L.X[0][0])[p] = ((const OgF4 *)coef_row)[p];      // 16 bytes per lane
     for (int p = tid; p < 2 * 800; p += OG_WG) L.R[p] = 0.f;
@@ -711,7 +724,7 @@ OG_DEV void og_celt_spectrum(const OgCeltHdr *hg, const OgBandPlan *plan, const 
         L.gband[ch][b] = g;
     }
     for (int p = tid; p < 960; p += OG_WG) ((float *)ldsW)[p] = ((const float *)T->fft_w)[p];
-    for (int p = tid; p < 960 / 4; p += OG_WG) ((uint32_t *)L.w.t.bin2band)[p] = ((const uint32_t *)T->bin2band[lm0])[p];
+    for (int p = tid; p < 960 / 4; p += OG_WG) ((uint32_t *)L.R)[p] = ((const uint32_t *)T->bin2band[lm0])[p];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int q = tid + j * OG_WG;
@@ -729,7 +742,7 @@ OG_DEV void og_celt_spectrum(const OgCeltHdr *hg, const OgBandPlan *plan, const 
 #pragma unroll
     for (int k = 0; k < 4; k++) {                       // loads first (independent), then arithmetic: the LDS latencies overlap
         const int j = tid + k * OG_WG < 960 ? tid + k * OG_WG : 959;
-        bb[k] = L.w.t.bin2band[j];
+        bb[k] = ((const uint8_t *)L.R)[j];
         x0[k] = L.X[0][j];
         x1[k] = L.X[1][j];
     }

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(64) void og_plan_kernel(const OgCeltHdr *__restrict
 // workgroups per CU (31 KB of LDS, 96 VGPRs).  og_celt_tail_kernel: one 128-lane workgroup per group of
 // frames_per_group consecutive records (a stream's frames in time order), which it walks in order carrying the stream's
 // state: window + overlap-add, comb filter, de-emphasis, PCM.
-__global__ __launch_bounds__(OG_WG) __attribute__((amdgpu_waves_per_eu(7, 7))) void og_celt_kernel(const OgCeltHdr *__restrict__ hdr, uint32_t nframes,
+__global__ __launch_bounds__(OG_WG) __attribute__((amdgpu_waves_per_eu(8, 8))) void og_celt_kernel(const OgCeltHdr *__restrict__ hdr, uint32_t nframes,
                                                                                                    const OgCeltTables *__restrict__ T, void *work,
                                                                                                    OgCeltDebug dbg)
 {
