@@ -198,21 +198,23 @@ template <class T> OG_DEV T og_uniform(const T &v) { return v; }
 template <int K> struct OgXr { float v[K]; };
 
 template <int K, bool PRE>
-OG_DEV void og_xf_perm_read(const float *buf, const OgTask tk, float scale, int first, int step, OgXr<K> &r)
+OG_DEV void og_xf_perm_read(const float *buf, const OgTask tk, float scale, int first, int step, OgXr<K> &r, int nmax)
 {
     const int n = tk.n, slog = tk.slog, n0p = tk.n0p, had = (tk.flags & OG_T_LONG) != 0;
 #pragma unroll
     for (int k = 0; k < K; k++) {
+        if (k * step >= nmax) break;                    // nmax: a uniform bound on n (the unrolled steps end on a scalar branch)
         const int p = first + k * step;
         r.v[k] = p < n ? (PRE ? buf[p] * scale : buf[og_reorder(slog, n0p, had, p)]) : 0.f;
     }
 }
 template <int K, bool PRE>
-OG_DEV void og_xf_perm_write(float *buf, const OgTask tk, int first, int step, const OgXr<K> &r)
+OG_DEV void og_xf_perm_write(float *buf, const OgTask tk, int first, int step, const OgXr<K> &r, int nmax)
 {
     const int n = tk.n, slog = tk.slog, n0p = tk.n0p, had = (tk.flags & OG_T_LONG) != 0;
 #pragma unroll
     for (int k = 0; k < K; k++) {
+        if (k * step >= nmax) break;
         const int p = first + k * step;
         if (p < n) buf[PRE ? og_reorder(slog, n0p, had, p) : p] = r.v[k];
     }
@@ -256,10 +258,10 @@ OG_DEV void og_task_xform(OgCeltLds &L, const OgTask tk, int slot, float *lb)
         OG_WAVE_END
     } else if (tk.slog) {
         OG_WAVE_BEGIN(lane)
-        og_xf_perm_read<3, false>(buf, tk, 1.f, lane, 64, OG_WV(rv));
+        og_xf_perm_read<3, false>(buf, tk, 1.f, lane, 64, OG_WV(rv), tk.n);
         OG_WAVE_END
         OG_WAVE_BEGIN(lane)
-        og_xf_perm_write<3, false>(buf, tk, lane, 64, OG_WV(rv));
+        og_xf_perm_write<3, false>(buf, tk, lane, 64, OG_WV(rv), tk.n);
         OG_WAVE_END
     }
     for (int s = 0; s < 8; s++) {
@@ -272,10 +274,10 @@ OG_DEV void og_task_xform(OgCeltLds &L, const OgTask tk, int slot, float *lb)
     if (PRE) {
         const float scale = og_xf_scale(tk);
         OG_WAVE_BEGIN(lane)
-        og_xf_perm_read<3, true>(buf, tk, scale, lane, 64, OG_WV(rv));
+        og_xf_perm_read<3, true>(buf, tk, scale, lane, 64, OG_WV(rv), tk.n);
         OG_WAVE_END
         OG_WAVE_BEGIN(lane)
-        og_xf_perm_write<3, true>(buf, tk, lane, 64, OG_WV(rv));
+        og_xf_perm_write<3, true>(buf, tk, lane, 64, OG_WV(rv), tk.n);
         OG_WAVE_END
     }
 }
@@ -329,22 +331,24 @@ OG_DEV void og_fill_op(OgBandCtx &c, int k, int w, int task_pos)     // task_pos
     if (!(op.flags & OG_OP_FOLD)) {                     // noise (celt/decoder.rs:1644-1651)
         OG_WAVE_BEGIN(lane)
         float e = 0.f;
+        uint32_t s = og_lcg_jump((uint32_t)lane + 1u, s0);
         for (int p = lane; p < nn; p += 64) {
-            uint32_t s = og_lcg_jump((uint32_t)p + 1u, s0);
             const float v = (float)((int32_t)s >> 20);
             xl[p] = v;
             e += v * v;
+            s = og_lcg_jump(64u, s);
         }
         part[lane] = e;
         OG_WAVE_END
     } else {                                            // fold the lower band in (celt/decoder.rs:1652-1659)
         OG_WAVE_BEGIN(lane)
         float e = 0.f;
+        uint32_t s = og_lcg_jump((uint32_t)lane + 1u, s0);
         for (int p = lane; p < nn; p += 64) {
-            uint32_t s = og_lcg_jump((uint32_t)p + 1u, s0);
             const float v = lbl[p] + ((s & 0x8000) ? 1.f / 256 : -1.f / 256);
             xl[p] = v;
             e += v * v;
+            s = og_lcg_jump(64u, s);
         }
         part[lane] = e;
         OG_WAVE_END
@@ -393,6 +397,7 @@ OG_DEV void og_celt_bands(OgBandCtx &c)
                 OG_WAVE_VAR(OgTask, tkv);                           // the group's task: fetched once per round
                 OG_WAVE_VAR(int, slotv);
                 OG_WAVE_VAR(OgXr<11>, rv);                          // the in-place reorder's elements in flight
+                int nmax = 0;                                       // widest task of the wave's four: group 0's (largest first)
                 OG_WAVE_BEGIN(lane)
                 const int k = base + 4 * w + (lane >> 4);
                 OgTask tk;
@@ -402,14 +407,15 @@ OG_DEV void og_celt_bands(OgBandCtx &c)
                     const int id = PL->order[t1 - 1 - k];
                     tk = tasks[id];
                     slot = id & 1;
-                    if (tk.slog) og_xf_perm_read<11, false>(&L.X[0][0] + slot * 960 + tk.boff, tk, 1.f, lane & 15, 16, OG_WV(rv));
                 }
+                OG_WAVE_BCAST0(nmax, tk.n);
+                if (tk.slog) og_xf_perm_read<11, false>(&L.X[0][0] + slot * 960 + tk.boff, tk, 1.f, lane & 15, 16, OG_WV(rv), nmax);
                 OG_WV(tkv) = tk;
                 OG_WV(slotv) = slot;
                 OG_WAVE_END
                 OG_WAVE_BEGIN(lane)
                 if (OG_WV(tkv).slog)
-                    og_xf_perm_write<11, false>(&L.X[0][0] + OG_WV(slotv) * 960 + OG_WV(tkv).boff, OG_WV(tkv), lane & 15, 16, OG_WV(rv));
+                    og_xf_perm_write<11, false>(&L.X[0][0] + OG_WV(slotv) * 960 + OG_WV(tkv).boff, OG_WV(tkv), lane & 15, 16, OG_WV(rv), nmax);
                 OG_WAVE_END
                 for (int s = 0; s < maxb; s++) {
                     OG_WAVE_BEGIN(lane)

@@ -48,6 +48,8 @@
 // The same for a value that lives across OG_LANES regions (the regions' lane variable must be `tid`).
 #define OG_LANE_VAR(T, name) T name
 #define OG_LV(name) name
+// dst (a plain variable declared outside the OG_WAVE region) = lane 0's value of val, for every lane
+#define OG_WAVE_BCAST0(dst, val) dst = __builtin_amdgcn_readfirstlane((int)(val))
 #else
 #include <math.h>
 #define OG_DEV static inline
@@ -72,4 +74,5 @@
 #define OG_WV(name) name[lane]
 #define OG_LANE_VAR(T, name) T name[OG_WG]
 #define OG_LV(name) name[tid]
+#define OG_WAVE_BCAST0(dst, val) { if (lane == 0) dst = (int)(val); }
 #endif
