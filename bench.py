@@ -28,6 +28,7 @@ HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # SURVEY.md 8(d) algorithmic bytes per C2 frame: 1024 side-info + 7680 PCM + 1920 overlap r/w + ~700 energy/seed
 # = 11324, plus 7712 of post-filter history when the comb filter is active in the frame
 ALG_BYTES_BASE, ALG_BYTES_PF = 11324, 7712
+K2_BYTES = 1724 + 7680 + 7680       # og_celt_kernel per frame: side-info + energies, K1's coefficient row in, sample row out
 
 
 def parse_args():
@@ -161,6 +162,7 @@ def main():
     p_pvq, p_frm = C.c_void_p(s_pvq.cuda_stream), C.c_void_p(s_frm.cuda_stream)
     ready = [torch.cuda.Event() for _ in range(nsteps)]
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nsteps)]
+    evk = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nsteps)]   # around og_celt_kernel
 
     def check(rc):
         if rc:
@@ -170,9 +172,15 @@ def main():
         """step f; the frame kernel is bracketed by ev[f] on the stream it runs on"""
         w = works[f % 2]
         if (not a.pipeline):
+            # = opusgpu_launch_celt, issued as its three parts so that the dominant kernel can be bracketed on its stream
             ev[f][0].record(s_frm)
-            check(lib.opusgpu_launch_celt(hdr_dev[f].data_ptr(), leaf_dev[f].data_ptr(), S * T, T, ref_dev[f].data_ptr(), ref_classes[f],
-                                          w.data_ptr(), state.data_ptr(), pcm.data_ptr(), stride, None, p_frm))
+            check(lib.opusgpu_launch_celt_pvq(hdr_dev[f].data_ptr(), leaf_dev[f].data_ptr(), S * T, ref_dev[f].data_ptr(), ref_classes[f],
+                                              w.data_ptr(), None, p_frm))
+            evk[f][0].record(s_frm)
+            check(lib.opusgpu_launch_celt_spectrum(hdr_dev[f].data_ptr(), S * T, w.data_ptr(), None, p_frm))
+            evk[f][1].record(s_frm)
+            check(lib.opusgpu_launch_celt_tail(hdr_dev[f].data_ptr(), S * T, T, w.data_ptr(), state.data_ptr(), pcm.data_ptr(), stride,
+                                               None, p_frm))
             ev[f][1].record(s_frm)
             return
         if f >= 2:
@@ -182,8 +190,11 @@ def main():
         ready[f].record(s_pvq)
         s_frm.wait_event(ready[f])
         ev[f][0].record(s_frm)
-        check(lib.opusgpu_launch_celt_frames(hdr_dev[f].data_ptr(), S * T, T, w.data_ptr(), state.data_ptr(), pcm.data_ptr(), stride,
-                                             None, p_frm))
+        evk[f][0].record(s_frm)
+        check(lib.opusgpu_launch_celt_spectrum(hdr_dev[f].data_ptr(), S * T, w.data_ptr(), None, p_frm))
+        evk[f][1].record(s_frm)
+        check(lib.opusgpu_launch_celt_tail(hdr_dev[f].data_ptr(), S * T, T, w.data_ptr(), state.data_ptr(), pcm.data_ptr(), stride,
+                                           None, p_frm))
         ev[f][1].record(s_frm)
 
     torch.cuda.synchronize(dev)
@@ -207,13 +218,16 @@ def main():
     avg_alg = sum(alg_bytes[W:]) / K
     achieved = avg_alg / avg_kernel_s / 1e9
     step_achieved = avg_alg / (elapsed / K) / 1e9           # the same bytes over the whole step (all kernels)
-    traffic = None
-    tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")      # HBM bytes per launch from a rocprofv3 --pmc pass
-    if os.path.exists(tp):
+    k2_s = sum(e0.elapsed_time(e1) for e0, e1 in evk[W:]) / K / 1e3       # og_celt_kernel alone
+    k2_bytes = S * T * K2_BYTES
+    traffic = k2_traffic = None
+    tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")      # HBM bytes per launch from the rocprofv3 --pmc passes
+    if os.path.exists(tp) and S == STREAMS_PER_GPU and T == 8:   # collected on the default workload only
         try:
-            traffic = json.load(open(tp)).get("og_celt_kernel_bytes_per_launch")
+            tj = json.load(open(tp))
+            traffic, k2_traffic = tj.get("launch_bytes"), tj.get("og_celt_kernel_bytes")
         except Exception:
-            traffic = None
+            traffic = k2_traffic = None
 
     if rank == 0:
         out = {
@@ -229,12 +243,18 @@ def main():
                        "streams_per_gpu": S, "frame_ms": 20, "frames_per_stream_per_step": T, "payload_bytes": PAYLOAD,
                        "parallelism": f"streams sharded over {world} GPU(s), no collective",
                        "pipelined": bool(a.pipeline)},
+            # the launch = every kernel of one opusgpu_launch_celt (4 K1 size classes, plan, og_celt_kernel, og_celt_tail_kernel),
+            # priced with SURVEY 8(d)'s per-frame bytes; `dominant` = og_celt_kernel alone (52 % of the launch) with the bytes it
+            # moves by design (side-info + energies 1724, K1 row in 7680, sample row out 7680)
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "kernel": ("one opusgpu_launch_celt call (K1 classes + plan + og_celt_kernel)" if (not a.pipeline) else
-                                    "og_celt_kernel (K2+K3), the dominant kernel; K1 + plan of the next step overlap it"),
+                         "kernel": ("one opusgpu_launch_celt call: og_pvq_kernel x4 + og_plan_kernel + og_celt_kernel + og_celt_tail_kernel"
+                                    if (not a.pipeline) else "og_celt_kernel + og_celt_tail_kernel; K1 + plan of the next step overlap them"),
                          "avg_launch_us": round(avg_kernel_s * 1e6, 2),
                          "algorithmic_bytes_per_launch": int(avg_alg),
+                         "dominant": {"kernel": "og_celt_kernel", "avg_launch_us": round(k2_s * 1e6, 2), "bytes_per_launch": int(k2_bytes),
+                                      "achieved": round(k2_bytes / k2_s / 1e9, 2), "frac": round(k2_bytes / k2_s / 1e9 / HBM_PEAK_GBS, 5),
+                                      "traffic": k2_traffic},
                          "whole_step": {"achieved": round(step_achieved, 2), "frac": round(step_achieved / HBM_PEAK_GBS, 5)}},
             "host_parse": {"value": round(S * nframes * FRAME_S / t_parse, 1), "unit": "audio-s/s",
                            "note": "packets -> side-info on the host threads (untimed in `value`)",

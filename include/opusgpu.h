@@ -179,7 +179,7 @@ typedef struct {               /* optional stage dumps for parity tests; any poi
     float *norm;               /* [nframes][2][960]  normalised coefficients after band decoding */
     float *freq;               /* [nframes][2][960]  denormalised MDCT coefficients */
     uint8_t *collapse;         /* [nframes][2][21]   collapse masks */
-    uint64_t *cycles;          /* [nframes][64] + [177*4096][4]: shader-clock stamps, K2/K3 stages per frame at 0-8, then K1 stages
+    uint64_t *cycles;          /* [nframes][64] + [177*4096][4]: shader-clock stamps, K2/K3 stages per frame at 0-21, then K1 stages
                                   per workgroup at ((NMAX*4096 + block)*4) (profiling aid, tools/stage_profile.py) */
 } OgCeltDebug;
 
@@ -187,15 +187,18 @@ typedef struct {               /* optional stage dumps for parity tests; any poi
  * the launches too; exposed so a caller can pay the allocation before graph capture. */
 int opusgpu_init(int device);
 
-/* CELT, three kernel stages per launch:
+/* CELT, four kernel stages per launch:
  *   K1  og_pvq_kernel (one launch per leaf size class): one lane per PVQ leaf (refs[], sorted by size across the whole
  *       batch so that the lanes of a wavefront run the same trip counts): CWRS index -> pulses, normalise, spreading
  *       rotation, collapse mask (celt/decoder.rs:541-786); writes the shaped coefficients to the `work` scratch.
  *   plan  og_plan_kernel: one lane per frame: the integer half of decode_bands (celt/decoder.rs:2037-2220): which
  *       zero-pulse leaves fold / make noise and with which seed, collapse masks, dependency levels of the bands.
- *   K2+K3 og_celt_kernel: one workgroup per frame: fold / noise fill, Haar + Hadamard reordering, stereo merge
- *       (celt/decoder.rs:453-538, :788-827, :1601-1663, :1994-2032), then the synthesis the reference lacks
- *       (anti-collapse, denormalise, IMDCT, TDAC window, comb post-filter, de-emphasis), PCM out.
+ *   K2  og_celt_kernel ("spectrum"): one workgroup per frame, stateless: fold / noise fill, Haar + Hadamard reordering,
+ *       stereo merge (celt/decoder.rs:453-538, :788-827, :1601-1663, :1994-2032), then the first part of the synthesis
+ *       the reference lacks (anti-collapse, denormalise, IMDCT up to its post-twiddle); leaves the frame's
+ *       time-domain samples (before the window) in the frame's `work` row.
+ *   K3  og_celt_tail_kernel: one workgroup per group of frames, in stream order, carrying the decoder state: TDAC window
+ *       + overlap-add, comb post-filter, de-emphasis (RFC 6716 4.3.7), PCM out, state write-back.
  * Frames [i*frames_per_group, (i+1)*frames_per_group) must belong to one stream, in time order.
  * `work` = opusgpu_celt_work_bytes(nframes) bytes of device scratch (one block per frame, so a buffer sized for the
  * largest launch serves smaller ones), zero-filled ONCE by the caller; the kernels hand the parts that must start at
@@ -217,6 +220,12 @@ int opusgpu_launch_celt_pvq(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, uint
                             const uint32_t class_counts[4], void *work, const OgCeltDebug *debug, void *stream);
 int opusgpu_launch_celt_frames(const OgCeltHdr *hdr, uint32_t nframes, uint32_t frames_per_group, void *work, OgCeltState *state,
                                float *pcm, size_t pcm_stride_floats, const OgCeltDebug *debug, void *stream);
+/* opusgpu_launch_celt_frames as its two kernels (the thin per-kernel FFI of SURVEY 8(b): ..._launch_band / _celt_synth):
+ * K2 alone touches no decoder state, so any number of a stream's frames may be in one K2 launch; K3 must follow it on
+ * the same stream (or behind an event).  bench.py times K2, the dominant kernel, through this entry point. */
+int opusgpu_launch_celt_spectrum(const OgCeltHdr *hdr, uint32_t nframes, void *work, const OgCeltDebug *debug, void *stream);
+int opusgpu_launch_celt_tail(const OgCeltHdr *hdr, uint32_t nframes, uint32_t frames_per_group, void *work, OgCeltState *state,
+                             float *pcm, size_t pcm_stride_floats, const OgCeltDebug *debug, void *stream);
 
 /* SILK: K4 LTP + LPC synthesis with one lane per (stream, channel) over struct-of-arrays state (replaces
  * silk/decoder.rs:1775-1898), then K5 + K6: stereo unmix / mono copy (silk/decoder.rs:2012-2061, :2104-2113) and the

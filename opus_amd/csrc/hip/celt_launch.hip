@@ -219,8 +219,24 @@ int opusgpu_launch_celt_pvq(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, uint
     return OPUSGPU_OK;
 }
 
-int opusgpu_launch_celt_frames(const OgCeltHdr *hdr, uint32_t nframes, uint32_t frames_per_group, void *work, OgCeltState *state,
-                               float *pcm, size_t pcm_stride_floats, const OgCeltDebug *debug, void *stream)
+int opusgpu_launch_celt_spectrum(const OgCeltHdr *hdr, uint32_t nframes, void *work, const OgCeltDebug *debug, void *stream)
+{
+    if (nframes == 0) return OPUSGPU_OK;
+    if (!hdr || !work) return OPUSGPU_BAD_ARG;
+    int device = 0;
+    OG_HIP(hipGetDevice(&device));
+    const OgCeltTables *T;
+    int rc = og::celt_tables_for_device(device, &T);
+    if (rc) return rc;
+    OgCeltDebug dbg = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (debug) dbg = *debug;
+    hipLaunchKernelGGL(og_celt_kernel, dim3(nframes), dim3(OG_WG), 0, (hipStream_t)stream, hdr, nframes, T, work, dbg);
+    OG_HIP(hipGetLastError());
+    return OPUSGPU_OK;
+}
+
+int opusgpu_launch_celt_tail(const OgCeltHdr *hdr, uint32_t nframes, uint32_t frames_per_group, void *work, OgCeltState *state,
+                             float *pcm, size_t pcm_stride_floats, const OgCeltDebug *debug, void *stream)
 {
     if (nframes == 0) return OPUSGPU_OK;
     if (!hdr || !state || !pcm || !work || frames_per_group == 0) return OPUSGPU_BAD_ARG;
@@ -232,11 +248,20 @@ int opusgpu_launch_celt_frames(const OgCeltHdr *hdr, uint32_t nframes, uint32_t 
     OgCeltDebug dbg = {nullptr, nullptr, nullptr, nullptr, nullptr};
     if (debug) dbg = *debug;
     const uint32_t groups = (nframes + frames_per_group - 1) / frames_per_group;
-    hipLaunchKernelGGL(og_celt_kernel, dim3(nframes), dim3(OG_WG), 0, (hipStream_t)stream, hdr, nframes, T, work, dbg);
     hipLaunchKernelGGL(og_celt_tail_kernel, dim3(groups), dim3(OG_WGT), 0, (hipStream_t)stream, hdr, nframes, frames_per_group, T, work,
                        state, pcm, pcm_stride_floats, dbg);
     OG_HIP(hipGetLastError());
     return OPUSGPU_OK;
+}
+
+int opusgpu_launch_celt_frames(const OgCeltHdr *hdr, uint32_t nframes, uint32_t frames_per_group, void *work, OgCeltState *state,
+                               float *pcm, size_t pcm_stride_floats, const OgCeltDebug *debug, void *stream)
+{
+    if (nframes == 0) return OPUSGPU_OK;
+    if (!hdr || !state || !pcm || !work || frames_per_group == 0) return OPUSGPU_BAD_ARG;
+    int rc = opusgpu_launch_celt_spectrum(hdr, nframes, work, debug, stream);
+    if (rc) return rc;
+    return opusgpu_launch_celt_tail(hdr, nframes, frames_per_group, work, state, pcm, pcm_stride_floats, debug, stream);
 }
 
 int opusgpu_launch_celt(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, uint32_t nframes, uint32_t frames_per_group,
