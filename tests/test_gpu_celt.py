@@ -96,6 +96,21 @@ def test_synthetic_c2(payload):
             check_pcm(refs[s].decode(pk[s, f].tobytes()), dec.read(s), f"stream {s} frame {f}")
 
 
+@pytest.mark.parametrize("payload", [8, 24, 80])
+def test_low_rate_many_fill_leaves(payload):
+    """starved frames: most bands carry no pulses, up to ~42 noise / folded leaves per frame over several dependency
+    levels -- more than the 16 fill ops the spectrum kernel stages in LDS, so the rest are read from the plan in HBM"""
+    ns, nf = 48, 30
+    pk = synth.celt_fb_stereo_packets(range(ns), nf, payload)
+    dec = BatchDecoder(ns, 2, 0)
+    refs = [orc.Decoder(2) for _ in range(ns)]
+    for f in range(nf):
+        assert not any(dec.send([pk[s, f].tobytes() for s in range(ns)]))
+        dec.decode()
+        for s in range(ns):
+            check_pcm(refs[s].decode(pk[s, f].tobytes()), dec.read(s), f"payload {payload} stream {s} frame {f}")
+
+
 def test_stage_dumps_bit_exact_pulses():
     """raw launch (layer 3b) with stage dumps: PVQ pulse vectors and collapse masks bit-exact, normalised
     coefficients and MDCT bins within f32 rounding of the oracle's"""
