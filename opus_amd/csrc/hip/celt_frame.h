@@ -154,6 +154,7 @@ struct OgBandCtx {
     uint32_t seed;                    // uniform across the workgroup
     int lm;
     uint64_t *cycles;                 // profiling stamps (may be null)
+    int stop;                         // profiling aid: the frame ends after stage `stop` (0 = run everything)
 };
 
 // celt/decoder.rs:468-470 HADAMARD_ORDERY for strides 2, 4, 8, 16, one nibble per entry (entry i at bits 4i)
@@ -429,6 +430,7 @@ OG_DEV void og_celt_bands(OgBandCtx &c)
             }
             OG_WAVES_END
             OG_STAMP_TO(c.cycles, 17)
+            if (c.stop == 2) return;
             continue;
         }
         OG_WAVES_BEGIN(w)
@@ -449,6 +451,7 @@ OG_DEV void og_celt_bands(OgBandCtx &c)
     }
 
     OG_STAMP_TO(c.cycles, 18)
+    if (c.stop == 3) return;
     // ---- merges: stereo_merge (celt/decoder.rs:796-827) + the N == 2 case (:1826-1862): a band per 16-lane group,
     //      four bands per wave at a time (the dot products reduce inside the group, no barrier)
     if (C == 2) {
@@ -663,7 +666,7 @@ OG_DEV void og_wave_comb_filter(float *y, int T0, int T1, int n, float g0, float
 // mono output).  Uniform arguments; every lane of the workgroup calls it.  `dbg` pointers are already offset to this
 // frame (any may be null).
 OG_DEV void og_celt_spectrum(const OgCeltHdr *hg, const OgBandPlan *plan, const OgCeltTables *T, OgCeltLds &L, const OgCeltDebug &dbg,
-                             float *coef_row)
+                             float *coef_row, int stop = 0 /* profiling aid: leave after stage `stop` (tools/stage_insts.sh) */)
 {
     float *dbg_norm = dbg.norm, *dbg_freq = dbg.freq;
     uint8_t *dbg_collapse = dbg.collapse;
@@ -692,11 +695,12 @@ OG_DEV void og_celt_spectrum(const OgCeltHdr *hg, const OgBandPlan *plan, const 
     const bool transient = (h->flags & OG_F_TRANSIENT) != 0, silence = (h->flags & OG_F_SILENCE) != 0;
 
     OG_STAMP(1)
+    if (stop == 1) return;
     if (!silence) {
         OG_STAMP(2)
         // ---- phase 2 (K2): bands in order
         OgBandCtx c;
-        c.h = h; c.plan = plan; c.T = T; c.L = &L; c.seed = h->seed; c.lm = lm; c.cycles = dbg.cycles;
+        c.h = h; c.plan = plan; c.T = T; c.L = &L; c.seed = h->seed; c.lm = lm; c.cycles = dbg.cycles; c.stop = stop;
         og_celt_bands(c);
         if (dbg_norm || dbg_collapse) {
             OG_LANES_BEGIN(tid)
@@ -705,9 +709,11 @@ OG_DEV void og_celt_spectrum(const OgCeltHdr *hg, const OgBandPlan *plan, const 
             OG_LANES_END
         }
         OG_STAMP(3)
+        if (stop >= 2 && stop <= 5) return;
         if (h->flags & OG_F_ANTICOLLAPSE) og_anti_collapse(c);
     }
     OG_STAMP(4)
+    if (stop == 6) return;
     OG_BARRIER                                          // the uniform reads of the band-walk tables above are done in every wave
                                                         // before the twiddles below replace them
 
@@ -775,6 +781,7 @@ OG_DEV void og_celt_spectrum(const OgCeltHdr *hg, const OgBandPlan *plan, const 
     }
 
     OG_STAMP(5)
+    if (stop == 7) return;
     // ---- phase 5 (K3): IMDCT.  B blocks of NB bins, interleaved with stride B in X.  The FFT ping-pongs between the
     //      R and X.
     OgCf *bufA = (OgCf *)L.R, *bufB = (OgCf *)&L.X[0][0];

@@ -1,5 +1,6 @@
 // C ABI, layer 3b (include/opusgpu.h): raw CELT kernel launch on caller-owned device memory.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <mutex>
 #include <string>
 #include "celt_frame.h"
@@ -31,7 +32,7 @@ __global__ __launch_bounds__(WGS) void og_pvq_kernel(const OgLeafRef *__restrict
 // chain, so what it reads and indexes sits in LDS: the workgroup's headers (copied in coalesced; a lane's header is 167
 // dwords from its neighbour's, an odd stride, so the lanes' reads fall on distinct banks), the small constant tables, and
 // a row of scratch cells per lane for the arrays it indexes at run time.
-#define OG_PLAN_FPW 64
+#define OG_PLAN_FPW 16
 __global__ __launch_bounds__(64) void og_plan_kernel(const OgCeltHdr *__restrict__ hdr, const OgCeltLeaf *__restrict__ leaves,
                                                      uint32_t nframes, const OgCeltTables *__restrict__ T, void *work)
 {
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(64) void og_plan_kernel(const OgCeltHdr *__restrict
 // state: window + overlap-add, comb filter, de-emphasis, PCM.
 __global__ __launch_bounds__(OG_WG) __attribute__((amdgpu_waves_per_eu(8, 8))) void og_celt_kernel(const OgCeltHdr *__restrict__ hdr, uint32_t nframes,
                                                                                                    const OgCeltTables *__restrict__ T, void *work,
-                                                                                                   OgCeltDebug dbg)
+                                                                                                   OgCeltDebug dbg, int stop)
 {
     __shared__ OgCeltLds L;
     const uint32_t f = blockIdx.x;
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(OG_WG) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     d.freq = dbg.freq ? dbg.freq + (size_t)f * 1920 : nullptr;
     d.collapse = dbg.collapse ? dbg.collapse + (size_t)f * 42 : nullptr;
     d.cycles = dbg.cycles ? dbg.cycles + (size_t)f * 64 : nullptr;
-    og_celt_spectrum(hdr + f, og_work_plan(work, f), T, L, d, og_work_coef(work, f));
+    og_celt_spectrum(hdr + f, og_work_plan(work, f), T, L, d, og_work_coef(work, f), stop);
 }
 
 __global__ __launch_bounds__(OG_WGT) void og_celt_tail_kernel(const OgCeltHdr *__restrict__ hdr, uint32_t nframes, uint32_t frames_per_group,
@@ -230,7 +231,8 @@ int opusgpu_launch_celt_spectrum(const OgCeltHdr *hdr, uint32_t nframes, void *w
     if (rc) return rc;
     OgCeltDebug dbg = {nullptr, nullptr, nullptr, nullptr, nullptr};
     if (debug) dbg = *debug;
-    hipLaunchKernelGGL(og_celt_kernel, dim3(nframes), dim3(OG_WG), 0, (hipStream_t)stream, hdr, nframes, T, work, dbg);
+    static const int stop = getenv("OPUSGPU_STOP_AFTER") ? atoi(getenv("OPUSGPU_STOP_AFTER")) : 0;      // profiling aid (tools/stage_insts.sh)
+    hipLaunchKernelGGL(og_celt_kernel, dim3(nframes), dim3(OG_WG), 0, (hipStream_t)stream, hdr, nframes, T, work, dbg, stop);
     OG_HIP(hipGetLastError());
     return OPUSGPU_OK;
 }
