@@ -41,7 +41,8 @@ def build_lib(force=False, verbose=False):
     objs = []
     for s in srcs:
         o = os.path.join(objdir, s.replace("/", "_") + ".o")
-        cmd = [_hipcc(), "--offload-arch=gfx950"] + common + ["-c", os.path.join(CSRC, s), "-o", o]
+        flags = list(common)
+        cmd = [_hipcc(), "--offload-arch=gfx950"] + flags + ["-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

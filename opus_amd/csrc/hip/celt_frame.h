@@ -564,47 +564,50 @@ OG_DEV OgCf og_cmul(OgCf a, OgCf b) { OgCf r; r.r = a.r * b.r - a.i * b.i; r.i =
 // floor(q / d) for the small non-negative integers used as work-item indices (q < 4096, d <= 480): exact
 OG_DEV int og_div(int q, float inv_d) { return (int)(((float)q + 0.5f) * inv_d); }
 
-// One Stockham stage of radix R over nch*blocks transforms of size n; transform b of channel ch starts at
-// ch*schs + b*n in src and ch*dchs + b*n in dst.  Ns = product of the radices already done: a power of two for R = 2, 3, 4 (stage order 4,4,2,3,5)
-// and n/5 for the final R = 5 stage, so the position inside the sub-transform never needs a division.
+// One Stockham stage of radix R over TT = 2^tsh transforms of size n.  The transforms are interleaved: element i of
+// transform t sits at i * TT + t in both buffers, so a work item q splits into (transform, butterfly) with a mask and a
+// shift and its inputs are q, q + per * TT, ...  Ns = product of the radices already done: a power of two for R = 2, 3, 4
+// (stage order 4, 4, 2, 3, 5) and n/5 for the final R = 5 stage, so the position inside the sub-transform is a mask too.
+#if defined(__HIP__)
+#define OG_MUL24(a, b) __mul24((a), (b))                /* index products below 2^24: full-rate multiply */
+#else
+#define OG_MUL24(a, b) ((a) * (b))
+#endif
 template <int R>
-OG_DEV void og_wg_fft_stage(const OgCf *src, OgCf *dst, int schs, int dchs, int n, int nch, int blocks, int Ns, const OgCf *W)
+OG_DEV void og_wg_fft_stage(const OgCf *src, OgCf *dst, int n, int tsh, int Ns, const OgCf *W)
 {
-    const int per = n / R, total = nch * blocks * per, wstep = 480 / (Ns * R);
-    const float inv_per = 1.f / (float)per;
-    const int bsh = __builtin_ctz((unsigned)blocks);
+    const int per = n / R, total = per << tsh, wstep = 480 / (Ns * R), rstep = per << tsh, ostep = Ns << tsh;
     OG_LANES_BEGIN(tid)
     for (int q = tid; q < total; q += OG_WG) {
-        const int tt = og_div(q, inv_per), j = q - tt * per;
-        const int ch = tt >> bsh, b = tt & (blocks - 1);
-        const int base = ch * schs + b * n, obase = ch * dchs + b * n;
+        const int t = q & ((1 << tsh) - 1), j = q >> tsh;
         const int k = R == 5 ? j : (j & (Ns - 1));
-        const int j0 = (j - k) * R + k;
+        const int kw = OG_MUL24(k, wstep);
         OgCf v[R];
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            v[r] = src[base + j + r * per];
-            if (r) v[r] = og_cmul(v[r], W[k * r * wstep]);
+            v[r] = src[q + r * rstep];
+            if (r) v[r] = og_cmul(v[r], W[r * kw]);
         }
-        OgCf *o = dst + obase + j0;
+        OgCf *o = dst + ((((j - k) * R + k) << tsh) + t);
+        const int Ns_ = ostep;                          // outputs Ns apart in their transform = Ns * TT apart here
         if (R == 2) {
             o[0].r = v[0].r + v[1].r; o[0].i = v[0].i + v[1].i;
-            o[Ns].r = v[0].r - v[1].r; o[Ns].i = v[0].i - v[1].i;
+            o[Ns_].r = v[0].r - v[1].r; o[Ns_].i = v[0].i - v[1].i;
         } else if (R == 4) {
             OgCf t0 = {v[0].r + v[2].r, v[0].i + v[2].i}, t1 = {v[0].r - v[2].r, v[0].i - v[2].i};
             OgCf t2 = {v[1].r + v[3 % R].r, v[1].i + v[3 % R].i}, t3 = {v[1].i - v[3 % R].i, v[3 % R].r - v[1].r};   // -i (v1 - v3)
             o[0].r = t0.r + t2.r; o[0].i = t0.i + t2.i;
-            o[Ns].r = t1.r + t3.r; o[Ns].i = t1.i + t3.i;
-            o[2 * Ns].r = t0.r - t2.r; o[2 * Ns].i = t0.i - t2.i;
-            o[3 * Ns].r = t1.r - t3.r; o[3 * Ns].i = t1.i - t3.i;
+            o[Ns_].r = t1.r + t3.r; o[Ns_].i = t1.i + t3.i;
+            o[2 * Ns_].r = t0.r - t2.r; o[2 * Ns_].i = t0.i - t2.i;
+            o[3 * Ns_].r = t1.r - t3.r; o[3 * Ns_].i = t1.i - t3.i;
         } else if (R == 3) {
             const float s3 = 0.86602540378443864676f;
             OgCf s = {v[1].r + v[2 % R].r, v[1].i + v[2 % R].i}, d = {v[1].r - v[2 % R].r, v[1].i - v[2 % R].i};
             OgCf m = {v[0].r - 0.5f * s.r, v[0].i - 0.5f * s.i};
             OgCf e = {s3 * d.i, -s3 * d.r};                                                          // -i s3 d
             o[0].r = v[0].r + s.r; o[0].i = v[0].i + s.i;
-            o[Ns].r = m.r + e.r; o[Ns].i = m.i + e.i;
-            o[2 * Ns].r = m.r - e.r; o[2 * Ns].i = m.i - e.i;
+            o[Ns_].r = m.r + e.r; o[Ns_].i = m.i + e.i;
+            o[2 * Ns_].r = m.r - e.r; o[2 * Ns_].i = m.i - e.i;
         } else {
             const float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f;
             const float s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;
@@ -615,10 +618,10 @@ OG_DEV void og_wg_fft_stage(const OgCf *src, OgCf *dst, int schs, int dchs, int 
             OgCf q1 = {s1 * d14.r + s2 * d23.r, s1 * d14.i + s2 * d23.i};
             OgCf q2 = {s2 * d14.r - s1 * d23.r, s2 * d14.i - s1 * d23.i};
             o[0].r = v[0].r + s14.r + s23.r; o[0].i = v[0].i + s14.i + s23.i;
-            o[Ns].r = p1.r + q1.i; o[Ns].i = p1.i - q1.r;                                           // p1 - i q1
-            o[4 * Ns].r = p1.r - q1.i; o[4 * Ns].i = p1.i + q1.r;
-            o[2 * Ns].r = p2.r + q2.i; o[2 * Ns].i = p2.i - q2.r;
-            o[3 * Ns].r = p2.r - q2.i; o[3 * Ns].i = p2.i + q2.r;
+            o[Ns_].r = p1.r + q1.i; o[Ns_].i = p1.i - q1.r;                                           // p1 - i q1
+            o[4 * Ns_].r = p1.r - q1.i; o[4 * Ns_].i = p1.i + q1.r;
+            o[2 * Ns_].r = p2.r + q2.i; o[2 * Ns_].i = p2.i - q2.r;
+            o[3 * Ns_].r = p2.r - q2.i; o[3 * Ns_].i = p2.i + q2.r;
         }
     }
     OG_LANES_END
@@ -722,7 +725,9 @@ OG_DEV void og_celt_spectrum(const OgCeltHdr *hg, const OgBandPlan *plan, const 
     //      twiddles (the same for both: work item q of either pass has the same bin index) into registers
     const int B = transient ? M : 1, NB = N / B, n4 = NB >> 1;
     OgCf *ldsW = L.w.t.W;
-    const float inv_n4 = 1.f / (float)n4;
+    // the CC * B transforms of the frame are interleaved in the FFT buffers: work item q = bin i of transform t = ch * B + b
+    // at q = i * TT + t, TT = CC * B = 2^tsh
+    const int bsh = transient ? lm : 0, tsh = bsh + (CC == 2), tmask = (1 << tsh) - 1;
     struct OgTw4 { OgCf w[4]; };
     OG_LANE_VAR(OgTw4, twr);
     OG_LANES_BEGIN(tid)
@@ -741,10 +746,7 @@ OG_DEV void og_celt_spectrum(const OgCeltHdr *hg, const OgBandPlan *plan, const 
     for (int j = 0; j < 4; j++) {
         const int q = tid + j * OG_WG;
         OG_LV(twr).w[j] = OgCf{0.f, 0.f};
-        if (q < CC * (N >> 1)) {
-            const int ch = q >= (N >> 1), r = q - ch * (N >> 1), b = og_div(r, inv_n4), i = r - b * n4;
-            OG_LV(twr).w[j] = T->tw[(n4 - 60) + i];
-        }
+        if (q < CC * (N >> 1)) OG_LV(twr).w[j] = T->tw[(n4 - 60) + (q >> tsh)];
     }
     OG_LANES_END
     OG_STAMP(9)
@@ -782,21 +784,20 @@ OG_DEV void og_celt_spectrum(const OgCeltHdr *hg, const OgBandPlan *plan, const 
 
     OG_STAMP(5)
     if (stop == 7) return;
-    // ---- phase 5 (K3): IMDCT.  B blocks of NB bins, interleaved with stride B in X.  The FFT ping-pongs between the
-    //      R and X.
+    // ---- phase 5 (K3): IMDCT.  B blocks of NB bins, interleaved with stride B in X.  The FFT ping-pongs between R and X.
     OgCf *bufA = (OgCf *)L.R, *bufB = (OgCf *)&L.X[0][0];
     OG_LANES_BEGIN(tid)
 #pragma unroll
     for (int j = 0; j < 4; j++) {                                            // pre-twiddle
         const int q = tid + j * OG_WG;
         if (q < CC * (N >> 1)) {
-            const int ch = q >= (N >> 1), r = q - ch * (N >> 1), b = og_div(r, inv_n4), i = r - b * n4;
-            const float x1 = L.X[ch][(2 * i) * B + b], x2 = L.X[ch][(NB - 1 - 2 * i) * B + b];
+            const int t = q & tmask, i = q >> tsh, ch = t >> bsh, b = t & (B - 1);
+            const float x1 = L.X[ch][((2 * i) << bsh) + b], x2 = L.X[ch][N - B - ((2 * i) << bsh) + b];    // bins 2i and NB-1-2i of block b
             const OgCf w = OG_LV(twr).w[j];
             OgCf z;
             z.r = x1 * w.r + x2 * w.i;
             z.i = x2 * w.r - x1 * w.i;
-            bufA[ch * 480 + b * n4 + i] = z;
+            bufA[q] = z;
         }
     }
     OG_LANES_END
@@ -809,17 +810,15 @@ OG_DEV void og_celt_spectrum(const OgCeltHdr *hg, const OgBandPlan *plan, const 
         radix[ns++] = 5;
         int Ns = 1;
         OgCf *src = bufA, *dst = bufB;
-        int schs = 480, dchs = 480;
         for (int s = 0; s < ns; s++) {
             switch (radix[s]) {
-            case 4: og_wg_fft_stage<4>(src, dst, schs, dchs, n4, CC, B, Ns, ldsW); break;
-            case 2: og_wg_fft_stage<2>(src, dst, schs, dchs, n4, CC, B, Ns, ldsW); break;
-            case 3: og_wg_fft_stage<3>(src, dst, schs, dchs, n4, CC, B, Ns, ldsW); break;
-            default: og_wg_fft_stage<5>(src, dst, schs, dchs, n4, CC, B, Ns, ldsW); break;
+            case 4: og_wg_fft_stage<4>(src, dst, n4, tsh, Ns, ldsW); break;
+            case 2: og_wg_fft_stage<2>(src, dst, n4, tsh, Ns, ldsW); break;
+            case 3: og_wg_fft_stage<3>(src, dst, n4, tsh, Ns, ldsW); break;
+            default: og_wg_fft_stage<5>(src, dst, n4, tsh, Ns, ldsW); break;
             }
             Ns *= radix[s];
             OgCf *t = src; src = dst; dst = t;
-            const int ts = schs; schs = dchs; dchs = ts;
         }
         // `src` now holds the spectrum.  Post-twiddle into registers, past the barrier into X in time order (either FFT
         // buffer may be the source), then out to the frame's scratch row in 16-byte pieces.
@@ -831,8 +830,7 @@ OG_DEV void og_celt_spectrum(const OgCeltHdr *hg, const OgBandPlan *plan, const 
             const int q = tid + j * OG_WG;
             OG_LV(pv).r[j] = OG_LV(pv).i[j] = 0.f;
             if (q < CC * (N >> 1)) {
-                const int ch = q >= (N >> 1), r = q - ch * (N >> 1), b = og_div(r, inv_n4), k = r - b * n4;
-                const OgCf Z = src[ch * schs + b * n4 + k], w = OG_LV(twr).w[j];
+                const OgCf Z = src[q], w = OG_LV(twr).w[j];
                 OG_LV(pv).r[j] = Z.r * w.r + Z.i * w.i;
                 OG_LV(pv).i[j] = Z.i * w.r - Z.r * w.i;
             }
@@ -843,8 +841,8 @@ OG_DEV void og_celt_spectrum(const OgCeltHdr *hg, const OgBandPlan *plan, const 
         for (int j = 0; j < 4; j++) {
             const int q = tid + j * OG_WG;
             if (q < CC * (N >> 1)) {
-                const int ch = q >= (N >> 1), r = q - ch * (N >> 1), b = og_div(r, inv_n4), k = r - b * n4;
-                float *D = &L.X[ch][NB * b];
+                const int t = q & tmask, k = q >> tsh, ch = t >> bsh, b = t & (B - 1);
+                float *D = &L.X[ch][OG_MUL24(NB, b)];
                 D[2 * k] = OG_LV(pv).i[j];
                 D[NB - 1 - 2 * k] = -OG_LV(pv).r[j];
             }
