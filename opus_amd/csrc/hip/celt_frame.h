@@ -573,10 +573,11 @@ OG_DEV int og_div(int q, float inv_d) { return (int)(((float)q + 0.5f) * inv_d);
 #else
 #define OG_MUL24(a, b) ((a) * (b))
 #endif
-template <int R>
-OG_DEV void og_wg_fft_stage(const OgCf *src, OgCf *dst, int n, int tsh, int Ns, const OgCf *W)
+template <int R, int n, int Ns>      // compile-time sizes: every per-stage constant folds
+OG_DEV void og_wg_fft_stage(const OgCf *src, OgCf *dst, int tsh, const OgCf *W)
 {
-    const int per = n / R, total = per << tsh, wstep = 480 / (Ns * R), rstep = per << tsh, ostep = Ns << tsh;
+    constexpr int per = n / R, wstep = 480 / (Ns * R);
+    const int total = per << tsh, rstep = per << tsh, ostep = Ns << tsh;
     OG_LANES_BEGIN(tid)
     for (int q = tid; q < total; q += OG_WG) {
         const int t = q & ((1 << tsh) - 1), j = q >> tsh;
@@ -802,24 +803,37 @@ OG_DEV void og_celt_spectrum(const OgCeltHdr *hg, const OgBandPlan *plan, const 
     }
     OG_LANES_END
     {
-        int radix[5], ns = 0;                           // 60 * 2^lm = 4 * 4^a * 2^b * 3 * 5
-        int rem = n4 / 15;
-        while (rem % 4 == 0) { radix[ns++] = 4; rem /= 4; }
-        if (rem == 2) radix[ns++] = 2;
-        radix[ns++] = 3;
-        radix[ns++] = 5;
-        int Ns = 1;
+        // 60 * 2^k points = radix 4 (, 4) (, 2), 3, 5 stages; `src` ends up holding the spectrum
         OgCf *src = bufA, *dst = bufB;
-        for (int s = 0; s < ns; s++) {
-            switch (radix[s]) {
-            case 4: og_wg_fft_stage<4>(src, dst, n4, tsh, Ns, ldsW); break;
-            case 2: og_wg_fft_stage<2>(src, dst, n4, tsh, Ns, ldsW); break;
-            case 3: og_wg_fft_stage<3>(src, dst, n4, tsh, Ns, ldsW); break;
-            default: og_wg_fft_stage<5>(src, dst, n4, tsh, Ns, ldsW); break;
-            }
-            Ns *= radix[s];
-            OgCf *t = src; src = dst; dst = t;
+        switch (n4) {
+        case 60:
+            og_wg_fft_stage<4, 60, 1>(bufA, bufB, tsh, ldsW);
+            og_wg_fft_stage<3, 60, 4>(bufB, bufA, tsh, ldsW);
+            og_wg_fft_stage<5, 60, 12>(bufA, bufB, tsh, ldsW);
+            src = bufB; dst = bufA;
+            break;
+        case 120:
+            og_wg_fft_stage<4, 120, 1>(bufA, bufB, tsh, ldsW);
+            og_wg_fft_stage<2, 120, 4>(bufB, bufA, tsh, ldsW);
+            og_wg_fft_stage<3, 120, 8>(bufA, bufB, tsh, ldsW);
+            og_wg_fft_stage<5, 120, 24>(bufB, bufA, tsh, ldsW);
+            break;
+        case 240:
+            og_wg_fft_stage<4, 240, 1>(bufA, bufB, tsh, ldsW);
+            og_wg_fft_stage<4, 240, 4>(bufB, bufA, tsh, ldsW);
+            og_wg_fft_stage<3, 240, 16>(bufA, bufB, tsh, ldsW);
+            og_wg_fft_stage<5, 240, 48>(bufB, bufA, tsh, ldsW);
+            break;
+        default:
+            og_wg_fft_stage<4, 480, 1>(bufA, bufB, tsh, ldsW);
+            og_wg_fft_stage<4, 480, 4>(bufB, bufA, tsh, ldsW);
+            og_wg_fft_stage<2, 480, 16>(bufA, bufB, tsh, ldsW);
+            og_wg_fft_stage<3, 480, 32>(bufB, bufA, tsh, ldsW);
+            og_wg_fft_stage<5, 480, 96>(bufA, bufB, tsh, ldsW);
+            src = bufB; dst = bufA;
+            break;
         }
+        (void)dst;
         // `src` now holds the spectrum.  Post-twiddle into registers, past the barrier into X in time order (either FFT
         // buffer may be the source), then out to the frame's scratch row in 16-byte pieces.
         struct OgPost { float r[4], i[4]; };
