@@ -235,7 +235,11 @@ OG_DEV void og_xf_bfly(float *buf, const OgTask tk, int bit, int first, int step
 OG_DEV float og_xf_scale(const OgTask tk)               // 2^(-m/2) for the m butterflies
 {
     const int m = (tk.rctd & 15) + (tk.rctd >> 4);
-    return tk.hm ? (m & 1 ? 0.70710678118654752440f : 1.f) / (float)(1 << (m >> 1)) : 1.f;
+    if (!tk.hm) return 1.f;
+    const uint32_t pw = (127u - (uint32_t)(m >> 1)) << 23;     // 2^-(m >> 1), exactly what the division by (1 << (m >> 1)) gives
+    float f;
+    __builtin_memcpy(&f, &pw, 4);
+    return (m & 1 ? 0.70710678118654752440f : 1.f) * f;
 }
 
 // the s-th butterfly bit of a task, -1 when it has fewer (tf changes are at most 3 steps: celt/decoder.rs:221-226)
@@ -724,7 +728,7 @@ OG_DEV void og_celt_spectrum(const OgCeltHdr *hg, const OgBandPlan *plan, const 
     // ---- phase 4: denormalise (RFC 6716 4.3.6) + channel up/down-mix into MDCT bins; the first region also stages the
     //      FFT twiddles and the bin -> band map over the (now dead) band-walk tables and fetches the lane's IMDCT pre / post
     //      twiddles (the same for both: work item q of either pass has the same bin index) into registers
-    const int B = transient ? M : 1, NB = N / B, n4 = NB >> 1;
+    const int B = transient ? M : 1, NB = N >> (transient ? lm : 0), n4 = NB >> 1;
     OgCf *ldsW = L.w.t.W;
     // the CC * B transforms of the frame are interleaved in the FFT buffers: work item q = bin i of transform t = ch * B + b
     // at q = i * TT + t, TT = CC * B = 2^tsh
