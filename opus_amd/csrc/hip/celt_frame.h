@@ -20,6 +20,13 @@
 
 struct alignas(16) OgF4 { float x, y, z, w; };
 
+#if defined(__HIP__)
+#define OG_MUL24(a, b) __mul24((a), (b))                /* index products below 2^24: full-rate multiply */
+#else
+#define OG_MUL24(a, b) ((a) * (b))
+#endif
+
+
 #ifndef OG_LDS_OPS
 #define OG_LDS_OPS 16                 // fill ops staged in LDS per frame (C2 frames carry ~5); the rest stay in HBM
 #endif
@@ -303,22 +310,23 @@ OG_DEV void og_task_finish(OgCeltLds &L, const OgTask tk, int slot, int norm_off
     }
 }
 
-// The noise generator (celt/decoder.rs:1595-1599, seed' = 1664525 seed + 1013904223) advanced j < 256 steps at once: the
+// The noise generator (celt/decoder.rs:1595-1599, seed' = 1664525 seed + 1013904223) advanced j < 4096 steps at once: the
 // 2^k-step maps seed -> a_k seed + c_k (compile-time constants) applied for the set bits of j.  Integer arithmetic mod
 // 2^32: the same value as j single steps.
-struct OgLcgPow { uint32_t a[8], c[8]; };
+struct OgLcgPow { uint32_t a[12], c[12]; };
 constexpr OgLcgPow og_lcg_pows()
 {
     OgLcgPow p = {};
     p.a[0] = 1664525u; p.c[0] = 1013904223u;
-    for (int k = 0; k + 1 < 8; k++) { p.a[k + 1] = p.a[k] * p.a[k]; p.c[k + 1] = p.c[k] * (p.a[k] + 1u); }
+    for (int k = 0; k + 1 < 12; k++) { p.a[k + 1] = p.a[k] * p.a[k]; p.c[k + 1] = p.c[k] * (p.a[k] + 1u); }
     return p;
 }
+template <int BITS = 8>               // j < 2^BITS
 OG_DEV uint32_t og_lcg_jump(uint32_t j, uint32_t s)
 {
     constexpr OgLcgPow P = og_lcg_pows();
 #pragma unroll
-    for (int k = 0; k < 8; k++)
+    for (int k = 0; k < BITS; k++)
         if ((j >> k) & 1u) s = P.a[k] * s + P.c[k];
     return s;
 }
@@ -522,43 +530,76 @@ OG_DEV void og_celt_bands(OgBandCtx &c)
     OG_STAMP_TO(c.cycles, 19)
 }
 
-// RFC 6716 4.3.5 anti-collapse (bands.c); the reference only reserves its flag bit (celt/decoder.rs:1092)
+// RFC 6716 4.3.5 anti-collapse (bands.c); the reference only reserves its flag bit (celt/decoder.rs:1092).  In decode
+// order -- band, channel, block -- every block no pulse or fold reached is filled with +-r from the frame's noise
+// generator and its band renormalised.  Here: one lane per (band, channel) computes r, the collapsed blocks and, from the
+// prefix of their widths, where the band's first draw sits in the generator's sequence (an LCG jump); then the (band,
+// channel) pairs are dealt to the waves, which fill and renormalise their bands with no workgroup barrier in between.
+struct OgAcScratch { float r[44]; uint32_t steps[44], seed[44]; };      // in the (idle) lowband buffers
 OG_DEV void og_anti_collapse(OgBandCtx &c)
 {
     const OgCeltHdr *h = c.h;
     OgCeltLds &L = *c.L;
-    const int lm = c.lm, C = (h->flags & OG_F_STEREO) ? 2 : 1;
-    for (int i = h->start; i < h->end; i++) {
+    static_assert(sizeof(OgAcScratch) <= sizeof(L.w.b.s), "scratch fits the lowband buffers");
+    OgAcScratch &A = *(OgAcScratch *)&L.w.b.s;
+    const int lm = c.lm, M = 1 << lm, C = (h->flags & OG_F_STEREO) ? 2 : 1;
+    const int start = h->start, end = h->end, npairs = (end - start) * C;
+    const uint8_t (*collapse)[24] = ((const OgBandPlan *)L.w.b.plan_head)->collapse;
+    OG_LANES_BEGIN(tid)
+    if (tid < npairs) {
+        const int i = start + (C == 2 ? tid >> 1 : tid), ch = C == 2 ? tid & 1 : 0;
         const int n0 = L.k.width[i];
-        const int depth = h->pulses_depth[i];
-        const float thresh = 0.5f * exp2f(-0.125f * (float)depth);
+        const float thresh = 0.5f * exp2f(-0.125f * (float)h->pulses_depth[i]);
         const float sqrt_1 = 1.f / sqrtf((float)(n0 << lm));
-        for (int ch = 0; ch < C; ch++) {
-            float ediff = h->energy[ch][i] - h->prev_min[ch][i];
-            if (ediff < 0) ediff = 0;
-            float r = 2.f * exp2f(-ediff);
-            if (lm == 3) r *= 1.41421356f;
-            if (r > thresh) r = thresh;
-            r *= sqrt_1;
-            float *x = L.X[ch] + (L.k.ebands[i] << lm);
-            const int mask = ((const OgBandPlan *)L.w.b.plan_head)->collapse[ch][i];
-            bool renorm = false;
-            for (int k = 0; k < (1 << lm); k++) {
-                if (mask & (1 << k)) continue;
-                const uint32_t s0 = c.seed;
-                OG_LANES_BEGIN(tid)
-                for (int j = tid; j < n0; j += OG_WG) {
-                    uint32_t s = og_lcg_jump((uint32_t)j + 1u, s0);
-                    x[(j << lm) + k] = (s & 0x8000) ? r : -r;
-                }
-                OG_LANES_END
-                c.seed = og_lcg_jump((uint32_t)n0, s0);
-                renorm = true;
-            }
-            if (renorm) og_wg_renormalize(x, n0 << lm, 1.f);
-        }
+        float ediff = h->energy[ch][i] - h->prev_min[ch][i];
+        if (ediff < 0) ediff = 0;
+        float r = 2.f * exp2f(-ediff);
+        if (lm == 3) r *= 1.41421356f;
+        if (r > thresh) r = thresh;
+        A.r[tid] = r * sqrt_1;
+        const uint32_t dead = ~(uint32_t)collapse[ch][i] & ((1u << M) - 1u);      // one bit per block
+        A.steps[tid] = (uint32_t)__builtin_popcount(dead) * (uint32_t)n0;
     }
-}
+    OG_LANES_END
+    const uint32_t seed0 = c.seed;
+    OG_LANES_BEGIN(tid)
+    if (tid < npairs) {
+        uint32_t before = 0;
+        for (int u = 0; u < tid; u++) before += A.steps[u];
+        A.seed[tid] = og_lcg_jump<12>(before, seed0);       // at most 2 * 800 draws per frame
+    }
+    OG_LANES_END
+    OG_WAVES_BEGIN(w)
+    for (int t = w; t < npairs; t += OG_WG / 64) {
+        if (OG_U32(A.steps[t]) == 0) continue;              // nothing collapsed in this band
+        const int i = start + (C == 2 ? t >> 1 : t), ch = C == 2 ? t & 1 : 0;
+        const int n0 = L.k.width[i], n = n0 << lm;
+        const float r = A.r[t];
+        const uint32_t sb = A.seed[t], dead = ~(uint32_t)collapse[ch][i] & ((1u << M) - 1u);
+        float *x = L.X[ch] + (L.k.ebands[i] << lm), *part = og_part(L, w);
+        OG_WAVE_BEGIN(lane)
+        float e = 0.f;
+        for (int p = lane; p < n; p += 64) {                // element p = coefficient j of block k
+            const int k = p & (M - 1), j = p >> lm;
+            float v = x[p];
+            if (dead & (1u << k)) {
+                const int rank = __builtin_popcount(dead & ((1u << k) - 1u));      // collapsed blocks before this one
+                const uint32_t s = og_lcg_jump<8>((uint32_t)(OG_MUL24(rank, n0) + j + 1), sb);
+                v = (s & 0x8000) ? r : -r;
+                x[p] = v;
+            }
+            e += v * v;
+        }
+        part[lane] = e;
+        OG_WAVE_END
+        const float g = 1.f / sqrtf(1e-15f + og_wave_tree_sum(part));
+        OG_WAVE_BEGIN(lane)
+        for (int p = lane; p < n; p += 64) x[p] *= g;
+        OG_WAVE_END
+    }
+    OG_WAVES_END
+}                                                       // (the generator's state after the frame is not needed: every frame's
+                                                        //  header carries its own seed)
 
 // ------------------------------------------------------------------------------------------------
 // K3: IMDCT as an N/4-point complex FFT (N/4 = 60 * 2^lm = 15 * 2^(lm+2): radix 4/2/3/5 Stockham
@@ -572,11 +613,6 @@ OG_DEV int og_div(int q, float inv_d) { return (int)(((float)q + 0.5f) * inv_d);
 // transform t sits at i * TT + t in both buffers, so a work item q splits into (transform, butterfly) with a mask and a
 // shift and its inputs are q, q + per * TT, ...  Ns = product of the radices already done: a power of two for R = 2, 3, 4
 // (stage order 4, 4, 2, 3, 5) and n/5 for the final R = 5 stage, so the position inside the sub-transform is a mask too.
-#if defined(__HIP__)
-#define OG_MUL24(a, b) __mul24((a), (b))                /* index products below 2^24: full-rate multiply */
-#else
-#define OG_MUL24(a, b) ((a) * (b))
-#endif
 template <int R, int n, int Ns>      // compile-time sizes: every per-stage constant folds
 OG_DEV void og_wg_fft_stage(const OgCf *src, OgCf *dst, int tsh, const OgCf *W)
 {
