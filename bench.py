@@ -169,11 +169,10 @@ def main():
             raise RuntimeError(lib.opusgpu_last_error().decode())
 
     def step(f):
-        """step f; the frame kernel is bracketed by ev[f] on the stream it runs on"""
+        """step f; og_celt_kernel is bracketed by evk[f] on the stream it runs on"""
         w = works[f % 2]
         if (not a.pipeline):
             # = opusgpu_launch_celt, issued as its three parts so that the dominant kernel can be bracketed on its stream
-            ev[f][0].record(s_frm)
             check(lib.opusgpu_launch_celt_pvq(hdr_dev[f].data_ptr(), leaf_dev[f].data_ptr(), S * T, ref_dev[f].data_ptr(), ref_classes[f],
                                               w.data_ptr(), None, p_frm))
             evk[f][0].record(s_frm)
@@ -181,7 +180,6 @@ def main():
             evk[f][1].record(s_frm)
             check(lib.opusgpu_launch_celt_tail(hdr_dev[f].data_ptr(), S * T, T, w.data_ptr(), state.data_ptr(), pcm.data_ptr(), stride,
                                                None, p_frm))
-            ev[f][1].record(s_frm)
             return
         if f >= 2:
             s_pvq.wait_event(ev[f - 2][1])              # the scratch buffer is free once frames(f-2) has consumed it
@@ -213,8 +211,11 @@ def main():
     elapsed = sharding.max_over_ranks(elapsed, dev)
     assert bool(torch.isfinite(pcm).all())
 
-    kernel_ms = [e0.elapsed_time(e1) for e0, e1 in ev[W:]]
-    avg_kernel_s = sum(kernel_ms) / K / 1e3
+    if a.pipeline:
+        kernel_ms = [e0.elapsed_time(e1) for e0, e1 in ev[W:]]
+        avg_kernel_s = sum(kernel_ms) / K / 1e3
+    else:                                                    # the calls run back to back on one stream: per call = step time
+        avg_kernel_s = elapsed / K
     avg_alg = sum(alg_bytes[W:]) / K
     achieved = avg_alg / avg_kernel_s / 1e9
     step_achieved = avg_alg / (elapsed / K) / 1e9           # the same bytes over the whole step (all kernels)

@@ -47,9 +47,21 @@ __global__ __launch_bounds__(64) void og_plan_kernel(const OgCeltHdr *__restrict
     for (int p = threadIdx.x; p < (int)(sizeof(OgCeltConst) / 4); p += 64) ((uint32_t *)&K)[p] = ((const uint32_t *)&T->k)[p];
     for (int p = threadIdx.x; p < 184; p += 64) { la[p] = T->lcg_a[p]; lc[p] = T->lcg_c[p]; }
     __syncthreads();
+    // K1's collapse masks (48 words per frame): fetched coalesced, handed back zeroed, and kept over the band energies (energy, prev_min) of
+    // the LDS header copies, which the plan does not read (no extra LDS: 2048 workgroups stay resident at once)
+    static_assert(offsetof(OgCeltHdr, energy) % 4 == 0 && offsetof(OgCeltHdr, band) - offsetof(OgCeltHdr, energy) >= 48 * 4, "room for the masks (over energy + prev_min)");
+    constexpr uint32_t HW = sizeof(OgCeltHdr) / 4, EOFF = offsetof(OgCeltHdr, energy) / 4;
+    for (uint32_t p = threadIdx.x; p < nf * 48; p += 64) {
+        const uint32_t fr = p / 48, j = p - fr * 48;
+        uint32_t *cm = og_work_cm(work, f0 + fr);
+        hs[fr * HW + EOFF + j] = cm[j];
+        cm[j] = 0;
+    }
+    __syncthreads();
     const uint32_t f = f0 + threadIdx.x;
     if (threadIdx.x < OG_PLAN_FPW && f < nframes)
-        og_plan_frame((const OgCeltHdr *)hs + threadIdx.x, leaves, f, K, la, lc, work, OgLaneScratch{sc + threadIdx.x, OG_PLAN_FPW});
+        og_plan_frame<true>((const OgCeltHdr *)hs + threadIdx.x, leaves, f, K, la, lc, work, OgLaneScratch{sc + threadIdx.x, OG_PLAN_FPW},
+                      hs + threadIdx.x * HW + EOFF);
 }
 
 // Frame kernels.  og_celt_kernel: one 256-lane workgroup per frame, stateless (band walk .. IMDCT post-twiddle), five

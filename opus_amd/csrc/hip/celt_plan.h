@@ -284,10 +284,16 @@ OG_DEV OgBandPlan *og_work_plan(void *work, uint32_t frame)
 }
 
 // The plan of frame f: consumes (and re-zeroes) K1's collapse masks.  h = the frame's header (the kernel passes an LDS copy).
+// STAGED: cm_staged holds the frame's 48 collapse-mask words, already fetched (and re-zeroed in `work`) by the caller.
+template <bool STAGED = false>
 OG_DEV void og_plan_frame(const OgCeltHdr *h, const OgCeltLeaf *leaves, uint32_t f, const OgCeltConst &K, const uint32_t *la,
-                          const uint32_t *lc, void *work, OgLaneScratch sc)
+                          const uint32_t *lc, void *work, OgLaneScratch sc, const uint32_t *cm_staged = nullptr)
 {
-    uint32_t *cm = og_work_cm(work, f);
-    og_band_plan(h, leaves + h->leaf_begin, K, la, lc, cm, og_work_coef(work, f), og_work_plan(work, f), sc);
-    for (int i = 0; i < 48; i++) cm[i] = 0;
+    if (STAGED) {
+        og_band_plan(h, leaves + h->leaf_begin, K, la, lc, cm_staged, og_work_coef(work, f), og_work_plan(work, f), sc);
+    } else {
+        uint32_t *cm = og_work_cm(work, f);
+        og_band_plan(h, leaves + h->leaf_begin, K, la, lc, cm, og_work_coef(work, f), og_work_plan(work, f), sc);
+        for (int i = 0; i < 48; i++) cm[i] = 0;
+    }
 }
