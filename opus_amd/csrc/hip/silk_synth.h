@@ -45,16 +45,29 @@ struct OgSilkTables {
 OG_DEV float og_clamp1(float v) { v = v > -1.f ? v : -1.f; return v < 1.f ? v : 1.f; }
 
 // One channel's frame.  `ch` = this channel's record; `slot` = 2*stream + channel.
+// Every loop runs in blocks: a block's loads (which do not depend on the block's own results) are issued together, then
+// the samples are computed in the reference's order, then stored -- the recursions are unchanged, but a lane waits for
+// HBM once per block instead of once per sample.  Block sizes divide every SILK subframe (40 / 60 / 80 samples).
+#define OG_SILK_BLK 20                // LPC synthesis, excitation, history shift
+#define OG_SILK_LTP_BLK 10            // long-term predictor: needs lag - 2 >= block (SILK's shortest lag is 2 ms = 16 samples)
 template <int ORDER>
-OG_DEV void og_silk_channel_t(const OgSilkChan *ch, const OgSilkArrays &A, uint32_t slot)
+OG_DEV void og_silk_channel_t(const OgSilkChan *__restrict__ ch, const OgSilkArrays &A, uint32_t slot)
 {
     const size_t ns = A.nslots;
-    float *out = A.out + slot, *res = A.res + slot, *lpcst = A.lpc + slot;
+    float *__restrict__ out = A.out + slot;
+    float *__restrict__ res = A.res + slot;
+    float *__restrict__ lpcst = A.lpc + slot;
     const int subframes = ch->subframes, sf = ch->sf_size, f_size = subframes * sf;
     const bool voiced = (ch->flags & OG_S_VOICED) != 0, interp = (ch->flags & OG_S_INTERP) != 0;
     const bool factor4 = (ch->flags & OG_S_INTERP4) != 0;
 
-    for (int i = 0; i < f_size; i++) res[(size_t)(OG_SILK_RES_HIST + i) * ns] = (float)ch->excitation[i] / 8388608.0f;   // :1637
+    for (int i0 = 0; i0 < f_size; i0 += OG_SILK_BLK) {                       // :1637
+        int32_t e[OG_SILK_BLK];
+#pragma unroll
+        for (int k = 0; k < OG_SILK_BLK; k++) e[k] = ch->excitation[i0 + k];
+#pragma unroll
+        for (int k = 0; k < OG_SILK_BLK; k++) res[(size_t)(OG_SILK_RES_HIST + i0 + k) * ns] = (float)e[k] / 8388608.0f;
+    }
 
     float h[16];                      // h[0] = most recent unclamped output; always 16 deep: the order may change
 #pragma unroll                        // between frames (bandwidth switch) and the reference keeps the full history
@@ -79,47 +92,99 @@ OG_DEV void og_silk_channel_t(const OgSilkChan *ch, const OgSilkArrays &A, uint3
                 float w[ORDER];                                              // w[k] = out[start + n - 1 - k]
 #pragma unroll
                 for (int k = 0; k < ORDER; k++) w[k] = out[(size_t)(start - 1 - k) * ns];
-                for (int n = 0; n < cnt; n++) {
-                    const float cur = out[(size_t)(start + n) * ns];
-                    float sum = cur;
+                for (int n0 = 0; n0 < cnt; n0 += OG_SILK_LTP_BLK) {
+                    float cur[OG_SILK_LTP_BLK], r[OG_SILK_LTP_BLK];
 #pragma unroll
-                    for (int k = 0; k < ORDER; k++) sum -= a[k] * w[k];
-                    res[(size_t)(start_res + n) * ns] = og_clamp1(sum) * scale / gain;
+                    for (int q = 0; q < OG_SILK_LTP_BLK; q++) cur[q] = n0 + q < cnt ? out[(size_t)(start + n0 + q) * ns] : 0.f;
 #pragma unroll
-                    for (int k = ORDER - 1; k > 0; k--) w[k] = w[k - 1];
-                    w[0] = cur;
+                    for (int q = 0; q < OG_SILK_LTP_BLK; q++) {
+                        float sum = cur[q];
+#pragma unroll
+                        for (int k = 0; k < ORDER; k++) sum -= a[k] * w[k];
+                        r[q] = og_clamp1(sum) * scale / gain;
+#pragma unroll
+                        for (int k = ORDER - 1; k > 0; k--) w[k] = w[k - 1];
+                        w[0] = cur[q];
+                    }
+#pragma unroll
+                    for (int q = 0; q < OG_SILK_LTP_BLK; q++)
+                        if (n0 + q < cnt) res[(size_t)(start_res + n0 + q) * ns] = r[q];
                 }
             }
             if (end != 0) {                                                  // :1830-1841
                 const float rescale = ch->gain[i - 1] / gain;
-                for (int n = OG_SILK_RES_HIST + i * sf - end; n < OG_SILK_RES_HIST + i * sf; n++) res[(size_t)n * ns] *= rescale;
+                const int lo = OG_SILK_RES_HIST + i * sf - end, hi = OG_SILK_RES_HIST + i * sf;     // end: a multiple of sf
+                for (int n0 = lo; n0 < hi; n0 += OG_SILK_BLK) {
+                    float v[OG_SILK_BLK];
+#pragma unroll
+                    for (int q = 0; q < OG_SILK_BLK; q++) v[q] = res[(size_t)(n0 + q) * ns];
+#pragma unroll
+                    for (int q = 0; q < OG_SILK_BLK; q++) res[(size_t)(n0 + q) * ns] = v[q] * rescale;
+                }
             }
             const float t0 = ch->ltp_taps[i][0], t1 = ch->ltp_taps[i][1], t2 = ch->ltp_taps[i][2], t3 = ch->ltp_taps[i][3],
                         t4 = ch->ltp_taps[i][4];
-            for (int n = OG_SILK_RES_HIST + i * sf; n < OG_SILK_RES_HIST + (i + 1) * sf; n++) {   // LTP, :1843-1860
-                const float *r = res + (size_t)(n - lag + 2) * ns;
-                float sum = res[(size_t)n * ns];
-                sum += t0 * r[0];
-                sum += t1 * *(r - ns);
-                sum += t2 * *(r - 2 * ns);
-                sum += t3 * *(r - 3 * ns);
-                sum += t4 * *(r - 4 * ns);
-                res[(size_t)n * ns] = sum;
+            const int nlo = OG_SILK_RES_HIST + i * sf, nhi = OG_SILK_RES_HIST + (i + 1) * sf;
+            if (lag - 2 >= OG_SILK_LTP_BLK) {                                // LTP, :1843-1860, a block at a time: sample n reads
+                for (int n0 = nlo; n0 < nhi; n0 += OG_SILK_LTP_BLK) {        // res[n - lag - 2 .. n - lag + 2], all before the block
+                    float x[OG_SILK_LTP_BLK], p[OG_SILK_LTP_BLK + 4];        // p[m] = res[n0 - lag - 2 + m]
+#pragma unroll
+                    for (int m = 0; m < OG_SILK_LTP_BLK + 4; m++) p[m] = res[(size_t)(n0 - lag - 2 + m) * ns];
+#pragma unroll
+                    for (int q = 0; q < OG_SILK_LTP_BLK; q++) x[q] = res[(size_t)(n0 + q) * ns];
+#pragma unroll
+                    for (int q = 0; q < OG_SILK_LTP_BLK; q++) {
+                        float sum = x[q];
+                        sum += t0 * p[q + 4];
+                        sum += t1 * p[q + 3];
+                        sum += t2 * p[q + 2];
+                        sum += t3 * p[q + 1];
+                        sum += t4 * p[q];
+                        x[q] = sum;
+                    }
+#pragma unroll
+                    for (int q = 0; q < OG_SILK_LTP_BLK; q++) res[(size_t)(n0 + q) * ns] = x[q];
+                }
+            } else {                                                         // (a lag the bitstream cannot code: sample by sample)
+                for (int n = nlo; n < nhi; n++) {
+                    const float *r = res + (size_t)(n - lag + 2) * ns;
+                    float sum = res[(size_t)n * ns];
+                    sum += t0 * r[0];
+                    sum += t1 * *(r - ns);
+                    sum += t2 * *(r - 2 * ns);
+                    sum += t3 * *(r - 3 * ns);
+                    sum += t4 * *(r - 4 * ns);
+                    res[(size_t)n * ns] = sum;
+                }
             }
         }
-        for (int j = 0; j < sf; j++) {                                       // LPC synthesis, :1864-1884
-            float sum = res[(size_t)(OG_SILK_RES_HIST + i * sf + j) * ns] * gain;
+        for (int j0 = 0; j0 < sf; j0 += OG_SILK_BLK) {                       // LPC synthesis, :1864-1884
+            float x[OG_SILK_BLK];
 #pragma unroll
-            for (int k = 0; k < ORDER; k++) sum += a[k] * h[k];
+            for (int q = 0; q < OG_SILK_BLK; q++) x[q] = res[(size_t)(OG_SILK_RES_HIST + i * sf + j0 + q) * ns];
 #pragma unroll
-            for (int k = 15; k > 0; k--) h[k] = h[k - 1];
-            h[0] = sum;
-            out[(size_t)(OG_SILK_HIST + i * sf + j) * ns] = og_clamp1(sum);
+            for (int q = 0; q < OG_SILK_BLK; q++) {
+                float sum = x[q] * gain;
+#pragma unroll
+                for (int k = 0; k < ORDER; k++) sum += a[k] * h[k];
+#pragma unroll
+                for (int k = 15; k > 0; k--) h[k] = h[k - 1];
+                h[0] = sum;
+                x[q] = og_clamp1(sum);
+            }
+#pragma unroll
+            for (int q = 0; q < OG_SILK_BLK; q++) out[(size_t)(OG_SILK_HIST + i * sf + j0 + q) * ns] = x[q];
         }
     }
 #pragma unroll
     for (int k = 0; k < 16; k++) lpcst[(size_t)(15 - k) * ns] = h[k];
-    for (int i = 0; i < OG_SILK_HIST; i++) out[(size_t)i * ns] = out[(size_t)(i + f_size) * ns];     // :1891-1898
+    for (int i0 = 0; i0 < OG_SILK_HIST; i0 += 14) {                          // :1891-1898 (322 = 23 * 14; reads run ahead of writes)
+        float v[14];
+#pragma unroll
+        for (int q = 0; q < 14; q++) v[q] = out[(size_t)(i0 + q + f_size) * ns];
+#pragma unroll
+        for (int q = 0; q < 14; q++) out[(size_t)(i0 + q) * ns] = v[q];
+    }
 }
 
 // Dispatch for lane `idx` of a launch over 2*nframes (frame, channel) pairs.
