@@ -193,23 +193,29 @@ int opusgpu_launch_celt_pvq(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, uint
     if (debug) dbg = *debug;
     hipStream_t st = (hipStream_t)stream;
     // K1: one launch per size class (refs are sorted by decreasing N): the many small leaves do not pay the 45 KB of
-    // LDS per wavefront that the few 176-wide ones need.  The first class present runs on the caller's stream, the
-    // others on the side streams, forked from and joined back into the caller's stream with events.
+    // LDS per wavefront that the few 176-wide ones need.  The classes are dealt round-robin to the caller's stream and
+    // the side streams (three by default: every class on its own stream; OPUSGPU_K1_SIDE_STREAMS = 0..3 for callers that
+    // need the hardware queues for streams of their own), forked from and joined back into the caller's stream with events.
     {
+        static const int nside = [] { const char *e = getenv("OPUSGPU_K1_SIDE_STREAMS"); int n = e ? atoi(e) : 3; return n < 0 ? 0 : n > 3 ? 3 : n; }();
         std::lock_guard<std::mutex> lk(og::g_fork_mu);
         int nclasses = 0;
         for (int c = 0; c < 4; c++) nclasses += class_counts[c] != 0;
-        if (nclasses > 1) OG_HIP(hipEventRecord(ctx->fork, st));
+        const bool fork = nclasses > 1 && nside > 0;
+        if (fork) OG_HIP(hipEventRecord(ctx->fork, st));
         const OgLeafRef *r = refs;
-        int used = 0;
-        bool first = true;
+        bool used[3] = {false, false, false};
+        int idx = 0;
         for (int c = 0; c < 4; c++) {
             const uint32_t cnt = class_counts[c];
             if (!cnt) continue;
+            const int lane = fork ? idx % (nside + 1) : 0;      // 0 = the caller's stream
+            idx++;
             hipStream_t cur = st;
-            if (!first) {
-                cur = ctx->side[used];
-                OG_HIP(hipStreamWaitEvent(cur, ctx->fork, 0));
+            if (lane) {
+                cur = ctx->side[lane - 1];
+                if (!used[lane - 1]) OG_HIP(hipStreamWaitEvent(cur, ctx->fork, 0));
+                used[lane - 1] = true;
             }
 #define OG_PVQ_LAUNCH(NMAX, WGS)                                                                                          \
             hipLaunchKernelGGL(HIP_KERNEL_NAME(og_pvq_kernel<NMAX, WGS>), dim3((cnt + (WGS) - 1) / (WGS)), dim3(WGS), 0, cur, r, cnt, \
@@ -221,11 +227,13 @@ int opusgpu_launch_celt_pvq(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, uint
             default: OG_PVQ_LAUNCH(8, 256); break;
             }
 #undef OG_PVQ_LAUNCH
-            if (!first) OG_HIP(hipEventRecord(ctx->join[used++], cur));
-            first = false;
             r += cnt;
         }
-        for (int k = 0; k < used; k++) OG_HIP(hipStreamWaitEvent(st, ctx->join[k], 0));
+        for (int k = 0; k < 3; k++)
+            if (used[k]) {
+                OG_HIP(hipEventRecord(ctx->join[k], ctx->side[k]));
+                OG_HIP(hipStreamWaitEvent(st, ctx->join[k], 0));
+            }
     }
     hipLaunchKernelGGL(og_plan_kernel, dim3((nframes + OG_PLAN_FPW - 1) / OG_PLAN_FPW), dim3(64), 0, st, hdr, leaves, nframes, T, work);
     OG_HIP(hipGetLastError());
