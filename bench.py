@@ -40,7 +40,9 @@ def parse_args():
     ap.add_argument("--streams", type=int, default=STREAMS_PER_GPU, help="streams per GPU (BASELINE: 4096)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pipeline", action="store_true",
-                    help="overlap the first half (K1 + plan) of step k+1 with the frame kernel of step k on two streams")
+                    help="EXPERIMENTAL: overlap the first half (K1 + plan) of step k+1 with the frame kernels of step k on two "
+                         "streams; no gain measured, and cross-stream waits can deadlock when HIP streams share a hardware "
+                         "queue (DESIGN.md section 5): not used for any reported number")
     return ap.parse_args()
 
 
