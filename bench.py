@@ -41,8 +41,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pipeline", action="store_true",
                     help="EXPERIMENTAL: overlap the first half (K1 + plan) of step k+1 with the frame kernels of step k on two "
-                         "streams; no gain measured, and cross-stream waits can deadlock when HIP streams share a hardware "
-                         "queue (DESIGN.md section 5): not used for any reported number")
+                         "streams; no gain measured (DESIGN.md section 5): not used for any reported number")
     return ap.parse_args()
 
 

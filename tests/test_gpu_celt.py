@@ -181,8 +181,8 @@ def test_full_size_properties():
 
 def test_split_launches_match_single_call():
     """opusgpu_launch_celt_pvq / _spectrum / _tail issued separately, alternating two scratch buffers (the way a caller
-    pipelines consecutive batches), give bit-identical PCM to the one-call launch.  Everything runs on one stream: HIP
-    streams share hardware queues, so a test must not depend on cross-stream waits."""
+    pipelines consecutive batches), give bit-identical PCM to the one-call launch.  Everything runs on one stream (the
+    test is about the split, not about overlap)."""
     import torch
     lib = A.load()
     dev = torch.device("cuda:0")
