@@ -40,8 +40,8 @@ def parse_args():
     ap.add_argument("--streams", type=int, default=STREAMS_PER_GPU, help="streams per GPU (BASELINE: 4096)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pipeline", action="store_true",
-                    help="EXPERIMENTAL: overlap the first half (K1 + plan) of step k+1 with the frame kernels of step k on two "
-                         "streams; no gain measured (DESIGN.md section 5): not used for any reported number")
+                    help="EXPERIMENTAL: the stateless chain (K1, plan, og_celt_kernel) of step k+1 on one stream, the tail kernel of step k on "
+                         "another; 1-2 %% measured (DESIGN.md section 5): not used for any reported number")
     return ap.parse_args()
 
 
@@ -159,7 +159,7 @@ def main():
     stride = T * 960 * 2
     pcm = torch.zeros(S * stride, dtype=torch.float32, device=dev)
     # the first half is short and on the critical path of the next frame kernel: its stream ranks first for free CU slots
-    s_pvq, s_frm = torch.cuda.Stream(dev, priority=-1), torch.cuda.Stream(dev)
+    s_pvq, s_frm = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
     p_pvq, p_frm = C.c_void_p(s_pvq.cuda_stream), C.c_void_p(s_frm.cuda_stream)
     ready = [torch.cuda.Event() for _ in range(nsteps)]
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nsteps)]
@@ -182,16 +182,18 @@ def main():
             check(lib.opusgpu_launch_celt_tail(hdr_dev[f].data_ptr(), S * T, T, w.data_ptr(), state.data_ptr(), pcm.data_ptr(), stride,
                                                None, p_frm))
             return
+        # pipelined: the stateless chain K1 -> plan -> og_celt_kernel of step f on one stream, the tail kernels (which carry
+        # the decoder state, in order) on another: tail(f) overlaps the stateless chain of step f + 1
         if f >= 2:
-            s_pvq.wait_event(ev[f - 2][1])              # the scratch buffer is free once frames(f-2) has consumed it
+            s_pvq.wait_event(ev[f - 2][1])              # the scratch buffer is free once tail(f-2) has consumed it
         check(lib.opusgpu_launch_celt_pvq(hdr_dev[f].data_ptr(), leaf_dev[f].data_ptr(), S * T, ref_dev[f].data_ptr(), ref_classes[f],
                                           w.data_ptr(), None, p_pvq))
+        evk[f][0].record(s_pvq)
+        check(lib.opusgpu_launch_celt_spectrum(hdr_dev[f].data_ptr(), S * T, w.data_ptr(), None, p_pvq))
+        evk[f][1].record(s_pvq)
         ready[f].record(s_pvq)
         s_frm.wait_event(ready[f])
         ev[f][0].record(s_frm)
-        evk[f][0].record(s_frm)
-        check(lib.opusgpu_launch_celt_spectrum(hdr_dev[f].data_ptr(), S * T, w.data_ptr(), None, p_frm))
-        evk[f][1].record(s_frm)
         check(lib.opusgpu_launch_celt_tail(hdr_dev[f].data_ptr(), S * T, T, w.data_ptr(), state.data_ptr(), pcm.data_ptr(), stride,
                                            None, p_frm))
         ev[f][1].record(s_frm)

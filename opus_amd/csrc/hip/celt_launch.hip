@@ -118,7 +118,9 @@ int device_fail(hipError_t e, const char *what)
 struct DevCtx {
     OgCeltTables *tables = nullptr;
     hipStream_t side[3] = {nullptr, nullptr, nullptr};
-    hipEvent_t fork = nullptr, join[3] = {nullptr, nullptr, nullptr};
+    enum { RING = 8 };                  // fork / join event sets, used in turn: an event is not re-recorded while waits on its
+    hipEvent_t fork[RING] = {}, join[RING][3] = {};     // previous record may still be queued
+    unsigned turn = 0;
 };
 static std::mutex g_tables_mu;
 static std::mutex g_fork_mu;            // fork / join sequences on the shared side streams are enqueued one launch at a time
@@ -140,11 +142,19 @@ static int ctx_for_device(int device, DevCtx **out)
         delete host;
         int prio_lo = 0, prio_hi = 0;                    // K1 is short and on the critical path: its streams rank first
         if (e == hipSuccess) e = hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-        for (int k = 0; k < 3 && e == hipSuccess; k++) {
-            e = hipStreamCreateWithPriority(&c.side[k], hipStreamNonBlocking, prio_hi);
-            if (e == hipSuccess) e = hipEventCreateWithFlags(&c.join[k], hipEventDisableTiming);
+        // Normal priority by default.  High priority (OPUSGPU_K1_STREAM_PRIORITY=high) measured 2 % faster in bench.py's
+        // single-stream flow (the runtime then gives every side stream a hardware queue of its own; streams that share one
+        // run one after the other), but a high-priority stream parked on an event wait can keep the command processor from
+        // serving the other queues: depending on how the process's streams fall onto the four hardware queues, the launch
+        // then never finishes (tools/pipeline_probe.py reproduces it).  Not worth a hang.
+        const char *pe = getenv("OPUSGPU_K1_STREAM_PRIORITY");
+        const bool high = pe && pe[0] == 'h';
+        for (int k = 0; k < 3 && e == hipSuccess; k++)
+            e = high ? hipStreamCreateWithPriority(&c.side[k], hipStreamNonBlocking, prio_hi) : hipStreamCreateWithFlags(&c.side[k], hipStreamNonBlocking);
+        for (int r = 0; r < DevCtx::RING && e == hipSuccess; r++) {
+            e = hipEventCreateWithFlags(&c.fork[r], hipEventDisableTiming);
+            for (int k = 0; k < 3 && e == hipSuccess; k++) e = hipEventCreateWithFlags(&c.join[r][k], hipEventDisableTiming);
         }
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&c.fork, hipEventDisableTiming);
         (void)hipSetDevice(prev);
         if (e != hipSuccess) return device_fail(e, "celt device set-up");
         c.tables = dev;
@@ -194,27 +204,29 @@ int opusgpu_launch_celt_pvq(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, uint
     hipStream_t st = (hipStream_t)stream;
     // K1: one launch per size class (refs are sorted by decreasing N): the many small leaves do not pay the 45 KB of
     // LDS per wavefront that the few 176-wide ones need.  The classes are dealt round-robin to the caller's stream and
-    // the side streams (three by default: every class on its own stream; OPUSGPU_K1_SIDE_STREAMS = 0..3 for callers that
-    // need the hardware queues for streams of their own), forked from and joined back into the caller's stream with events.
+    // the side streams (three by default, OPUSGPU_K1_SIDE_STREAMS = 0..3), forked from and joined back into the caller's
+    // stream with events (a ring of event sets, so none is re-recorded while a wait on it may still be queued).
     {
         static const int nside = [] { const char *e = getenv("OPUSGPU_K1_SIDE_STREAMS"); int n = e ? atoi(e) : 3; return n < 0 ? 0 : n > 3 ? 3 : n; }();
         std::lock_guard<std::mutex> lk(og::g_fork_mu);
         int nclasses = 0;
         for (int c = 0; c < 4; c++) nclasses += class_counts[c] != 0;
         const bool fork = nclasses > 1 && nside > 0;
-        if (fork) OG_HIP(hipEventRecord(ctx->fork, st));
+        const unsigned ring = ctx->turn++ % og::DevCtx::RING;
+        if (fork) OG_HIP(hipEventRecord(ctx->fork[ring], st));
         const OgLeafRef *r = refs;
         bool used[3] = {false, false, false};
         int idx = 0;
         for (int c = 0; c < 4; c++) {
             const uint32_t cnt = class_counts[c];
             if (!cnt) continue;
-            const int lane = fork ? idx % (nside + 1) : 0;      // 0 = the caller's stream
+            static const int lane_of[4][4] = {{0, 0, 0, 0}, {0, 1, 0, 1}, {0, 1, 1, 2}, {0, 1, 2, 3}};   // [side streams][class]
+            const int lane = fork ? lane_of[nside][c] : 0;      // 0 = the caller's stream
             idx++;
             hipStream_t cur = st;
             if (lane) {
                 cur = ctx->side[lane - 1];
-                if (!used[lane - 1]) OG_HIP(hipStreamWaitEvent(cur, ctx->fork, 0));
+                if (!used[lane - 1]) OG_HIP(hipStreamWaitEvent(cur, ctx->fork[ring], 0));
                 used[lane - 1] = true;
             }
 #define OG_PVQ_LAUNCH(NMAX, WGS)                                                                                          \
@@ -231,8 +243,8 @@ int opusgpu_launch_celt_pvq(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, uint
         }
         for (int k = 0; k < 3; k++)
             if (used[k]) {
-                OG_HIP(hipEventRecord(ctx->join[k], ctx->side[k]));
-                OG_HIP(hipStreamWaitEvent(st, ctx->join[k], 0));
+                OG_HIP(hipEventRecord(ctx->join[ring][k], ctx->side[k]));
+                OG_HIP(hipStreamWaitEvent(st, ctx->join[ring][k], 0));
             }
     }
     hipLaunchKernelGGL(og_plan_kernel, dim3((nframes + OG_PLAN_FPW - 1) / OG_PLAN_FPW), dim3(64), 0, st, hdr, leaves, nframes, T, work);
