@@ -28,6 +28,40 @@ __global__ __launch_bounds__(WGS) void og_pvq_kernel(const OgLeafRef *__restrict
         og_pvq_lane(refs[g], hdr, leaves, nframes, work, U2, x + (threadIdx.x >> 6) * (NMAX * 64) + (threadIdx.x & 63), 64, dbg_pulses, stamps);
 }
 
+// K1, all four size classes in one launch (the default): 256-thread workgroups, each serving one class with as many lanes as
+// fit a common LDS budget -- 16 lanes for N <= 176, 32 for N <= 64, 128 for N <= 24, 256 for N <= 8 (12 KB of vectors + the
+// 10.6 KB U table: seven workgroups per CU); wavefronts without a leaf leave at once.  A wave's vectors are interleaved
+// with the stride of its live lanes (16 / 32 / 64: still one bank per lane).  No side streams, no fork / join events.
+struct OgPvqClasses { uint32_t cnt[4], wg0[4]; };      // leaves per class (largest first); first workgroup of each class
+__global__ __launch_bounds__(256) void og_pvq_all_kernel(const OgLeafRef *__restrict__ refs, OgPvqClasses cl,
+                                                         const OgCeltHdr *__restrict__ hdr, const OgCeltLeaf *__restrict__ leaves,
+                                                         uint32_t nframes, const OgCeltTables *__restrict__ T, void *work,
+                                                         int16_t *dbg_pulses, uint64_t *dbg_cycles)
+{
+    __shared__ uint32_t U2[15 * OG_U2_STRIDE];
+    __shared__ float x[3072];                           // 176 * 16 = 2816, 64 * 32 = 2048, 24 * 128 = 3072, 8 * 256 = 2048
+    const uint32_t b = blockIdx.x, tid = threadIdx.x;
+    const int c = b >= cl.wg0[3] ? 3 : b >= cl.wg0[2] ? 2 : b >= cl.wg0[1] ? 1 : 0;
+    const uint32_t lanes = c == 0 ? 16u : c == 1 ? 32u : c == 2 ? 128u : 256u;
+    if (tid >= ((lanes + 63u) & ~63u)) return;          // whole wavefronts with nothing to do (no barrier after this point for them)
+    const uint32_t nw = (lanes + 63u) >> 6;             // wavefronts that stay: they share the table
+    for (uint32_t p = tid; p < 15 * OG_U2_STRIDE; p += 64 * nw) U2[p] = T->pvq_u2[p];
+    __syncthreads();                                    // wavefronts that have ended no longer take part in the barrier
+    uint32_t base = 0;
+    for (int k = 0; k < c; k++) base += cl.cnt[k];
+    const uint32_t g = (b - cl.wg0[c]) * lanes + tid;
+    if (tid >= lanes || g >= cl.cnt[c]) return;
+    const int nmax = c == 0 ? 176 : c == 1 ? 64 : c == 2 ? 24 : 8;
+    uint64_t *stamps = dbg_cycles && tid == 0 && (b - cl.wg0[c]) < 4096 ? dbg_cycles + (size_t)nframes * 64 + ((size_t)nmax * 4096 + (b - cl.wg0[c])) * 4 : nullptr;
+    const OgLeafRef ref = refs[base + g];
+    switch (c) {
+    case 0: og_pvq_lane(ref, hdr, leaves, nframes, work, U2, x + tid, 16, dbg_pulses, stamps); break;
+    case 1: og_pvq_lane(ref, hdr, leaves, nframes, work, U2, x + tid, 32, dbg_pulses, stamps); break;
+    case 2: og_pvq_lane(ref, hdr, leaves, nframes, work, U2, x + (tid >> 6) * (24 * 64) + (tid & 63), 64, dbg_pulses, stamps); break;
+    default: og_pvq_lane(ref, hdr, leaves, nframes, work, U2, x + (tid >> 6) * (8 * 64) + (tid & 63), 64, dbg_pulses, stamps); break;
+    }
+}
+
 // Band plan: one lane per frame (celt_plan.h), OG_PLAN_FPW frames per wavefront.  The per-lane code is one long serial
 // chain, so what it reads and indexes sits in LDS: the workgroup's headers (copied in coalesced; a lane's header is 167
 // dwords from its neighbour's, an odd stride, so the lanes' reads fall on distinct banks), the small constant tables, and
@@ -202,6 +236,14 @@ int opusgpu_launch_celt_pvq(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, uint
     OgCeltDebug dbg = {nullptr, nullptr, nullptr, nullptr, nullptr};
     if (debug) dbg = *debug;
     hipStream_t st = (hipStream_t)stream;
+    static const bool fused = [] { const char *e = getenv("OPUSGPU_K1_FUSED"); return !(e && e[0] == '0'); }();
+    if (fused && nrefs) {                               // K1 as one launch (og_pvq_all_kernel); the per-class launches below stay
+        OgPvqClasses cl;                                // selectable (OPUSGPU_K1_FUSED=0) for comparison
+        static const uint32_t lanes[4] = {16, 32, 128, 256};
+        uint32_t wg = 0;
+        for (int c = 0; c < 4; c++) { cl.cnt[c] = class_counts[c]; cl.wg0[c] = wg; wg += (class_counts[c] + lanes[c] - 1) / lanes[c]; }
+        hipLaunchKernelGGL(og_pvq_all_kernel, dim3(wg), dim3(256), 0, st, refs, cl, hdr, leaves, nframes, T, work, dbg.pulses, dbg.cycles);
+    } else
     // K1: one launch per size class (refs are sorted by decreasing N): the many small leaves do not pay the 45 KB of
     // LDS per wavefront that the few 176-wide ones need.  The classes are dealt round-robin to the caller's stream and
     // the side streams (three by default, OPUSGPU_K1_SIDE_STREAMS = 0..3), forked from and joined back into the caller's
