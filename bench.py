@@ -247,12 +247,12 @@ def main():
                        "streams_per_gpu": S, "frame_ms": 20, "frames_per_stream_per_step": T, "payload_bytes": PAYLOAD,
                        "parallelism": f"streams sharded over {world} GPU(s), no collective",
                        "pipelined": bool(a.pipeline)},
-            # the launch = every kernel of one opusgpu_launch_celt (4 K1 size classes, plan, og_celt_kernel, og_celt_tail_kernel),
+            # the launch = every kernel of one opusgpu_launch_celt (K1, plan, og_celt_kernel, og_celt_tail_kernel),
             # priced with SURVEY 8(d)'s per-frame bytes; `dominant` = og_celt_kernel alone (52 % of the launch) with the bytes it
             # moves by design (side-info + energies 1724, K1 row in 7680, sample row out 7680)
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "kernel": ("one opusgpu_launch_celt call: og_pvq_kernel x4 + og_plan_kernel + og_celt_kernel + og_celt_tail_kernel"
+                         "kernel": ("one opusgpu_launch_celt call: og_pvq_all_kernel + og_plan_kernel + og_celt_kernel + og_celt_tail_kernel"
                                     if (not a.pipeline) else "og_celt_kernel + og_celt_tail_kernel; K1 + plan of the next step overlap them"),
                          "avg_launch_us": round(avg_kernel_s * 1e6, 2),
                          "algorithmic_bytes_per_launch": int(avg_alg),

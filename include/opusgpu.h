@@ -188,7 +188,7 @@ typedef struct {               /* optional stage dumps for parity tests; any poi
 int opusgpu_init(int device);
 
 /* CELT, four kernel stages per launch:
- *   K1  og_pvq_kernel (one launch per leaf size class): one lane per PVQ leaf (refs[], sorted by size across the whole
+ *   K1  og_pvq_all_kernel (one launch; its workgroups each serve one leaf size class): one lane per PVQ leaf (refs[], sorted by size across the whole
  *       batch so that the lanes of a wavefront run the same trip counts): CWRS index -> pulses, normalise, spreading
  *       rotation, collapse mask (celt/decoder.rs:541-786); writes the shaped coefficients to the `work` scratch.
  *   plan  og_plan_kernel: one lane per frame: the integer half of decode_bands (celt/decoder.rs:2037-2220): which
