@@ -40,7 +40,18 @@ __global__ __launch_bounds__(256) void og_pvq_all_kernel(const OgLeafRef *__rest
 {
     __shared__ uint32_t U2[15 * OG_U2_STRIDE];
     __shared__ float x[3072];                           // 176 * 16 = 2816, 64 * 32 = 2048, 24 * 128 = 3072, 8 * 256 = 2048
-    const uint32_t b = blockIdx.x, tid = threadIdx.x;
+    // Workgroup order: the two large classes keep one 16 / 32-lane wavefront busy for ~100 us each while holding a full
+    // workgroup's LDS, so they are dealt one in three among the small-class workgroups from the start of the grid (every CU
+    // then runs a mix) instead of all first.  cl.wg0[] is the sequential numbering; `b` below is the position in it.
+    const uint32_t tid = threadIdx.x;
+    uint32_t b = blockIdx.x;
+    {
+        const uint32_t nbig = cl.wg0[2], nall = gridDim.x;
+        if (nall - nbig >= 2 * nbig) {
+            if (b < 3 * nbig) b = (b % 3 == 0) ? b / 3 : nbig + (b - b / 3 - 1);
+            // else: b already counts nbig large + (b - nbig) small ones before it
+        }
+    }
     const int c = b >= cl.wg0[3] ? 3 : b >= cl.wg0[2] ? 2 : b >= cl.wg0[1] ? 1 : 0;
     const uint32_t lanes = c == 0 ? 16u : c == 1 ? 32u : c == 2 ? 128u : 256u;
     if (tid >= ((lanes + 63u) & ~63u)) return;          // whole wavefronts with nothing to do (no barrier after this point for them)
