@@ -146,3 +146,30 @@ def test_synth_generator_is_deterministic_per_stream():
     b = synth.celt_fb_stereo_packets([9], 3, 160)
     assert np.array_equal(a[1], b[0]) and not np.array_equal(a[0], a[1])
     assert (a[:, :, 0] == 0xFC).all() and a.shape == (2, 3, 161)
+
+
+def test_sort_pvq_leaves_orders_by_size_then_pulses():
+    """opusgpu_sort_pvq_leaves (host helper of the K1 launch): every PVQ leaf (K > 0, N > 1) exactly once, key
+    (N, min(K, 63)) non-increasing, class counts = leaves with N > 64 / > 24 / > 8 / the rest"""
+    lib = A.load()
+    hp = HostParser(2)
+    pk = synth.celt_fb_stereo_packets(range(4), 6, 160)
+    N1 = 64                                              # OG_L_N1 (include/opusgpu_sideinfo.h)
+    for s in range(4):
+        for f in range(6):
+            n, nc, nl, _ = hp.parse(pk[s, f].tobytes())
+            assert n == 1 and nc == 1
+            refs = (A.LeafRef * max(nl, 1))()
+            classes = (C.c_uint32 * 4)()
+            got = lib.opusgpu_sort_pvq_leaves(hp.celt, 1, hp.leaves, refs, nl, classes)
+            leaves = [hp.leaves[i] for i in range(nl)]
+            want = [i for i, lf in enumerate(leaves) if lf.k and not (lf.meta & N1)]
+            assert got == len(want) and sorted(refs[i].leaf for i in range(got)) == want
+            keys = [(leaves[refs[i].leaf].n, min(leaves[refs[i].leaf].k, 63)) for i in range(got)]
+            assert keys == sorted(keys, reverse=True)
+            ns = [leaves[i].n for i in want]
+            assert list(classes) == [sum(x > 64 for x in ns), sum(24 < x <= 64 for x in ns), sum(8 < x <= 24 for x in ns), sum(x <= 8 for x in ns)]
+            assert all(refs[i].frame == 0 for i in range(got))
+            # a buffer that is too small is refused, not overrun
+            if got:
+                assert lib.opusgpu_sort_pvq_leaves(hp.celt, 1, hp.leaves, refs, got - 1, classes) == 0
