@@ -874,42 +874,25 @@ OG_DEV void og_celt_spectrum(const OgCeltHdr *hg, const OgBandPlan *plan, const 
             break;
         }
         (void)dst;
-        // `src` now holds the spectrum.  Post-twiddle into registers, past the barrier into X in time order (either FFT
-        // buffer may be the source), then out to the frame's scratch row in 16-byte pieces.
-        struct OgPost { float r[4], i[4]; };
-        OG_LANE_VAR(OgPost, pv);
+        // `src` now holds the spectrum.  Post-twiddle, and straight out to the frame's scratch row in time order: each lane's
+        // samples land 8 bytes apart (even positions ascending, odd ones descending), so a wavefront's two stores fill the
+        // same cache lines and merge in L2; cheaper for this VALU-bound kernel than a second pass through LDS.
         OG_LANES_BEGIN(tid)
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int q = tid + j * OG_WG;
-            OG_LV(pv).r[j] = OG_LV(pv).i[j] = 0.f;
             if (q < CC * (N >> 1)) {
                 const OgCf Z = src[q], w = OG_LV(twr).w[j];
-                OG_LV(pv).r[j] = Z.r * w.r + Z.i * w.i;
-                OG_LV(pv).i[j] = Z.i * w.r - Z.r * w.i;
-            }
-        }
-        OG_LANES_END
-        OG_LANES_BEGIN(tid)
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int q = tid + j * OG_WG;
-            if (q < CC * (N >> 1)) {
+                const float vr = Z.r * w.r + Z.i * w.i, vi = Z.i * w.r - Z.r * w.i;
                 const int t = q & tmask, k = q >> tsh, ch = t >> bsh, b = t & (B - 1);
-                float *D = &L.X[ch][OG_MUL24(NB, b)];
-                D[2 * k] = OG_LV(pv).i[j];
-                D[NB - 1 - 2 * k] = -OG_LV(pv).r[j];
+                float *D = coef_row + ch * 960 + OG_MUL24(NB, b);
+                D[2 * k] = vi;
+                D[NB - 1 - 2 * k] = -vr;
             }
         }
         OG_LANES_END
     }
     OG_STAMP(11)
-    OG_LANES_BEGIN(tid)
-    for (int q = tid; q < CC * (N >> 2); q += OG_WG) {
-        const int ch = q >= (N >> 2), i = q - ch * (N >> 2);
-        ((OgF4 *)coef_row)[ch * 240 + i] = ((const OgF4 *)&L.X[ch][0])[i];
-    }
-    OG_LANES_END
     OG_STAMP(13)
 }
 
