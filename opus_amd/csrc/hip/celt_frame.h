@@ -344,7 +344,7 @@ OG_DEV void og_fill_op(OgBandCtx &c, int k, int w, int task_pos)     // task_pos
     if (!(op.flags & OG_OP_FOLD)) {                     // noise (celt/decoder.rs:1644-1651)
         OG_WAVE_BEGIN(lane)
         float e = 0.f;
-        uint32_t s = og_lcg_jump((uint32_t)lane + 1u, s0);
+        uint32_t s = og_lcg_jump<7>((uint32_t)lane + 1u, s0);   // lane + 1 <= 64
         for (int p = lane; p < nn; p += 64) {
             const float v = (float)((int32_t)s >> 20);
             xl[p] = v;
@@ -356,7 +356,7 @@ OG_DEV void og_fill_op(OgBandCtx &c, int k, int w, int task_pos)     // task_pos
     } else {                                            // fold the lower band in (celt/decoder.rs:1652-1659)
         OG_WAVE_BEGIN(lane)
         float e = 0.f;
-        uint32_t s = og_lcg_jump((uint32_t)lane + 1u, s0);
+        uint32_t s = og_lcg_jump<7>((uint32_t)lane + 1u, s0);   // lane + 1 <= 64
         for (int p = lane; p < nn; p += 64) {
             const float v = lbl[p] + ((s & 0x8000) ? 1.f / 256 : -1.f / 256);
             xl[p] = v;
