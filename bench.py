@@ -3,13 +3,17 @@
 synthetic CELT-only fullband 48 kHz stereo 20 ms frames, 4096 streams per MI355X (weak scaling over GPUs).
 
 A step = one pass of the hot path over one batch: the next T consecutive 20 ms frames (default T = 8, 160 ms of
-audio) of each of the 4096 streams through the C ABI (layer 3b): opusgpu_launch_celt_pvq (the K1 PVQ kernels over all
-4096*T frames' leaves + the band-plan kernel) and opusgpu_launch_celt_frames (the K2+K3 kernel, one workgroup per stream
-walking its T frames in time order), issued as one opusgpu_launch_celt call per step on one stream.  --pipeline issues
-the two halves separately and lets the first half of step k+1 (which touches no decoder state) run on its own stream and
-scratch buffer while the frame kernel of step k is still busy (measured: no gain on MI355X, the frame kernel's workgroups
-hold all of the LDS, so the other kernels only get on a CU when it drains).  Inputs (side-info records, pre-parsed by the host layer) are resident in HBM before the timed region; PCM and
-decoder state stay in HBM.  --frames-per-step 1 gives the one-frame-per-call figure.  Prints ONE JSON line on rank 0.
+audio) of each of the 4096 streams through the C ABI (layer 3b), i.e. one opusgpu_launch_celt per step on one stream,
+issued as its three parts (opusgpu_launch_celt_pvq: the K1 PVQ kernel over all 4096*T frames' leaves + the band-plan
+kernel; opusgpu_launch_celt_spectrum: the stateless frame kernel, one workgroup per frame; opusgpu_launch_celt_tail: one
+workgroup per stream walking its T frames in time order) so that HIP events on the launching stream bracket the dominant
+kernel.  Inputs (side-info records, pre-parsed by the host layer) are resident in HBM before the timed region; PCM and
+decoder state stay in HBM.  --frames-per-step 1 gives the one-frame-per-call figure.  After the timed region the last
+step's PCM of a sample of streams is compared with the CPU oracle ("verified").
+
+--gpus N > 1 without a torch.distributed environment starts N ranks itself (torch.distributed.run, one process per GPU,
+before this process touches a GPU); RCCL is used only for the barrier and the max over the ranks' elapsed times.
+Prints ONE JSON line on rank 0.
 """
 import argparse
 import ctypes as C
@@ -39,10 +43,25 @@ def parse_args():
     ap.add_argument("--frames-per-step", type=int, default=8, help="consecutive frames of every stream decoded per step")
     ap.add_argument("--streams", type=int, default=STREAMS_PER_GPU, help="streams per GPU (BASELINE: 4096)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--pipeline", action="store_true",
-                    help="EXPERIMENTAL: the stateless chain (K1, plan, og_celt_kernel) of step k+1 on one stream, the tail kernel of step k on "
-                         "another; 1-2 %% measured (DESIGN.md section 5): not used for any reported number")
+    ap.add_argument("--no-verify", action="store_true", help="skip the oracle comparison of the last step's PCM")
+    ap.add_argument("--parse-only", action="store_true",
+                    help="host half only (packets -> side-info through the C ABI parser), no GPU; with --backend gloo this is "
+                         "the CPU rehearsal of the N-rank path (tests/test_sharding_gloo.py)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL)")
     return ap.parse_args()
+
+
+def spawn_ranks(a):
+    """--gpus N > 1 outside torch.distributed.run: start N ranks (one process per GPU) and pass their exit code on.
+    Runs before this process has made any GPU call; the ranks are child processes, not an exec."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
 
 
 def cpu_baseline(packets, budget_s=12.0):
@@ -90,19 +109,75 @@ def cpu_baseline(packets, budget_s=12.0):
     return out
 
 
+def parse_only(a, rank, world):
+    """The N-rank path without a GPU: every rank parses its shard of the streams on the host (layer 3a) and the ranks
+    meet for the barrier and the max, exactly as the GPU path does."""
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from gpu_util import HostParser
+    from opus_amd import sharding, synth
+    S, K, T = a.streams, a.steps, a.frames_per_step
+    ids = sharding.shard_stream_ids(rank, world, S)
+    packets = synth.celt_fb_stereo_packets(ids, K * T, PAYLOAD)
+    parsers = [HostParser(2) for _ in range(S)]
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    leaves = 0
+    for f in range(K * T):
+        for s in range(S):
+            n, nc, nl, _ = parsers[s].parse(packets[s, f].tobytes())
+            assert n == 1 and nc == 1
+            leaves += nl
+    if world > 1:
+        dist.barrier()
+    elapsed = sharding.max_over_ranks(time.perf_counter() - t0)
+    tot = torch.tensor([leaves, int(ids[0]), int(ids[-1])], dtype=torch.int64)
+    if world > 1:
+        allv = [torch.zeros(3, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(allv, tot)
+    else:
+        allv = [tot]
+    if rank == 0:
+        print(json.dumps({
+            "metric": "host parse audio-sec/sec (CPU rehearsal of the N-rank path, no GPU)",
+            "value": round(sharding.aggregate_audio_seconds_per_second(world, S, K, T * FRAME_S, elapsed), 1),
+            "unit": "audio-s/s", "n_gpus": world, "steps": K, "warmup": 0, "ms_per_step": round(elapsed / K * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int", "data": "synthetic",
+            "config": {"workload": "parse-only", "streams_per_gpu": S, "frames_per_stream_per_step": T,
+                       "shards": [[int(v[1]), int(v[2])] for v in allv], "leaves": int(sum(int(v[0]) for v in allv)),
+                       "parallelism": f"streams sharded over {world} rank(s), no collective in the data path; "
+                                      f"{a.backend} only for the barrier and the max of the elapsed times"}}), flush=True)
+
+
 def main():
     a = parse_args()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(spawn_ranks(a))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        sys.exit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {a.gpus}")
     import numpy as np
     import torch
     import torch.distributed as dist
-    from opus_amd import BatchDecoder, _abi as A, sharding, synth
+    from opus_amd import sharding, synth
+
+    if a.parse_only:
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(a.backend)
+        parse_only(a, rank, world)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    from opus_amd import BatchDecoder, _abi as A, steps as stepmod
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group(a.backend, device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     lib = A.load()
@@ -114,55 +189,23 @@ def main():
     packets = synth.celt_fb_stereo_packets(ids, nframes, PAYLOAD)
 
     # ---- host half (untimed here; its rate is reported separately): packets -> side-info, copied to HBM.
-    # Per step the records are laid out [stream][t] (a workgroup walks one stream's T frames in time order).
+    # Per step the records are laid out [stream][t] (a tail workgroup walks one stream's T frames in time order).
     parser = BatchDecoder(S, 2, local_rank)
-    hdr_dev, leaf_dev, ref_dev, ref_classes, alg_bytes, nleaves = [], [], [], [], [], []
-    t_parse = 0.0
-    HS = C.sizeof(A.CeltHdr)
-    o_lb, o_po = A.CeltHdr.leaf_begin.offset, A.CeltHdr.pcm_off.offset
-    for k in range(nsteps):
-        hb_all = np.zeros((S, T, HS), np.uint8)
-        leaf_parts, leaf_off, pf_on = [], 0, 0
-        for t in range(T):
-            f = k * T + t
-            pk = [packets[s, f].tobytes() for s in range(S)]
-            t0 = time.perf_counter()
-            errs = parser.send(pk)
-            t_parse += time.perf_counter() - t0
-            assert not any(errs)
-            celt, leaves, _ = parser.sideinfo()
-            assert len(celt) == S
-            hb = np.frombuffer(celt, dtype=np.uint8).reshape(S, HS).copy()
-            hb[:, o_lb:o_lb + 4].view(np.uint32)[:] += leaf_off          # leaf indices are relative to the step's array
-            hb[:, o_po:o_po + 4].view(np.uint32)[:] = t * 960            # frame t lands at sample t*960 of the PCM row
-            gq = hb[:, A.CeltHdr.pf_gain_q.offset:A.CeltHdr.pf_gain_q.offset + 3]
-            pf_on += int((gq != 0).any(axis=1).sum())
-            hb_all[:, t] = hb
-            leaf_parts.append(np.frombuffer(leaves, dtype=np.uint8).copy())
-            leaf_off += len(leaves)
-        lb = np.concatenate(leaf_parts)
-        hbc = np.ascontiguousarray(hb_all.reshape(S * T, HS))
-        refs = (A.LeafRef * max(leaf_off, 1))()
-        classes = (C.c_uint32 * 4)()
-        nref = lib.opusgpu_sort_pvq_leaves(hbc.ctypes.data, S * T, lb.ctypes.data, refs, leaf_off, classes)
-        alg_bytes.append(int(S * T * ALG_BYTES_BASE + pf_on * ALG_BYTES_PF))
-        nleaves.append(leaf_off)
-        hdr_dev.append(torch.from_numpy(hbc).to(dev))
-        leaf_dev.append(torch.from_numpy(lb).to(dev))
-        ref_dev.append(torch.from_numpy(np.frombuffer(refs, dtype=np.uint8)[: max(nref, 1) * 8].copy()).to(dev))
-        ref_classes.append(classes)
+    host_steps, t_parse = stepmod.build_celt_steps(parser, packets, T, nsteps)
     parser.close()
+    hdr_dev = [torch.from_numpy(st.hdr).to(dev) for st in host_steps]
+    leaf_dev = [torch.from_numpy(st.leaves).to(dev) for st in host_steps]
+    ref_dev = [torch.from_numpy(st.refs).to(dev) for st in host_steps]
+    ref_classes = [st.classes for st in host_steps]
+    alg_bytes = [int(S * T * ALG_BYTES_BASE + st.pf_on * ALG_BYTES_PF) for st in host_steps]
+    nleaves = [st.nleaves for st in host_steps]
 
     state = torch.zeros(S * C.sizeof(A.CeltState), dtype=torch.uint8, device=dev)
-    # K1 -> plan -> frame-kernel scratch (kept zero by the kernels); two of them so that consecutive steps can overlap
-    works = [torch.zeros(lib.opusgpu_celt_work_bytes(S * T), dtype=torch.uint8, device=dev) for _ in range(2)]
+    work = torch.zeros(lib.opusgpu_celt_work_bytes(S * T), dtype=torch.uint8, device=dev)     # K1 -> plan -> frame-kernel scratch
     stride = T * 960 * 2
     pcm = torch.zeros(S * stride, dtype=torch.float32, device=dev)
-    # the first half is short and on the critical path of the next frame kernel: its stream ranks first for free CU slots
-    s_pvq, s_frm = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
-    p_pvq, p_frm = C.c_void_p(s_pvq.cuda_stream), C.c_void_p(s_frm.cuda_stream)
-    ready = [torch.cuda.Event() for _ in range(nsteps)]
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nsteps)]
+    s_frm = torch.cuda.Stream(dev)
+    p_frm = C.c_void_p(s_frm.cuda_stream)
     evk = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nsteps)]   # around og_celt_kernel
 
     def check(rc):
@@ -170,33 +213,14 @@ def main():
             raise RuntimeError(lib.opusgpu_last_error().decode())
 
     def step(f):
-        """step f; og_celt_kernel is bracketed by evk[f] on the stream it runs on"""
-        w = works[f % 2]
-        if (not a.pipeline):
-            # = opusgpu_launch_celt, issued as its three parts so that the dominant kernel can be bracketed on its stream
-            check(lib.opusgpu_launch_celt_pvq(hdr_dev[f].data_ptr(), leaf_dev[f].data_ptr(), S * T, ref_dev[f].data_ptr(), ref_classes[f],
-                                              w.data_ptr(), None, p_frm))
-            evk[f][0].record(s_frm)
-            check(lib.opusgpu_launch_celt_spectrum(hdr_dev[f].data_ptr(), S * T, w.data_ptr(), None, p_frm))
-            evk[f][1].record(s_frm)
-            check(lib.opusgpu_launch_celt_tail(hdr_dev[f].data_ptr(), S * T, T, w.data_ptr(), state.data_ptr(), pcm.data_ptr(), stride,
-                                               None, p_frm))
-            return
-        # pipelined: the stateless chain K1 -> plan -> og_celt_kernel of step f on one stream, the tail kernels (which carry
-        # the decoder state, in order) on another: tail(f) overlaps the stateless chain of step f + 1
-        if f >= 2:
-            s_pvq.wait_event(ev[f - 2][1])              # the scratch buffer is free once tail(f-2) has consumed it
+        """step f = opusgpu_launch_celt, issued as its three parts; og_celt_kernel is bracketed by evk[f] on the stream it runs on"""
         check(lib.opusgpu_launch_celt_pvq(hdr_dev[f].data_ptr(), leaf_dev[f].data_ptr(), S * T, ref_dev[f].data_ptr(), ref_classes[f],
-                                          w.data_ptr(), None, p_pvq))
-        evk[f][0].record(s_pvq)
-        check(lib.opusgpu_launch_celt_spectrum(hdr_dev[f].data_ptr(), S * T, w.data_ptr(), None, p_pvq))
-        evk[f][1].record(s_pvq)
-        ready[f].record(s_pvq)
-        s_frm.wait_event(ready[f])
-        ev[f][0].record(s_frm)
-        check(lib.opusgpu_launch_celt_tail(hdr_dev[f].data_ptr(), S * T, T, w.data_ptr(), state.data_ptr(), pcm.data_ptr(), stride,
+                                          work.data_ptr(), None, p_frm))
+        evk[f][0].record(s_frm)
+        check(lib.opusgpu_launch_celt_spectrum(hdr_dev[f].data_ptr(), S * T, work.data_ptr(), None, p_frm))
+        evk[f][1].record(s_frm)
+        check(lib.opusgpu_launch_celt_tail(hdr_dev[f].data_ptr(), S * T, T, work.data_ptr(), state.data_ptr(), pcm.data_ptr(), stride,
                                            None, p_frm))
-        ev[f][1].record(s_frm)
 
     torch.cuda.synchronize(dev)
     for f in range(W):
@@ -214,14 +238,21 @@ def main():
     elapsed = sharding.max_over_ranks(elapsed, dev)
     assert bool(torch.isfinite(pcm).all())
 
-    if a.pipeline:
-        kernel_ms = [e0.elapsed_time(e1) for e0, e1 in ev[W:]]
-        avg_kernel_s = sum(kernel_ms) / K / 1e3
-    else:                                                    # the calls run back to back on one stream: per call = step time
-        avg_kernel_s = elapsed / K
+    # ---- outside the timed region: the last step's PCM of a sample of streams (first, last, interior) against the CPU oracle,
+    #      which decodes those streams from their first packet (all nsteps * T frames: the decoder state carries over)
+    verified = None
+    if not a.no_verify:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from gpu_util import oracle_check_last_step
+        sample = sorted({0, 1, S // 3, S // 2, (2 * S) // 3 + 1, S - 1})
+        rows = pcm.view(S, stride)[sample].cpu().numpy()
+        worst = oracle_check_last_step({s: rows[i] for i, s in enumerate(sample)}, packets, sample, nframes, T, "bench last step")
+        verified = {"ok": True, "streams": sample, "frames_each": T, "max_scaled_err": float(f"{worst:.3e}"),
+                    "bar": "max abs err <= 1e-4 (scaled by the reference peak when that exceeds 1), SNR >= 90 dB vs the CPU oracle"}
+
+    avg_kernel_s = elapsed / K                               # the calls run back to back on one stream: per call = step time
     avg_alg = sum(alg_bytes[W:]) / K
     achieved = avg_alg / avg_kernel_s / 1e9
-    step_achieved = avg_alg / (elapsed / K) / 1e9           # the same bytes over the whole step (all kernels)
     k2_s = sum(e0.elapsed_time(e1) for e0, e1 in evk[W:]) / K / 1e3       # og_celt_kernel alone
     k2_bytes = S * T * K2_BYTES
     traffic = k2_traffic = None
@@ -242,24 +273,24 @@ def main():
             "ms_per_step": round(elapsed / K * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "verified": bool(verified and verified["ok"]), "verify": verified,
             "config": {"workload": "BASELINE configs[1]: synthetic CELT-only FB 48 kHz stereo 20 ms frames (TOC 0xFC + "
-                                   f"{PAYLOAD} random payload bytes), {S} streams per GPU, {T} consecutive frames per stream per step",
+                                   f"{PAYLOAD} random payload bytes), {S} streams per GPU, {T} consecutive frames per stream per step; "
+                                   "device-only: side-info pre-parsed and resident in HBM, PCM stays in HBM",
                        "streams_per_gpu": S, "frame_ms": 20, "frames_per_stream_per_step": T, "payload_bytes": PAYLOAD,
-                       "parallelism": f"streams sharded over {world} GPU(s), no collective",
-                       "pipelined": bool(a.pipeline)},
+                       "parallelism": f"streams sharded over {world} GPU(s), one process per GPU, no collective in the data path; "
+                                      "RCCL only for the barrier and the max of the elapsed times"},
             # the launch = every kernel of one opusgpu_launch_celt (K1, plan, og_celt_kernel, og_celt_tail_kernel),
-            # priced with SURVEY 8(d)'s per-frame bytes; `dominant` = og_celt_kernel alone (52 % of the launch) with the bytes it
+            # priced with SURVEY 8(d)'s per-frame bytes; `dominant` = og_celt_kernel alone with the bytes it
             # moves by design (side-info + energies 1724, K1 row in 7680, sample row out 7680)
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "kernel": ("one opusgpu_launch_celt call: og_pvq_all_kernel + og_plan_kernel + og_celt_kernel + og_celt_tail_kernel"
-                                    if (not a.pipeline) else "og_celt_kernel + og_celt_tail_kernel; K1 + plan of the next step overlap them"),
+                         "kernel": "one opusgpu_launch_celt call: og_pvq_all_kernel + og_plan_kernel + og_celt_kernel + og_celt_tail_kernel",
                          "avg_launch_us": round(avg_kernel_s * 1e6, 2),
                          "algorithmic_bytes_per_launch": int(avg_alg),
                          "dominant": {"kernel": "og_celt_kernel", "avg_launch_us": round(k2_s * 1e6, 2), "bytes_per_launch": int(k2_bytes),
                                       "achieved": round(k2_bytes / k2_s / 1e9, 2), "frac": round(k2_bytes / k2_s / 1e9 / HBM_PEAK_GBS, 5),
-                                      "traffic": k2_traffic},
-                         "whole_step": {"achieved": round(step_achieved, 2), "frac": round(step_achieved / HBM_PEAK_GBS, 5)}},
+                                      "traffic": k2_traffic}},
             "host_parse": {"value": round(S * nframes * FRAME_S / t_parse, 1), "unit": "audio-s/s",
                            "note": "packets -> side-info on the host threads (untimed in `value`)",
                            "mean_leaves_per_frame": round(sum(nleaves) / (S * nframes), 1)},

@@ -47,6 +47,13 @@ const char *opusgpu_strerror(int code);
  * Not thread-safe per handle, exactly as the reference's `&mut self` methods. */
 typedef struct opusgpu_decoder opusgpu_decoder;
 
+/* Descriptor::describe (decoder.rs:37-39) -> &Descr{codec, name, desc, mime} of OPUS_DESCR (decoder.rs:190-197).  The
+ * strings are static; codec / name / mime are the reference's ("opus", "opus", "audio/OPUS"), desc names this engine. */
+typedef struct {
+    const char *codec, *name, *desc, *mime;
+} OgDescr;
+const OgDescr *opusgpu_describe(void);
+
 /* Descriptor::create (decoder.rs:33-35).  device = HIP device ordinal. */
 int opusgpu_decoder_create(opusgpu_decoder **out, int device);
 void opusgpu_decoder_destroy(opusgpu_decoder *);
@@ -111,7 +118,9 @@ void opusgpu_batch_destroy(opusgpu_batch *);
  * bad packet never poisons the batch.  Returns OPUSGPU_OK or a global failure. */
 int opusgpu_batch_send(opusgpu_batch *, const uint8_t *const *pkts, const uint32_t *lens,
                        const uint32_t *stream_ids, uint32_t n, int32_t *errors);
-/* Device half: H2D of the side-info, then the kernels, on the batch's HIP stream.  Asynchronous. */
+/* Device half: H2D of the side-info, then the kernels, on the batch's HIP stream.  Asynchronous: the next batch_send
+ * may follow at once (it waits for this call's H2D copies, not for its kernels, before it rewrites the staging arrays);
+ * batch_pcm / batch_read results are valid after batch_sync (batch_read synchronises itself). */
 int opusgpu_batch_decode(opusgpu_batch *);
 int opusgpu_batch_sync(opusgpu_batch *);
 /* Device-resident result of the last decode: interleaved f32, row s = stream s,
@@ -142,6 +151,9 @@ typedef struct {               /* one Opus frame of a packet */
     uint32_t celt_index;       /* index into the celt[] output */
     uint32_t silk_index;       /* index of the first SILK frame in silk[] */
     uint32_t final_range;      /* range decoder state after the frame (celt/decoder.rs:2322) */
+    uint32_t tell_bits;        /* bits the range decoder had consumed at the end of the frame (entropy.rs:375-378 tell) */
+    uint32_t budget_bits;      /* bits the frame held for it (8 * frame bytes, less a redundant frame's): a parse that
+                                  follows the bitstream never ends with tell_bits > budget_bits */
 } OgFrameInfo;
 
 int opusgpu_parser_create(opusgpu_parser **out, int channels);
@@ -188,8 +200,8 @@ typedef struct {               /* optional stage dumps for parity tests; any poi
 int opusgpu_init(int device);
 
 /* CELT, four kernel stages per launch:
- *   K1  og_pvq_all_kernel (one launch; its workgroups each serve one leaf size class): one lane per PVQ leaf (refs[], sorted by size across the whole
- *       batch so that the lanes of a wavefront run the same trip counts): CWRS index -> pulses, normalise, spreading
+ *   K1  og_pvq_all_kernel (one launch; its workgroups each serve one leaf size class): one lane per PVQ leaf (refs[], sorted by size
+ *       across the whole batch so that the lanes of a wavefront run the same trip counts): CWRS index -> pulses, normalise, spreading
  *       rotation, collapse mask (celt/decoder.rs:541-786); writes the shaped coefficients to the `work` scratch.
  *   plan  og_plan_kernel: one lane per frame: the integer half of decode_bands (celt/decoder.rs:2037-2220): which
  *       zero-pulse leaves fold / make noise and with which seed, collapse masks, dependency levels of the bands.
@@ -205,8 +217,8 @@ int opusgpu_init(int device);
  * zero back zero-filled.  Launches that share `work` must be ordered on one stream. */
 size_t opusgpu_celt_work_bytes(uint32_t nframes);
 /* Host helper: lists the PVQ leaves (K > 0) of hdr[0..nframes) in decreasing size N and counts them per size class
- * (N > 64, 24 < N <= 64, 8 < N <= 24, N <= 8): K1 runs one launch per class so that the many small leaves do not pay
- * the LDS of the few large ones.  Returns the total (<= cap; 0 if cap is too small). */
+ * (N > 64, 24 < N <= 64, 8 < N <= 24, N <= 8): every K1 workgroup serves one class, so that the many small leaves do not
+ * pay the LDS of the few large ones.  Returns the total (<= cap; 0 if cap is too small). */
 uint32_t opusgpu_sort_pvq_leaves(const OgCeltHdr *hdr, uint32_t nframes, const OgCeltLeaf *leaves, OgLeafRef *out, uint32_t cap,
                                  uint32_t class_counts[4]);
 int opusgpu_launch_celt(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, uint32_t nframes, uint32_t frames_per_group,
@@ -215,7 +227,7 @@ int opusgpu_launch_celt(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, uint32_t
 /* The same launch in its two halves, for callers that pipeline consecutive batches: the first half (K1 + plan) only
  * writes `work` and touches no decoder state, so batch k+1's first half may run on another stream -- with its own
  * `work` buffer -- while batch k's frame kernel is still running; the frame kernels of a stream's batches must stay in
- * order (they carry the decoder state).  bench.py runs this way.  opusgpu_launch_celt = both halves on one stream. */
+ * order (they carry the decoder state).  opusgpu_launch_celt = both halves on one stream. */
 int opusgpu_launch_celt_pvq(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, uint32_t nframes, const OgLeafRef *refs,
                             const uint32_t class_counts[4], void *work, const OgCeltDebug *debug, void *stream);
 int opusgpu_launch_celt_frames(const OgCeltHdr *hdr, uint32_t nframes, uint32_t frames_per_group, void *work, OgCeltState *state,

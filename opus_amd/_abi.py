@@ -51,7 +51,7 @@ class SilkFrame(C.Structure):
 class FrameInfo(C.Structure):
     _fields_ = [("mode", C.c_uint8), ("bandwidth", C.c_uint8), ("stereo", C.c_uint8), ("nsilk", C.c_uint8),
                 ("frame_size", C.c_uint16), ("has_celt", C.c_uint16), ("celt_index", C.c_uint32),
-                ("silk_index", C.c_uint32), ("final_range", C.c_uint32)]
+                ("silk_index", C.c_uint32), ("final_range", C.c_uint32), ("tell_bits", C.c_uint32), ("budget_bits", C.c_uint32)]
 
 
 class Packet(C.Structure):
@@ -74,12 +74,17 @@ class CeltDebug(C.Structure):
     _fields_ = [("pulses", C.c_void_p), ("norm", C.c_void_p), ("freq", C.c_void_p), ("collapse", C.c_void_p), ("cycles", C.c_void_p)]
 
 
+class Descr(C.Structure):
+    _fields_ = [("codec", C.c_char_p), ("name", C.c_char_p), ("desc", C.c_char_p), ("mime", C.c_char_p)]
+
+
 # every symbol include/opusgpu.h declares: name -> (restype, argtypes or None)
 _P = C.c_void_p
 PROTOTYPES = {
     "opusgpu_version": (C.c_char_p, []),
     "opusgpu_last_error": (C.c_char_p, []),
     "opusgpu_strerror": (C.c_char_p, [C.c_int]),
+    "opusgpu_describe": (C.POINTER(Descr), []),
     "opusgpu_decoder_create": (C.c_int, [C.POINTER(_P), C.c_int]),
     "opusgpu_decoder_destroy": (None, [_P]),
     "opusgpu_decoder_set_extradata": (C.c_int, [_P, C.c_char_p, C.c_size_t]),

@@ -6,6 +6,7 @@ import subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "opus_amd", "csrc")
 OUT = os.path.join(ROOT, "opus_amd", "libopusgpu.so")
+OUT_STATIC = os.path.join(ROOT, "opus_amd", "libopusgpu.a")     # the same objects archived (north_star: "gfx950 static library")
 
 HOST_SOURCES = ["host/packet.cpp", "host/celt_parse.cpp", "host/silk_parse.cpp", "host/stream_parser.cpp",
                 "host/capi_parse.cpp", "host/container.cpp", "host/celt_tables.cpp", "host/silk_tables.cpp", "host/engine.cpp"]
@@ -33,7 +34,8 @@ def _all_inputs():
 
 def build_lib(force=False, verbose=False):
     srcs = [s for s in HOST_SOURCES + HIP_SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    if not force and not _newer(OUT, _all_inputs() + [os.path.abspath(__file__)]):
+    deps = _all_inputs() + [os.path.abspath(__file__)]
+    if not force and not _newer(OUT, deps) and not _newer(OUT_STATIC, deps):
         return OUT
     objdir = os.path.join(ROOT, "build", "obj")
     os.makedirs(objdir, exist_ok=True)
@@ -48,6 +50,11 @@ def build_lib(force=False, verbose=False):
         subprocess.check_call(cmd)
         objs.append(o)
     subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "-shared", "-o", OUT] + objs + ["-lpthread"])
+    # static flavour for a Rust / C host that links the engine in (link with hipcc or add -lamdhip64 -lstdc++ -lpthread):
+    # the HIP objects carry their gfx950 code object, which the HIP runtime registers at start-up
+    if os.path.exists(OUT_STATIC):
+        os.remove(OUT_STATIC)
+    subprocess.check_call(["ar", "rcs", OUT_STATIC] + objs)
     return OUT
 
 

@@ -1,8 +1,8 @@
-// CELT frame decode, device side: one workgroup turns one frame's side-info (OgCeltHdr + leaves) into
-// PCM.  Fuses what SURVEY.md section 2.1 lists as K1 (PVQ index -> pulse vector, normalise, spreading
-// rotation, collapse mask), K2 (folding / noise fill, Haar + Hadamard reordering, stereo merge) and K3
-// (anti-collapse, denormalise, IMDCT, TDAC window, comb post-filter, de-emphasis): coefficients never
-// leave LDS between the stages.
+// CELT frame decode, device side, after K1 (celt_pvq.h: PVQ index -> pulse vector, normalise, spreading rotation,
+// collapse mask) and the band plan (celt_plan.h): og_celt_spectrum -- one workgroup per frame, stateless: folding / noise
+// fill, Haar + Hadamard reordering, stereo merge, anti-collapse, denormalise and the IMDCT up to its
+// post-twiddle, all in LDS -- and og_celt_tail -- one workgroup per stream in time order: TDAC window + overlap-add, comb
+// post-filter, de-emphasis, PCM (K3).  The two meet in the frame's scratch row in HBM (DESIGN.md section 4 has why).
 //
 // Reference anchors (lu-zero/opus): cwrsi celt/decoder.rs:541-660, unquantize :766-786, exp_rotation
 // :676-721, extract_collapse_mask :723-736, decode_band_no_split fill paths :1633-1661, haar1 :453-466,

@@ -7,31 +7,11 @@
 #include "../host/celt_tables.hpp"
 #include "device_util.hpp"
 
-// K1: one lane per PVQ leaf, WGS / 64 wavefronts per workgroup sharing one copy of the unpacked U table.  A wave's 64
-// vectors are lane-interleaved in LDS: element i of lane l at x[i*64 + l], so every access of the serial per-lane loops
-// hits bank l (conflict-free).  NMAX bounds the leaf size of the launch's size class; refs are sorted by decreasing size,
-// so a class is a contiguous range.
-template <int NMAX, int WGS>
-__global__ __launch_bounds__(WGS) void og_pvq_kernel(const OgLeafRef *__restrict__ refs, uint32_t nrefs,
-                                                     const OgCeltHdr *__restrict__ hdr, const OgCeltLeaf *__restrict__ leaves,
-                                                     uint32_t nframes, const OgCeltTables *__restrict__ T, void *work,
-                                                     int16_t *dbg_pulses, uint64_t *dbg_cycles)
-{
-    __shared__ uint32_t U2[15 * OG_U2_STRIDE];
-    __shared__ float x[NMAX * WGS];
-    for (int p = threadIdx.x; p < 15 * OG_U2_STRIDE; p += WGS) U2[p] = T->pvq_u2[p];
-    __syncthreads();
-    const uint32_t g = blockIdx.x * WGS + threadIdx.x;
-    // profiling: lane 0 of each workgroup stamps its stages behind the per-frame stamps ([nframes][64]) of the buffer
-    uint64_t *stamps = dbg_cycles && threadIdx.x == 0 && blockIdx.x < 4096 ? dbg_cycles + (size_t)nframes * 64 + ((size_t)NMAX * 4096 + blockIdx.x) * 4 : nullptr;
-    if (g < nrefs)
-        og_pvq_lane(refs[g], hdr, leaves, nframes, work, U2, x + (threadIdx.x >> 6) * (NMAX * 64) + (threadIdx.x & 63), 64, dbg_pulses, stamps);
-}
-
-// K1, all four size classes in one launch (the default): 256-thread workgroups, each serving one class with as many lanes as
-// fit a common LDS budget -- 16 lanes for N <= 176, 32 for N <= 64, 128 for N <= 24, 256 for N <= 8 (12 KB of vectors + the
-// 10.6 KB U table: seven workgroups per CU); wavefronts without a leaf leave at once.  A wave's vectors are interleaved
-// with the stride of its live lanes (16 / 32 / 64: still one bank per lane).  No side streams, no fork / join events.
+// K1: one lane per PVQ leaf, all four size classes in one launch: 256-thread workgroups, each serving one class with as many
+// lanes as fit a common LDS budget -- 16 lanes for N <= 176, 32 for N <= 64, 128 for N <= 24, 256 for N <= 8 (12 KB of
+// vectors + the 10.6 KB U table: seven workgroups per CU); wavefronts without a leaf leave at once.  A wave's vectors are
+// lane-interleaved in LDS with the stride of its live lanes (16 / 32 / 64: element i of lane l at x[i * stride + l], one bank
+// per lane, conflict-free).  refs are sorted by decreasing size, so a class is a contiguous range.
 struct OgPvqClasses { uint32_t cnt[4], wg0[4]; };      // leaves per class (largest first); first workgroup of each class
 __global__ __launch_bounds__(256) void og_pvq_all_kernel(const OgLeafRef *__restrict__ refs, OgPvqClasses cl,
                                                          const OgCeltHdr *__restrict__ hdr, const OgCeltLeaf *__restrict__ leaves,
@@ -109,8 +89,8 @@ __global__ __launch_bounds__(64) void og_plan_kernel(const OgCeltHdr *__restrict
                       hs + threadIdx.x * HW + EOFF);
 }
 
-// Frame kernels.  og_celt_kernel: one 256-lane workgroup per frame, stateless (band walk .. IMDCT post-twiddle), five
-// workgroups per CU (31 KB of LDS, 96 VGPRs).  og_celt_tail_kernel: one 128-lane workgroup per group of
+// Frame kernels.  og_celt_kernel: one 256-lane workgroup per frame, stateless (band walk .. IMDCT post-twiddle), eight
+// workgroups per CU (20.4 KB of LDS, 64 VGPRs).  og_celt_tail_kernel: one 128-lane workgroup per group of
 // frames_per_group consecutive records (a stream's frames in time order), which it walks in order carrying the stream's
 // state: window + overlap-add, comb filter, de-emphasis, PCM.
 __global__ __launch_bounds__(OG_WG) __attribute__((amdgpu_waves_per_eu(8, 8))) void og_celt_kernel(const OgCeltHdr *__restrict__ hdr, uint32_t nframes,
@@ -158,17 +138,11 @@ int device_fail(hipError_t e, const char *what)
     return OPUSGPU_DEVICE;
 }
 
-// Per-device context, built once: the constant tables, and three side streams + events with which a launch runs its
-// four K1 size classes side by side (each class alone is latency-bound at low occupancy; together they overlap).
+// Per-device context, built once: the constant tables.
 struct DevCtx {
     OgCeltTables *tables = nullptr;
-    hipStream_t side[3] = {nullptr, nullptr, nullptr};
-    enum { RING = 8 };                  // fork / join event sets, used in turn: an event is not re-recorded while waits on its
-    hipEvent_t fork[RING] = {}, join[RING][3] = {};     // previous record may still be queued
-    unsigned turn = 0;
 };
 static std::mutex g_tables_mu;
-static std::mutex g_fork_mu;            // fork / join sequences on the shared side streams are enqueued one launch at a time
 static DevCtx g_ctx[64];
 
 static int ctx_for_device(int device, DevCtx **out)
@@ -185,21 +159,6 @@ static int ctx_for_device(int device, DevCtx **out)
         hipError_t e = hipMalloc(&dev, sizeof(OgCeltTables));
         if (e == hipSuccess) e = hipMemcpy(dev, host, sizeof(OgCeltTables), hipMemcpyHostToDevice);
         delete host;
-        int prio_lo = 0, prio_hi = 0;                    // K1 is short and on the critical path: its streams rank first
-        if (e == hipSuccess) e = hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-        // Normal priority by default.  High priority (OPUSGPU_K1_STREAM_PRIORITY=high) measured 2 % faster in bench.py's
-        // single-stream flow (the runtime then gives every side stream a hardware queue of its own; streams that share one
-        // run one after the other), but a high-priority stream parked on an event wait can keep the command processor from
-        // serving the other queues: depending on how the process's streams fall onto the four hardware queues, the launch
-        // then never finishes (tools/pipeline_probe.py reproduces it).  Not worth a hang.
-        const char *pe = getenv("OPUSGPU_K1_STREAM_PRIORITY");
-        const bool high = pe && pe[0] == 'h';
-        for (int k = 0; k < 3 && e == hipSuccess; k++)
-            e = high ? hipStreamCreateWithPriority(&c.side[k], hipStreamNonBlocking, prio_hi) : hipStreamCreateWithFlags(&c.side[k], hipStreamNonBlocking);
-        for (int r = 0; r < DevCtx::RING && e == hipSuccess; r++) {
-            e = hipEventCreateWithFlags(&c.fork[r], hipEventDisableTiming);
-            for (int k = 0; k < 3 && e == hipSuccess; k++) e = hipEventCreateWithFlags(&c.join[r][k], hipEventDisableTiming);
-        }
         (void)hipSetDevice(prev);
         if (e != hipSuccess) return device_fail(e, "celt device set-up");
         c.tables = dev;
@@ -247,58 +206,12 @@ int opusgpu_launch_celt_pvq(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, uint
     OgCeltDebug dbg = {nullptr, nullptr, nullptr, nullptr, nullptr};
     if (debug) dbg = *debug;
     hipStream_t st = (hipStream_t)stream;
-    static const bool fused = [] { const char *e = getenv("OPUSGPU_K1_FUSED"); return !(e && e[0] == '0'); }();
-    if (fused && nrefs) {                               // K1 as one launch (og_pvq_all_kernel); the per-class launches below stay
-        OgPvqClasses cl;                                // selectable (OPUSGPU_K1_FUSED=0) for comparison
+    if (nrefs) {                                        // K1 (skipped when no frame carries a PVQ leaf)
+        OgPvqClasses cl;
         static const uint32_t lanes[4] = {16, 32, 128, 256};
         uint32_t wg = 0;
         for (int c = 0; c < 4; c++) { cl.cnt[c] = class_counts[c]; cl.wg0[c] = wg; wg += (class_counts[c] + lanes[c] - 1) / lanes[c]; }
         hipLaunchKernelGGL(og_pvq_all_kernel, dim3(wg), dim3(256), 0, st, refs, cl, hdr, leaves, nframes, T, work, dbg.pulses, dbg.cycles);
-    } else
-    // K1: one launch per size class (refs are sorted by decreasing N): the many small leaves do not pay the 45 KB of
-    // LDS per wavefront that the few 176-wide ones need.  The classes are dealt round-robin to the caller's stream and
-    // the side streams (three by default, OPUSGPU_K1_SIDE_STREAMS = 0..3), forked from and joined back into the caller's
-    // stream with events (a ring of event sets, so none is re-recorded while a wait on it may still be queued).
-    {
-        static const int nside = [] { const char *e = getenv("OPUSGPU_K1_SIDE_STREAMS"); int n = e ? atoi(e) : 3; return n < 0 ? 0 : n > 3 ? 3 : n; }();
-        std::lock_guard<std::mutex> lk(og::g_fork_mu);
-        int nclasses = 0;
-        for (int c = 0; c < 4; c++) nclasses += class_counts[c] != 0;
-        const bool fork = nclasses > 1 && nside > 0;
-        const unsigned ring = ctx->turn++ % og::DevCtx::RING;
-        if (fork) OG_HIP(hipEventRecord(ctx->fork[ring], st));
-        const OgLeafRef *r = refs;
-        bool used[3] = {false, false, false};
-        int idx = 0;
-        for (int c = 0; c < 4; c++) {
-            const uint32_t cnt = class_counts[c];
-            if (!cnt) continue;
-            static const int lane_of[4][4] = {{0, 0, 0, 0}, {0, 1, 0, 1}, {0, 1, 1, 2}, {0, 1, 2, 3}};   // [side streams][class]
-            const int lane = fork ? lane_of[nside][c] : 0;      // 0 = the caller's stream
-            idx++;
-            hipStream_t cur = st;
-            if (lane) {
-                cur = ctx->side[lane - 1];
-                if (!used[lane - 1]) OG_HIP(hipStreamWaitEvent(cur, ctx->fork[ring], 0));
-                used[lane - 1] = true;
-            }
-#define OG_PVQ_LAUNCH(NMAX, WGS)                                                                                          \
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(og_pvq_kernel<NMAX, WGS>), dim3((cnt + (WGS) - 1) / (WGS)), dim3(WGS), 0, cur, r, cnt, \
-                               hdr, leaves, nframes, T, work, dbg.pulses, dbg.cycles)
-            switch (c) {
-            case 0: OG_PVQ_LAUNCH(176, 64); break;
-            case 1: OG_PVQ_LAUNCH(64, 128); break;
-            case 2: OG_PVQ_LAUNCH(24, 256); break;
-            default: OG_PVQ_LAUNCH(8, 256); break;
-            }
-#undef OG_PVQ_LAUNCH
-            r += cnt;
-        }
-        for (int k = 0; k < 3; k++)
-            if (used[k]) {
-                OG_HIP(hipEventRecord(ctx->join[ring][k], ctx->side[k]));
-                OG_HIP(hipStreamWaitEvent(st, ctx->join[ring][k], 0));
-            }
     }
     hipLaunchKernelGGL(og_plan_kernel, dim3((nframes + OG_PLAN_FPW - 1) / OG_PLAN_FPW), dim3(64), 0, st, hdr, leaves, nframes, T, work);
     OG_HIP(hipGetLastError());

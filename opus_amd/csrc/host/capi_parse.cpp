@@ -16,6 +16,13 @@ extern "C" {
 
 const char *opusgpu_version(void) { return "opus_amd 0.1 (gfx950)"; }
 
+// Descriptor::describe (decoder.rs:37-39) of OPUS_DESCR (decoder.rs:190-197)
+const OgDescr *opusgpu_describe(void)
+{
+    static const OgDescr d = {"opus", "opus", "opus_amd batched opus decoder (MI355X / gfx950)", "audio/OPUS"};
+    return &d;
+}
+
 const char *opusgpu_strerror(int code)
 {
     switch (code) {

@@ -1,7 +1,7 @@
 // CELT frame parser: the sequential (range-decoder) half of the reference's Celt::decode
 // (lu-zero/opus src/celt/decoder.rs:2222-2323) run "dry": every symbol is decoded and all integer
 // control is evaluated, but no coefficient is touched.  Output = one OgCeltHdr + its leaf records,
-// which the HIP kernels (hip/celt_bands.hip, hip/celt_synth.hip) turn into PCM.
+// which the HIP kernels (hip/celt_launch.hip: celt_pvq.h, celt_plan.h, celt_frame.h) turn into PCM.
 //
 // Where the reference is defective or stops (SURVEY.md section 8 notes) the behaviour is RFC 6716's.
 #include <algorithm>

@@ -172,47 +172,73 @@ struct opusgpu_demux {
         return true;
     }
 
-    // walks the children of a master element; depth-limited by the set of ids it descends into
-    bool walk(const uint8_t *b, size_t p, size_t end)
+    // Walks the children of a master element.  `parent` says which one, and each master id is entered only below its
+    // proper parent (Segment at the top, Tracks / Info / Cluster in the Segment, BlockGroup in a Cluster), so the
+    // recursion is at most four frames deep whatever the file nests; a master element anywhere else is malformed.
+    // An unknown-size Cluster (live muxers) ends where the next Segment-level element starts: the walk returns that
+    // position in *resume and the Segment loop goes on from there (no recursion from cluster to cluster).
+    enum Parent { TOP, SEGMENT, TRACKS, INFO, CLUSTER, BLOCKGROUP };
+    static bool segment_level_id(uint64_t id)
+    {
+        switch (id) {
+        case 0x1F43B675: case 0x1654AE6B: case 0x1549A966: case 0x114D9B74: case 0x1C53BB6B: case 0x1254C367:
+        case 0x1941A469: case 0x1043A770:               // Cluster, Tracks, Info, SeekHead, Cues, Tags, Attachments, Chapters
+            return true;
+        default: return false;
+        }
+    }
+    bool walk(const uint8_t *b, size_t p, size_t end, Parent parent, bool open_ended, size_t *resume)
     {
         Cursor c{b, p, end};
         while (c.p < end) {
+            const size_t at = c.p;
             const uint64_t id = c.vint(true);
             bool unk = false;
             uint64_t sz = c.vint(false, &unk);
             if (!c.ok) return false;
+            if (open_ended && parent == CLUSTER && (segment_level_id(id) || id == 0x18538067)) { *resume = at; return true; }
             if (unk) {                                          // unknown size: only Segment / Cluster may (live muxers)
                 if (id != 0x18538067 && id != 0x1F43B675) return false;
                 sz = end - c.p;
             }
             if (sz > end - c.p) return false;
-            const size_t q = c.p, qe = c.p + size_t(sz);
+            const size_t q = c.p;
+            size_t qe = c.p + size_t(sz);
             switch (id) {
             case 0x18538067:                                    // Segment
+                if (parent != TOP || !walk(b, q, qe, SEGMENT, false, nullptr)) return false;
+                break;
             case 0x1654AE6B:                                    // Tracks
+                if (parent != SEGMENT || !walk(b, q, qe, TRACKS, false, nullptr)) return false;
+                break;
             case 0x1549A966:                                    // Info
-            case 0xA0:                                          // BlockGroup
-                if (!walk(b, q, qe)) return false;
+                if (parent != SEGMENT || !walk(b, q, qe, INFO, false, nullptr)) return false;
                 break;
-            case 0x1F43B675:                                    // Cluster
+            case 0x1F43B675: {                                  // Cluster
+                if (parent != SEGMENT) return false;
                 cluster_tc = 0;
-                if (unk) {                                      // ends where the next Cluster / top-level element starts
-                    if (!walk(b, q, qe)) return false;
-                    return true;
-                }
-                if (!walk(b, q, qe)) return false;
+                size_t stop = qe;
+                if (!walk(b, q, qe, CLUSTER, unk, &stop)) return false;
+                qe = stop;
                 break;
-            case 0xAE: if (!track_entry(b, q, qe)) return false; break;
-            case 0x2AD7B1: { Cursor d{b, q, qe}; timecode_scale = d.uint_be(size_t(sz)); break; }
-            case 0xE7: { Cursor d{b, q, qe}; cluster_tc = int64_t(d.uint_be(size_t(sz))); break; }
+            }
+            case 0xA0:                                          // BlockGroup
+                if (parent != CLUSTER || !walk(b, q, qe, BLOCKGROUP, false, nullptr)) return false;
+                break;
+            case 0xAE: if (parent == TRACKS && !track_entry(b, q, qe)) return false; break;
+            case 0x2AD7B1: if (parent == INFO) { Cursor d{b, q, qe}; timecode_scale = d.uint_be(size_t(sz)); } break;
+            case 0xE7: if (parent == CLUSTER) { Cursor d{b, q, qe}; cluster_tc = int64_t(d.uint_be(size_t(sz))); } break;
             case 0xA3:                                          // SimpleBlock
+                if (parent == CLUSTER && !block(b, q, qe)) return false;
+                break;
             case 0xA1:                                          // Block
-                if (!block(b, q, qe)) return false;
+                if (parent == BLOCKGROUP && !block(b, q, qe)) return false;
                 break;
             default: break;                                     // EBML header, SeekHead, Cues, Tags, Void, ...: skipped
             }
             c.p = qe;
         }
+        if (resume) *resume = end;
         return true;
     }
 
@@ -302,10 +328,13 @@ int opusgpu_demux_open(opusgpu_demux **out, const uint8_t *data, size_t len)
     if (std::memcmp(data, "OggS", 4) == 0) { d->container = 1; ok = d->ogg(data, len); }
     else if (data[0] == 0x1A && data[1] == 0x45 && data[2] == 0xDF && data[3] == 0xA3) {
         d->container = 0;
-        ok = d->walk(data, 0, len) && d->have_track;
+        ok = d->walk(data, 0, len, opusgpu_demux::TOP, false, nullptr) && d->have_track;
     }
     OgOpusHead head;
-    if (!ok || opusgpu_opus_head_parse(d->extra.data(), d->extra.size(), &head) == OPUSGPU_CONFIG_INVALID) {
+    int hrc = ok ? opusgpu_opus_head_parse(d->extra.data(), d->extra.size(), &head) : OPUSGPU_INVALID_DATA;
+    // a track whose OpusHead no decoder could be configured from is not an Opus track (an empty or short CodecPrivate,
+    // a header cut short); a well-formed header this build cannot decode (version) still opens: configure reports it
+    if (hrc != OPUSGPU_OK && hrc != OPUSGPU_UNSUPPORTED) {
         delete d;
         return OPUSGPU_INVALID_DATA;
     }

@@ -104,11 +104,14 @@ struct opusgpu_batch {
     float *d_pcm = nullptr;
     size_t pcm_stride = 0;
     bool pending = false;
+    hipEvent_t h2d_done = nullptr;                          // recorded behind the last H2D copy of batch_decode
+    bool h2d_in_flight = false;                             // the pinned side-info may still be read by the copy engine
 
     ~opusgpu_batch()
     {
         (void)hipSetDevice(device);
         if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
+        if (h2d_done) (void)hipEventDestroy(h2d_done);
         h_celt.release(); h_leaves.release(); h_silk.release(); h_refs.release();
         d_celt.release(); d_leaves.release(); d_silk.release(); d_refs.release(); d_work.release();
         if (d_celt_state) (void)hipFree(d_celt_state);
@@ -140,6 +143,7 @@ int opusgpu_batch_create(opusgpu_batch **out, uint32_t nstreams, int channels, i
     b->seen.assign(nstreams, 0);
     b->pcm_stride = size_t(OPUSGPU_MAX_FRAME) * channels;
     hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&b->h2d_done, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc((void **)&b->d_celt_state, size_t(nstreams) * sizeof(OgCeltState));
     if (e == hipSuccess) e = hipMemsetAsync(b->d_celt_state, 0, size_t(nstreams) * sizeof(OgCeltState), b->stream);
     if (e == hipSuccess) e = hipMalloc(&b->d_silk_state, opusgpu_silk_state_bytes(nstreams));
@@ -163,6 +167,13 @@ int opusgpu_batch_send(opusgpu_batch *b, const uint8_t *const *pkts, const uint3
         uint32_t s = stream_ids ? stream_ids[i] : i;
         if (s >= b->nstreams || b->seen[s]) return OPUSGPU_BAD_ARG;
         b->seen[s] = 1;
+    }
+    // batch_decode is asynchronous: its H2D copies read the pinned side-info arrays this call is about to rewrite.  Wait
+    // for the copies (not for the kernels) of the previous decode before touching them.
+    if (b->h2d_in_flight) {
+        OG_HIP(hipSetDevice(b->device));
+        OG_HIP(hipEventSynchronize(b->h2d_done));
+        b->h2d_in_flight = false;
     }
     std::fill(b->nsamples.begin(), b->nsamples.end(), 0);
 
@@ -288,6 +299,8 @@ int opusgpu_batch_decode(opusgpu_batch *b)
     if (b->h_silk.n) OG_HIP(hipMemcpyAsync(b->d_silk.p, b->h_silk.p, b->h_silk.n * sizeof(OgSilkFrame), hipMemcpyHostToDevice, b->stream));
     if ((rc = b->d_refs.reserve(b->h_refs.n + 1))) return rc;
     if (b->h_refs.n) OG_HIP(hipMemcpyAsync(b->d_refs.p, b->h_refs.p, b->h_refs.n * sizeof(OgLeafRef), hipMemcpyHostToDevice, b->stream));
+    OG_HIP(hipEventRecord(b->h2d_done, b->stream));
+    b->h2d_in_flight = true;
     {
         uint32_t maxc = 0;
         for (size_t r = 0; r + 1 < b->celt_round_off.size(); r++) maxc = std::max(maxc, b->celt_round_off[r + 1] - b->celt_round_off[r]);

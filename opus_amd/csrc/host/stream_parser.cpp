@@ -82,6 +82,8 @@ int StreamParser::parse(const uint8_t *pkt, size_t len, OgFrameInfo *frames, std
             fi.has_celt = 1;
         }
         fi.final_range = rd.rng();
+        fi.tell_bits = uint32_t(rd.tell());
+        fi.budget_bits = uint32_t(rd.storage_bits());
     }
     prev_mode_ = p.mode;
     return p.nframes;

@@ -60,6 +60,7 @@ int orc_extract_collapse_mask(const int *y, int n, int b);
 void orc_haar1(float *x, int n0, int stride);
 void orc_exp_rotation(float *x, int len, int stride, int k, int spread);
 void orc_stereo_merge(float *x, float *y, float mid, int n);
+void orc_fft(const float *in_re_im, int stride, int n, float *out_re_im);
 void orc_imdct_raw(const float *in, int stride, int n2, float *D);
 void orc_imdct_raw_direct(const float *in, int stride, int n2, double *D);
 const float *orc_celt_window(void);

@@ -603,6 +603,17 @@ static void fft_rec(const cpx *in, cpx *out, int n, int stride, int nfull)
     }
 }
 
+/* the forward DFT above on interleaved (re, im) pairs taken `stride` complex elements apart: lets the tests hold it against
+ * the reference's one FFT known-answer vector (celt/imdct15.rs:213-251, the radix-5 butterfly on every third of 15 inputs) */
+void orc_fft(const float *in, int stride, int n, float *out)
+{
+    cpx a[480], b[480];
+    if (n < 1 || n > 480) return;
+    for (int i = 0; i < n; i++) { a[i].r = in[2 * i * stride]; a[i].i = in[2 * i * stride + 1]; }
+    fft_rec(a, b, n, 1, n);
+    for (int i = 0; i < n; i++) { out[2 * i] = b[i].r; out[2 * i + 1] = b[i].i; }
+}
+
 /* Inverse MDCT of n2 coefficients (stride `stride`) -> n2 raw samples D[0..n2).  Structure of RFC 6716
  * mdct.c clt_mdct_backward: pre-twiddle, n2/2-point complex FFT, post-twiddle, no scaling.  Closed form
  * (tests check it):  D[n] = -sum_m X[m] cos(pi/n2 (m+1/2)(n2-n-1/2)). */

@@ -82,3 +82,19 @@ class CeltLaunch:
                                           up["refs"].data_ptr(), up["classes"], self.work.data_ptr(), state.data_ptr(),
                                           pcm.data_ptr(), stride, C.byref(dbg) if dbg is not None else None, stream)
         assert rc == 0, self.lib.opusgpu_last_error()
+
+
+def oracle_check_last_step(pcm_rows, packets, streams, nframes_done, T, what="step"):
+    """The last T frames of `streams` (rows of the last step's PCM, numpy [S, T*960*2]) against the CPU oracle, which
+    decodes each of those streams from its first packet (decoder state carries across steps).  -> worst scaled error"""
+    import orc
+    worst = 0.0
+    for s in streams:
+        ref = orc.Decoder(2)
+        for f in range(nframes_done):
+            r = ref.decode(packets[s, f].tobytes())
+            t = f - (nframes_done - T)
+            if t >= 0:
+                out = pcm_rows[s][t * 1920:(t + 1) * 1920].reshape(960, 2)
+                worst = max(worst, check_pcm(r, out, f"{what}: stream {s} frame {f}"))
+    return worst

@@ -179,6 +179,41 @@ def test_matroska_malformed(vec):
         assert e.value.code == A.INVALID_DATA
 
 
+def test_matroska_nesting_is_bounded(vec):
+    """master elements are entered only below their proper parent, so a crafted file cannot drive the walker deep:
+    100 000 nested BlockGroups (2 bytes a level: 0xA0 + unknown... here 0xA0 with a size that covers the rest) in a
+    Cluster are malformed, not a stack overflow; the same for Segments in Segments and Clusters in Clusters"""
+    extra, pk = vec[1]
+    head = _el("1A45DFA3", _el("4282", b"matroska"))
+    tracks = _el("1654AE6B", _el("AE", _el("D7", _uint(2)) + _el("86", b"A_OPUS") + _el("63A2", extra)))
+    depth = 100000
+    nest = b""
+    for _ in range(depth):                                    # innermost first; sizes grow, so widths are minimal
+        nest = b"\xa0" + _vint(len(nest)) + nest
+    for bad in (head + _el("18538067", tracks + _el("1F43B675", nest)),
+                head + _el("18538067", tracks + _el("1F43B675", _el("1F43B675", _el("1F43B675", b"")))),
+                head + _el("18538067", _el("18538067", tracks))):
+        with pytest.raises(OpusError) as e:
+            Demuxer(bad)
+        assert e.value.code == A.INVALID_DATA
+    # many unknown-size Clusters in a row are walked iteratively (each ends where the next one starts)
+    blk = _vint(2) + struct.pack(">h", 0) + b"\x80" + pk[0]
+    many = b"".join(bytes.fromhex("1F43B675") + b"\x01\xff\xff\xff\xff\xff\xff\xff" + _el("E7", _uint(i)) + _el("A3", blk)
+                    for i in range(20000))
+    d = Demuxer(head + bytes.fromhex("18538067") + b"\x01\xff\xff\xff\xff\xff\xff\xff" + tracks + many)
+    assert len(d) == 20000 and d.packet(19999)[0] == pk[0]
+
+
+def test_matroska_track_needs_a_usable_opus_head(vec):
+    """an A_OPUS track with an empty or short CodecPrivate, or a family != 0 header cut short, does not open"""
+    extra, pk = vec[1]
+    fam1_short = extra[:18] + b"\x01"                           # mapping family 1 without its stream counts / mapping
+    for bad_extra in (b"", extra[:12], fam1_short):
+        with pytest.raises(OpusError) as e:
+            Demuxer(make_mka(bad_extra, pk[:3]))
+        assert e.value.code == A.INVALID_DATA
+
+
 # ------------------------------------------------------------------ Ogg
 @pytest.mark.parametrize("per_page,max_segs", [(4, 255), (1, 255), (7, 3)])
 def test_ogg_roundtrip(vec, per_page, max_segs):

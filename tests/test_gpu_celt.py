@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import orc
-from gpu_util import CeltLaunch, HostParser, check_pcm
+from gpu_util import CeltLaunch, HostParser, check_pcm, oracle_check_last_step
 from opus_amd import BatchDecoder, Decoder, _abi as A, synth
 
 pytestmark = pytest.mark.gpu
@@ -68,6 +68,25 @@ def test_batch_subset_and_bad_packet():
     dec.decode()
     check_pcm(refs[0].decode(V[1]), dec.read(0))
     check_pcm(refs[1].decode(V[0]), dec.read(1))
+
+
+def test_send_while_decode_in_flight():
+    """decode(sync=False) -> send -> sync: batch_send waits for the previous decode's H2D copies before it rewrites the
+    pinned side-info, so back-to-back calls with no sync in between still decode every frame right.  Enough streams that
+    the copies take a while (4096 x 668-byte headers + leaves)."""
+    ns, nf = 4096, 6
+    pk = synth.celt_fb_stereo_packets(range(ns), nf, 160)
+    dec = BatchDecoder(ns, 2, 0)
+    sample = [0, 5, 1000, 2047, 4095]
+    refs = {s: orc.Decoder(2) for s in sample}
+    lists = [[pk[s, f].tobytes() for s in range(ns)] for f in range(nf)]
+    assert not any(dec.send(lists[0]))
+    for f in range(nf):
+        dec.decode(sync=False)
+        if f + 1 < nf:
+            assert not any(dec.send(lists[f + 1]))     # parses (and rewrites the staging arrays) while frame f is in flight
+        for s in sample:                               # read() synchronises; frame f's PCM is still in the device rows
+            check_pcm(refs[s].decode(lists[f][s]), dec.read(s), f"stream {s} frame {f}")
 
 
 def test_flush_resets_stream():
@@ -240,3 +259,34 @@ def test_split_launches_match_single_call():
         for t in range(T):
             r = ref.decode(pk[0, k * T + t].tobytes())
             check_pcm(r, a[k][t * 1920:(t + 1) * 1920].reshape(960, 2), f"step {k} frame {t}")
+
+
+def test_bench_launch_shape_against_oracle():
+    """bench.py's exact launch shape -- 4096 streams x 8 frames per launch (32768 frames), frames_per_group = 8 -- for three
+    consecutive launches on the same decoder state, through the layer-3b entry points bench.py calls; the first, the last
+    and interior streams against the CPU oracle after every launch, every sample finite.  (Round 1's oracle comparisons
+    ran at frames_per_group = 1, or T = 4 with 96 streams; DESIGN.md section 5a has the fault this shape once showed.)"""
+    import torch
+    from opus_amd import steps as stepmod
+    lib = A.load()
+    dev = torch.device("cuda:0")
+    S, T, nsteps = 4096, 8, 3
+    pk = synth.celt_fb_stereo_packets(range(S), T * nsteps, 160)
+    parser = BatchDecoder(S, 2, 0)
+    host_steps, _ = stepmod.build_celt_steps(parser, pk, T, nsteps)
+    parser.close()
+    state = torch.zeros(S * C.sizeof(A.CeltState), dtype=torch.uint8, device=dev)
+    work = torch.zeros(lib.opusgpu_celt_work_bytes(S * T), dtype=torch.uint8, device=dev)
+    stride = T * 960 * 2
+    pcm = torch.zeros(S * stride, dtype=torch.float32, device=dev)
+    sample = [0, 1, 777, 2047, 2048, 3333, 4095]
+    for k, st in enumerate(host_steps):
+        hdr, leaves, refs = (torch.from_numpy(x).to(dev) for x in (st.hdr, st.leaves, st.refs))
+        torch.cuda.synchronize()
+        assert lib.opusgpu_launch_celt_pvq(hdr.data_ptr(), leaves.data_ptr(), S * T, refs.data_ptr(), st.classes, work.data_ptr(), None, None) == 0
+        assert lib.opusgpu_launch_celt_spectrum(hdr.data_ptr(), S * T, work.data_ptr(), None, None) == 0
+        assert lib.opusgpu_launch_celt_tail(hdr.data_ptr(), S * T, T, work.data_ptr(), state.data_ptr(), pcm.data_ptr(), stride, None, None) == 0
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(pcm).all()), f"launch {k}"
+        rows = pcm.view(S, stride)[sample].cpu().numpy()
+        oracle_check_last_step({s: rows[i] for i, s in enumerate(sample)}, pk, sample, (k + 1) * T, T, f"launch {k}")

@@ -24,6 +24,24 @@ def test_abi_exports_every_declared_symbol():
     assert lib.opusgpu_strerror(A.INVALID_DATA) == b"invalid data"
 
 
+def test_describe_matches_the_reference_descriptor():
+    """Descriptor::describe of OPUS_DESCR (decoder.rs:190-197): codec, name and mime are the reference's strings"""
+    d = A.load().opusgpu_describe().contents
+    assert (d.codec, d.name, d.mime) == (b"opus", b"opus", b"audio/OPUS")
+    assert d.desc and b"opus" in d.desc
+
+
+def test_static_library_carries_the_same_entry_points():
+    """libopusgpu.a (the static flavour north_star names) defines every symbol the header declares"""
+    import os
+    import subprocess
+    a = os.path.join(A.ROOT, "opus_amd", "libopusgpu.a")
+    assert os.path.exists(a), "build() archives the objects next to the shared library"
+    out = subprocess.run(["nm", "--defined-only", "-g", a], capture_output=True, text=True).stdout
+    defined = {l.split()[-1] for l in out.splitlines() if " T " in l}
+    assert set(A.PROTOTYPES) <= defined, set(A.PROTOTYPES) - defined
+
+
 def test_header_declares_what_the_mirror_binds():
     import os
     import re
@@ -77,6 +95,29 @@ def test_framing_matches_oracle_on_all_vectors():
             assert (a["mode"], a["bandwidth"], a["frame_size"], a["stereo"], a["code"], a["nframes"]) == (
                 o.mode, o.bandwidth, o.frame_size, o.stereo, o.code, o.nframes)
             assert a["frames"] == [(o.off[i], o.len[i]) for i in range(o.nframes)]
+
+
+def test_range_decoder_never_overruns_on_the_vectors():
+    """every frame of every packet of the 12 RFC vectors: the host parser ends inside the frame's bit budget, and so does
+    the oracle (which raises on an overrun).  tf / allocation / theta / bits2pulses have no reference KAT; a
+    misread symbol would desynchronise the decoder and overrun some frame of these 1.1e4 packets almost surely."""
+    frames = 0
+    for vid, (_, pk) in sorted(orc.load_vectors().items()):
+        hp = HostParser(2)
+        for i, p in enumerate(pk):
+            n, _, _, _ = hp.parse(p)
+            assert n > 0, (vid, i, n)
+            for f in range(n):
+                # SILK-only frames are exempt: the encoder strips their trailing zero bytes (RFC 6716 4.1.1: the decoder
+                # reads zeros past the end), so their tell may legitimately pass the stored length
+                if hp.fi[f].has_celt:
+                    assert hp.fi[f].tell_bits <= hp.fi[f].budget_bits, (vid, i, f, hp.fi[f].tell_bits, hp.fi[f].budget_bits)
+            frames += n
+        # the oracle over the whole vector (state carries across packets): any overrun raises
+        d = orc.Decoder(2)
+        for p in pk:
+            d.decode(p)
+    assert frames > 11000
 
 
 def _compare_frame(hd, leaves, fi, t):

@@ -86,6 +86,29 @@ def test_haar1():  # celt/decoder.rs:2451-2481
         assert np.array_equal(a, b)
 
 
+def test_fft5():  # celt/imdct15.rs:213-251: radix-5 butterfly on a[0], a[3], .. of a[v] = (v, -v), v < 15
+    """The reference's `fft5` test asserts exact f32 equality with its own butterfly's operation order; that function is an
+    orphan (IMDCT15 is never constructed outside its tests) and the oracle's DFT is a different
+    factorisation, so the bar here is f32 rounding (2 ulp of the largest output), not bit equality."""
+    k = K["fft5"]
+    a = np.array([[v, -v] for v in range(15)], np.float32)
+    out = np.zeros((5, 2), np.float32)
+    L.orc_fft(a.ctypes.data_as(C.c_void_p), k["stride"], 5, out.ctypes.data_as(C.c_void_p))
+    # the reference's butterfly uses the e^{+2 pi i jk/5} kernel (its IMDCT is built on an inverse FFT), the oracle's DFT the
+    # forward one: output k of one is output (5 - k) mod 5 of the other
+    want = np.array(k["out"], np.float32)[[0, 4, 3, 2, 1]]
+    assert np.abs(out - want).max() <= 2 * np.spacing(np.float32(30.0)), (out, want)
+    # and the sizes the IMDCT uses, against numpy's f64 FFT
+    rng = np.random.default_rng(5)
+    for n in (15, 60, 120, 240, 480):
+        x = rng.standard_normal((n, 2)).astype(np.float32)
+        y = np.zeros((n, 2), np.float32)
+        L.orc_fft(x.ctypes.data_as(C.c_void_p), 1, n, y.ctypes.data_as(C.c_void_p))
+        ref = np.fft.fft(x[:, 0].astype(np.float64) + 1j * x[:, 1].astype(np.float64))
+        err = np.abs((y[:, 0] + 1j * y[:, 1]) - ref).max()
+        assert err <= 2e-5 * np.abs(ref).max(), (n, err)
+
+
 def test_lsf_to_lpc():  # silk/tests.rs:847-870
     k = K["lsf_to_lpc"]
     nlsf = (C.c_int16 * 10)(*k["nlsf"])

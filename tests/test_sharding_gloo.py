@@ -68,3 +68,32 @@ def test_shards_generate_the_same_streams_as_one_rank():
     whole = synth.celt_fb_stereo_packets(np.arange(2 * S, dtype=np.uint64), 2, 160)
     parts = [synth.celt_fb_stereo_packets(sharding.shard_stream_ids(r, 2, S), 2, 160) for r in range(2)]
     assert np.array_equal(np.concatenate(parts), whole)
+
+
+def test_bench_entry_point_spawns_ranks():
+    """`python bench.py --gpus 2` outside torch.distributed.run starts two ranks itself (before any GPU call) and rank 0
+    prints one line with n_gpus 2; here on the host half only (--parse-only over gloo: no GPU in this container)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--parse-only", "--backend", "gloo",
+                        "--streams", "6", "--steps", "2", "--frames-per-step", "2"], capture_output=True, text=True, timeout=240, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak"
+    assert out["config"]["shards"] == [[0, 5], [6, 11]]               # contiguous, disjoint blocks of streams
+    assert out["config"]["leaves"] > 0 and out["value"] > 0
+
+
+def test_bench_rejects_mismatched_world_size():
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--parse-only"], capture_output=True, text=True,
+                       timeout=120, env=env)
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr

@@ -18,7 +18,7 @@ import sys
 from pathlib import Path
 
 REF = Path(sys.argv[1] if len(sys.argv) > 1 else "/root/reference/src")
-OUT = Path(__file__).resolve().parent.parent / "opus_amd" / "csrc" / "rfc6716_tables.h"
+OUT = Path(sys.argv[2]) if len(sys.argv) > 2 else Path(__file__).resolve().parent.parent / "opus_amd" / "csrc" / "rfc6716_tables.h"
 
 
 class Icdf:
