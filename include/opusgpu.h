@@ -239,6 +239,20 @@ int opusgpu_launch_celt_spectrum(const OgCeltHdr *hdr, uint32_t nframes, void *w
 int opusgpu_launch_celt_tail(const OgCeltHdr *hdr, uint32_t nframes, uint32_t frames_per_group, void *work, OgCeltState *state,
                              float *pcm, size_t pcm_stride_floats, const OgCeltDebug *debug, void *stream);
 
+/* opusgpu_launch_celt for callers that cannot allocate device memory or bring a workspace: code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc.  It has no counterpart in the reference (which has no device at
+ * all).  The `work` scratch is a static __device__ array inside the library (7.6 MiB per GPU, held until the process
+ * ends) instead of an argument; inputs, state and outputs are still the caller's.  Limits: nframes <=
+ * opusgpu_noalloc_max_frames() (256) per call, else OPUSGPU_BAD_ARG with opusgpu_last_error() set; opusgpu_init(device)
+ * must have run once on the device (that call makes the library's only allocation, the constant tables).  Every call on
+ * a GPU shares that GPU's array: calls that overlap in time on one GPU (two streams, two threads) race -- order them on
+ * one stream or behind events.  Calls hipMemsetAsync + the four kernels on `stream`; no hipMalloc / hipFree, no
+ * synchronisation. */
+uint32_t opusgpu_noalloc_max_frames(void);
+int opusgpu_launch_celt_noalloc(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, uint32_t nframes, uint32_t frames_per_group,
+                                const OgLeafRef *refs, const uint32_t class_counts[4], OgCeltState *state, float *pcm,
+                                size_t pcm_stride_floats, void *stream);
+
 /* SILK: K4 LTP + LPC synthesis with one lane per (stream, channel) over struct-of-arrays state (replaces
  * silk/decoder.rs:1775-1898), then K5 + K6: stereo unmix / mono copy (silk/decoder.rs:2012-2061, :2104-2113) and the
  * internal-rate -> 48 kHz resampler the reference lacks, writing interleaved PCM at OgSilkFrame.pcm_off.

@@ -120,6 +120,8 @@ PROTOTYPES = {
     "opusgpu_launch_celt_frames": (C.c_int, [_P, C.c_uint32, C.c_uint32, _P, _P, _P, C.c_size_t, C.POINTER(CeltDebug), _P]),
     "opusgpu_launch_celt_spectrum": (C.c_int, [_P, C.c_uint32, _P, C.POINTER(CeltDebug), _P]),
     "opusgpu_launch_celt_tail": (C.c_int, [_P, C.c_uint32, C.c_uint32, _P, _P, _P, C.c_size_t, C.POINTER(CeltDebug), _P]),
+    "opusgpu_noalloc_max_frames": (C.c_uint32, []),
+    "opusgpu_launch_celt_noalloc": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, _P, C.POINTER(C.c_uint32), _P, _P, C.c_size_t, _P]),
     "opusgpu_sort_pvq_leaves": (C.c_uint32, [_P, C.c_uint32, _P, _P, C.c_uint32, C.POINTER(C.c_uint32)]),
     "opusgpu_celt_work_bytes": (C.c_size_t, [C.c_uint32]),
     "opusgpu_silk_state_bytes": (C.c_size_t, [C.c_uint32]),

@@ -128,6 +128,13 @@ __global__ __launch_bounds__(OG_WGT) void og_celt_tail_kernel(const OgCeltHdr *_
     }                                                                                   // stores precede frame t + 1's loads
 }
 
+// Scratch of opusgpu_launch_celt_noalloc (include/opusgpu.h): the `work` buffer of a launch of up to OG_NOALLOC_MAX_FRAMES
+// frames, held by every GPU the library runs on until the process ends (7.6 MiB).  In host code the array's NAME is only a
+// stand-in for the symbol: its device address on a given GPU comes from hipGetSymbolAddress (opusgpu_init, once per device,
+// kept in DevCtx::scratch) and that pointer is what every kernel argument and memset below uses.
+#define OG_NOALLOC_MAX_FRAMES 256
+static __device__ __align__(256) unsigned char og_noalloc_scratch[OG_WORK_BYTES(OG_NOALLOC_MAX_FRAMES)];
+
 namespace og {
 
 thread_local std::string g_last_error;
@@ -141,6 +148,7 @@ int device_fail(hipError_t e, const char *what)
 // Per-device context, built once: the constant tables.
 struct DevCtx {
     OgCeltTables *tables = nullptr;
+    void *scratch = nullptr;            // this device's copy of og_noalloc_scratch (hipGetSymbolAddress)
 };
 static std::mutex g_tables_mu;
 static DevCtx g_ctx[64];
@@ -159,8 +167,11 @@ static int ctx_for_device(int device, DevCtx **out)
         hipError_t e = hipMalloc(&dev, sizeof(OgCeltTables));
         if (e == hipSuccess) e = hipMemcpy(dev, host, sizeof(OgCeltTables), hipMemcpyHostToDevice);
         delete host;
+        void *scr = nullptr;                             // each GPU holds its own copy of the array at its own address
+        if (e == hipSuccess) e = hipGetSymbolAddress(&scr, HIP_SYMBOL(og_noalloc_scratch));
         (void)hipSetDevice(prev);
-        if (e != hipSuccess) return device_fail(e, "celt device set-up");
+        if (e != hipSuccess) { if (dev) (void)hipFree(dev); return device_fail(e, "celt device set-up"); }
+        c.scratch = scr;
         c.tables = dev;
     }
     *out = &c;
@@ -273,6 +284,37 @@ int opusgpu_launch_celt(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, uint32_t
     int rc = opusgpu_launch_celt_pvq(hdr, leaves, nframes, refs, class_counts, work, debug, stream);
     if (rc) return rc;
     return opusgpu_launch_celt_frames(hdr, nframes, frames_per_group, work, state, pcm, pcm_stride_floats, debug, stream);
+}
+
+uint32_t opusgpu_noalloc_max_frames(void) { return OG_NOALLOC_MAX_FRAMES; }
+
+int opusgpu_launch_celt_noalloc(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, uint32_t nframes, uint32_t frames_per_group,
+                                const OgLeafRef *refs, const uint32_t class_counts[4], OgCeltState *state, float *pcm,
+                                size_t pcm_stride_floats, void *stream)
+{
+    if (nframes == 0) return OPUSGPU_OK;
+    if (nframes > OG_NOALLOC_MAX_FRAMES) {
+        og::g_last_error = "opusgpu_launch_celt_noalloc: " + std::to_string(nframes) + " frames exceed the static scratch (" +
+                           std::to_string(OG_NOALLOC_MAX_FRAMES) + " frames per call); split the batch or use opusgpu_launch_celt";
+        return OPUSGPU_BAD_ARG;
+    }
+    int device = 0;
+    OG_HIP(hipGetDevice(&device));
+    if (device < 0 || device >= 64) return OPUSGPU_BAD_ARG;
+    void *scratch = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(og::g_tables_mu);
+        scratch = og::g_ctx[device].tables ? og::g_ctx[device].scratch : nullptr;
+    }
+    if (!scratch) {                                     // set-up allocates (the tables): it is opusgpu_init's job, not this call's
+        og::g_last_error = "opusgpu_launch_celt_noalloc: call opusgpu_init(device) once before the first launch on a device";
+        return OPUSGPU_BAD_ARG;
+    }
+    // the array keeps the last call's contents; the kernels hand the parts that must start at zero back zeroed, but a call
+    // that was cut short (a failed launch) would not have: clear this call's part first
+    OG_HIP(hipMemsetAsync(scratch, 0, OG_WORK_BYTES(nframes), (hipStream_t)stream));
+    return opusgpu_launch_celt(hdr, leaves, nframes, frames_per_group, refs, class_counts, scratch, state, pcm, pcm_stride_floats,
+                               nullptr, stream);
 }
 
 }  // extern "C"
