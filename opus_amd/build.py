@@ -9,7 +9,7 @@ OUT = os.path.join(ROOT, "opus_amd", "libopusgpu.so")
 OUT_STATIC = os.path.join(ROOT, "opus_amd", "libopusgpu.a")     # the same objects archived (north_star: "gfx950 static library")
 
 HOST_SOURCES = ["host/packet.cpp", "host/celt_parse.cpp", "host/silk_parse.cpp", "host/stream_parser.cpp",
-                "host/capi_parse.cpp", "host/container.cpp", "host/celt_tables.cpp", "host/silk_tables.cpp", "host/engine.cpp"]
+                "host/capi_parse.cpp", "host/leaf_sort.cpp", "host/container.cpp", "host/celt_tables.cpp", "host/silk_tables.cpp", "host/engine.cpp"]
 HIP_SOURCES = ["hip/celt_launch.hip", "hip/silk_launch.hip"]
 
 
@@ -69,6 +69,7 @@ def build_emu(variant="", defines=()):
     srcs = [os.path.join(ROOT, "tests", "emu", f) for f in os.listdir(os.path.join(ROOT, "tests", "emu")) if f.endswith(".cpp")]
     srcs.append(os.path.join(CSRC, "host", "celt_tables.cpp"))
     srcs.append(os.path.join(CSRC, "host", "silk_tables.cpp"))
+    srcs.append(os.path.join(CSRC, "host", "leaf_sort.cpp"))
     if not _newer(out, _all_inputs() + srcs + [os.path.abspath(__file__)]):
         return out
     subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fno-strict-aliasing", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",

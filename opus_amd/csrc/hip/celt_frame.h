@@ -668,9 +668,14 @@ OG_DEV void og_wg_fft_stage(const OgCf *src, OgCf *dst, int tsh, const OgCf *W)
     OG_LANES_END
 }
 
-// RFC 6716 celt.c comb_filter, in place, for one channel by one wave (inside an OG_WAVES section): y points at the
-// channel's sample 0 inside L.out.  The recursion reaches back >= 13 samples, so `step` samples are independent at a
-// time; the steps are ordered by the wave's own LDS ordering, no workgroup barrier.
+// RFC 6716 celt.c comb_filter, in place, for one channel by one wave (inside an OG_WAVES section): y points at the section's
+// sample 0 inside the channel's time buffer (history below it).  y[i] depends on y[i - T - 2 .. i - T + 2], so T - 2 samples
+// are independent at a time.  The section has two parts: the cross-fade from the old to the new parameter set over the first
+// `overlap` samples (both periods are read: steps of min(T0, T1) - 2 samples through LDS), and the rest with the new set alone.
+// For T1 <= 62 the rest runs in registers: a step's T1 - 2 new samples sit in lanes 4 .. T1 + 1 of one register behind the
+// previous step's last four (lanes 0 .. 3), the five taps are that register shifted down by 0 .. 4 lanes (DPP), and LDS only
+// sees the inputs coming in and the results going out -- nothing waits for an LDS round trip.  Longer periods take steps of up to
+// 128 samples through LDS (at most a dozen steps).  Same operations in the same order on every path.
 OG_DEV void og_wave_comb_filter(float *y, int T0, int T1, int n, float g0, float g1, int tap0, int tap1,
                                 const float *window, const float (*taps)[4])
 {
@@ -681,23 +686,65 @@ OG_DEV void og_wave_comb_filter(float *y, int T0, int T1, int n, float g0, float
     const float g10 = g1 * taps[tap1][0], g11 = g1 * taps[tap1][1], g12 = g1 * taps[tap1][2];
     const int overlap = (g0 == g1 && T0 == T1 && tap0 == tap1) ? 0 : 120;
     const int stop = g1 == 0.f ? overlap : n;          // with g1 == 0 only the cross-fade runs
-    int step = (T0 < T1 ? T0 : T1) - 2;
+    {
+        int step = (T0 < T1 ? T0 : T1) - 2;
+        if (step > 64) step = 64;
+        for (int i0 = 0; i0 < overlap; i0 += step) {
+            const int i1 = i0 + step < overlap ? i0 + step : overlap;
+            OG_WAVE_BEGIN(lane)
+            const int i = i0 + lane;
+            if (i < i1) {
+                const float f = window[i] * window[i];
+                const float *q0 = y + i - T0, *q1 = y + i - T1;
+                y[i] = y[i] + ((1.f - f) * g00) * q0[0]
+                     + ((1.f - f) * g01) * (q0[1] + q0[-1])
+                     + ((1.f - f) * g02) * (q0[2] + q0[-2])
+                     + (f * g10) * q1[0]
+                     + (f * g11) * (q1[1] + q1[-1])
+                     + (f * g12) * (q1[2] + q1[-2]);
+            }
+            OG_WAVE_END
+        }
+    }
+    if (stop <= overlap) return;
+    if (T1 <= 62) {
+        const int S = T1 - 2;                           // new samples per step
+        OG_WAVE_VAR(float, R);                          // lane l: y[i0 - 4 + l], i0 = first sample of the step to come
+        OG_WAVE_VAR(float, X);                          // lane l >= 4: the step's input y[i0 + l - 4]
+        OG_WAVE_VAR(float, s1); OG_WAVE_VAR(float, s2); OG_WAVE_VAR(float, s3); OG_WAVE_VAR(float, s4); OG_WAVE_VAR(float, H);
+        OG_WAVE_BEGIN(lane)
+        const int i = overlap + lane - 4;
+        OG_WV(R) = lane < S + 4 ? y[i - S] : 0.f;
+        OG_WV(X) = (lane >= 4 && lane < S + 4 && i < stop) ? y[i] : 0.f;
+        OG_WV(s1) = OG_WV(s2) = OG_WV(s3) = OG_WV(s4) = OG_WV(H) = 0.f;
+        OG_WAVE_END
+        for (int i0 = overlap; i0 < stop; i0 += S) {
+            OG_WAVE_SHR1(s1, R)
+            OG_WAVE_SHR1(s2, s1)
+            OG_WAVE_SHR1(s3, s2)
+            OG_WAVE_SHR1(s4, s3)
+            OG_WAVE_PULL(H, R, S + lane)                // lanes 0 .. 3: this step's history = the last four of R
+            OG_WAVE_REGS_BEGIN(lane)
+            const int i = i0 + lane - 4;
+            const bool mine = lane >= 4 && lane < S + 4;
+            // y[i - T1 + k], k = 0, +-1, +-2, are R of lanes l - 2, l - 1 / l - 3, l / l - 4
+            const float v = OG_WV(X) + g10 * OG_WV(s2) + g11 * (OG_WV(s1) + OG_WV(s3)) + g12 * (OG_WV(R) + OG_WV(s4));
+            if (mine && i < stop) y[i] = v;
+            OG_WV(R) = lane < 4 ? OG_WV(H) : v;
+            OG_WV(X) = (mine && i + S < stop) ? y[i + S] : 0.f;
+            OG_WAVE_REGS_END
+        }
+        OG_WAVE_FENCE
+        return;
+    }
+    int step = T1 - 2;
     if (step > 128) step = 128;
-    for (int i0 = 0; i0 < stop; i0 += step) {
+    for (int i0 = overlap; i0 < stop; i0 += step) {
         const int i1 = i0 + step < stop ? i0 + step : stop;
         OG_WAVE_BEGIN(lane)
         for (int i = i0 + lane; i < i1; i += 64) {
-            if (i < overlap) {
-                const float f = window[i] * window[i];
-                y[i] = y[i] + ((1.f - f) * g00) * y[i - T0]
-                     + ((1.f - f) * g01) * (y[i - T0 + 1] + y[i - T0 - 1])
-                     + ((1.f - f) * g02) * (y[i - T0 + 2] + y[i - T0 - 2])
-                     + (f * g10) * y[i - T1]
-                     + (f * g11) * (y[i - T1 + 1] + y[i - T1 - 1])
-                     + (f * g12) * (y[i - T1 + 2] + y[i - T1 - 2]);
-            } else {
-                y[i] = y[i] + g10 * y[i - T1] + g11 * (y[i - T1 + 1] + y[i - T1 - 1]) + g12 * (y[i - T1 + 2] + y[i - T1 - 2]);
-            }
+            const float *q1 = y + i - T1;
+            y[i] = y[i] + g10 * q1[0] + g11 * (q1[1] + q1[-1]) + g12 * (q1[2] + q1[-2]);
         }
         OG_WAVE_END
     }
@@ -716,8 +763,14 @@ OG_DEV void og_celt_spectrum(const OgCeltHdr *hg, const OgBandPlan *plan, const 
     uint8_t *dbg_collapse = dbg.collapse;
     OG_STAMP(0)
 
-    // ---- phase 0: stage the side-info, the band plan and the constants in LDS; fetch K1's coefficients
+    // ---- phase 0: stage the side-info, the band plan and the constants in LDS; fetch K1's coefficients.  The frame's scratch
+    //      row holds K1's output only where K1 wrote: the leaves of every (band, buffer) that has a PVQ leaf (its zero-pulse
+    //      leaves included: opusgpu_sort_pvq_leaves lists them and K1 stores zeros) and the one-bin bands' signs (plan kernel).
+    //      Everything else in the row is left over from earlier launches and is replaced by zero here, so nobody has to hand
+    //      the rows back zero-filled.
     const int lm0 = hg->lm & 3;
+    struct OgRow2 { OgF4 v[2]; uint32_t bb[2]; };
+    OG_LANE_VAR(OgRow2, rowv);
     OG_LANES_BEGIN(tid)
     {
         const uint32_t *src = (const uint32_t *)hg;
@@ -729,9 +782,40 @@ OG_DEV void og_celt_spectrum(const OgCeltHdr *hg, const OgBandPlan *plan, const 
         for (int p = tid; p < OG_LDS_OPS * 4; p += OG_WG) od[p] = ps[OG_PLAN_HEAD_BYTES / 4 + p];
     }
     if (tid < 24) { L.k.emeans[tid] = T->k.emeans[tid]; L.k.ebands[tid] = T->k.ebands[tid]; L.k.width[tid] = T->k.width[tid]; }
-    // K1's output for this frame: shaped PVQ coefficients (zero elsewhere)
-    for (int p = tid; p < 2 * 960 / 4; p += OG_WG) ((OgF4 *)&L.X[0][0])[p] = ((const OgF4 *)coef_row)[p];      // 16 bytes per lane
+#pragma unroll
+    for (int j = 0; j < 2; j++) {                       // 2 * 960 / 4 = 480 pieces of 16 bytes; piece p = bins 4p' .. 4p'+3 of buffer p / 240
+        const int p = tid + j * OG_WG;
+        OG_LV(rowv).v[j] = OgF4{0.f, 0.f, 0.f, 0.f};
+        OG_LV(rowv).bb[j] = 0xFFFFFFFFu;
+        if (p < 480) {
+            OG_LV(rowv).v[j] = ((const OgF4 *)coef_row)[p];
+            OG_LV(rowv).bb[j] = ((const uint32_t *)T->bin2band[lm0])[p >= 240 ? p - 240 : p];     // the four bins' bands
+        }
+    }
     for (int p = tid; p < 2 * 800; p += OG_WG) L.R[p] = 0.f;
+    OG_LANES_END
+    OG_LANES_BEGIN(tid)
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int p = tid + j * OG_WG;
+        if (p < 480) {
+            const int slot = p >= 240;
+            const OgF4 v = OG_LV(rowv).v[j];
+            const uint32_t bb = OG_LV(rowv).bb[j];
+            float e[4] = {v.x, v.y, v.z, v.w};
+            const int b_lo = L.hdr.start, b_hi = (L.hdr.flags & OG_F_SILENCE) ? 0 : (int)L.hdr.end;   // (a silent frame's row is untouched)
+#pragma unroll
+            for (int k = 0; k < 4; k++) {               // branch-free on purpose: one LDS read and one select per bin
+                const int b = (int)((bb >> (8 * k)) & 255u);
+                const OgCeltBand bd = L.hdr.band[b < 21 ? b : 20];
+                // leaves of this band that write this buffer with pulses (or a sign): all of them but the fill-path ones
+                const int cnt = slot ? (int)bd.ny - (int)bd.fy : (int)bd.nx - (int)bd.fx;
+                const int keep = (int)(b >= b_lo) & (int)(b < b_hi) & (int)(b < 21) & (int)(cnt > 0);
+                e[k] = keep ? e[k] : 0.f;
+            }
+            ((OgF4 *)&L.X[0][0])[p] = OgF4{e[0], e[1], e[2], e[3]};
+        }
+    }
     OG_LANES_END
     const OgCeltHdr *h = &L.hdr;
     const int lm = h->lm, M = 1 << lm, N = 120 << lm;
@@ -739,7 +823,14 @@ OG_DEV void og_celt_spectrum(const OgCeltHdr *hg, const OgBandPlan *plan, const 
     const bool transient = (h->flags & OG_F_TRANSIENT) != 0, silence = (h->flags & OG_F_SILENCE) != 0;
 
     OG_STAMP(1)
-    if (stop == 1) return;
+    if (stop == 1) {
+        if (dbg_norm) {
+            OG_LANES_BEGIN(tid)
+            for (int p = tid; p < 2 * 960; p += OG_WG) dbg_norm[p] = (&L.X[0][0])[p];
+            OG_LANES_END
+        }
+        return;
+    }
     if (!silence) {
         OG_STAMP(2)
         // ---- phase 2 (K2): bands in order
@@ -897,16 +988,22 @@ OG_DEV void og_celt_spectrum(const OgCeltHdr *hg, const OgBandPlan *plan, const 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Second half of a frame, in stream order: TDAC window + overlap-add (RFC 6716 mdct.c), comb post-filter (4.3.7.1),
-// de-emphasis, PCM and state write-back.  A workgroup of OG_WGT lanes, one wavefront per channel for the recursive
-// parts.  h: the frame's header in global memory (uniform reads).  coef_row: og_celt_spectrum's output; handed back
-// zero-filled (the contract of the scratch rows between launches).
+// Second half of the frames, in stream order: TDAC window + overlap-add (RFC 6716 mdct.c), comb post-filter (4.3.7.1),
+// de-emphasis, PCM.  A workgroup of OG_WGT lanes walks a RUN of consecutive frames of one stream, one wavefront per channel
+// for the recursive parts, and keeps the stream's synthesis state in LDS for the whole run.  Per channel the time buffer is
+//     [ history OG_HIST | frame N | IMDCT tail 60 ]        (samples after the comb filter, before de-emphasis)
+// the comb filter reads its history straight below the frame; after it the newest OG_HIST + 60 samples slide down by N to
+// become the next frame's history and TDAC input, and the de-emphasised output is staged in the slots that frees -- where the
+// next frame's row will land -- on its way to the interleaved PCM store.  HBM sees, per frame, the sample row
+// in (fetched into registers one frame ahead, while the previous frame filters) and the PCM out; per run, the history the
+// comb filters reach back to before the run, and at the end the state write-back (newest <= 1024 samples, IMDCT tail,
+// de-emphasis memory, position).
 struct alignas(16) OgTailLds {
     float out[2][OG_OUTLEN];          // per channel: [OG_HIST history | frame | tail]
     float window[120];
     float taps[3][4];
     float carry[2][64];               // de-emphasis carries
-    float dm[2];                      // the stream's de-emphasis memory at frame entry
+    float dm[2];                      // the stream's de-emphasis memory, carried from frame to frame of the run
     float pad_[2];
 };
 
@@ -921,163 +1018,281 @@ struct OgHdrHead {
 static_assert(sizeof(OgHdrHead) == 36 && offsetof(OgCeltHdr, pf_tapset) == offsetof(OgHdrHead, pf_tapset) &&
               offsetof(OgCeltHdr, flags) == offsetof(OgHdrHead, flags), "OgHdrHead mirrors the start of OgCeltHdr");
 
-struct OgTailCarry { uint32_t stream, pos; int valid; };    // the ring position of the stream the previous frame belonged to
-
-OG_DEV void og_celt_tail(const OgCeltHdr *hg, OgCeltState *states, float *pcm_base, size_t pcm_stride, OgTailLds &L,
-                         const OgCeltDebug &dbg, float *coef_row, OgTailCarry &carry)
+// comb post-filter state of a frame (RFC 6716 4.3.7.1): sets [0] old, [1] current, [2] new; how far back it reads
+OG_DEV bool og_pf_on(const OgHdrHead &h) { return h.pf_gain_q[0] != 0 || h.pf_gain_q[1] != 0 || ((h.lm & 3) != 0 && h.pf_gain_q[2] != 0); }
+OG_DEV int og_pf_reach(const OgHdrHead &h)
 {
-    const OgHdrHead hd = og_uniform(*(const OgHdrHead *)hg);
-    const OgHdrHead *h = &hd;
-    const int lm = h->lm & 3, M = 1 << lm, N = 120 << lm;
-    const uint32_t flags = h->flags;
-    const int CC = (flags & OG_F_OUT_STEREO) ? 2 : 1;
-    const bool transient = (flags & OG_F_TRANSIENT) != 0, reset = (flags & OG_F_RESET) != 0;
-    const int B = transient ? M : 1, NB = N / B;
-    OgCeltState *st = states + h->stream;
-    // comb post-filter parameters (RFC 6716 4.3.7.1): sets [0] old, [1] current, [2] new
-    const float pg0 = 0.09375f * h->pf_gain_q[0], pg1 = 0.09375f * h->pf_gain_q[1], pg2 = 0.09375f * h->pf_gain_q[2];
-    const uint32_t pos0 = reset ? 0u : (carry.valid && carry.stream == h->stream) ? carry.pos : OG_U32(st->pos);
-    carry.stream = h->stream; carry.pos = pos0 + (uint32_t)N; carry.valid = 1;
-    const bool pf_on = pg0 != 0.f || pg1 != 0.f || (lm != 0 && pg2 != 0.f);
-    int reach = 0;                                      // history samples the comb filter reads
-    if (pf_on) {
-        for (int k = 0; k < 3; k++) { int t = h->pf_period[k] < 15 ? 15 : h->pf_period[k]; if (t > reach) reach = t; }
-        reach += 2;
-        if (reach > OG_HIST) reach = OG_HIST;
-    }
-    const int hgroups = (reach + 3) >> 2;               // the history is fetched in aligned groups of four samples
-    OG_STAMP(12)
-    OG_TLANES_BEGIN(tid)
-    // all of the frame's loads first (independent: their latencies overlap), then the LDS stores
-    OgF4 rv[4], hv[4];
-    float ov = 0.f, dm = 0.f;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {                       // the frame, before the window: CC * N / 4 <= 480 pieces
-        const int q = tid + j * OG_WGT;
-        rv[j] = OgF4{0.f, 0.f, 0.f, 0.f};
-        if (q < CC * (N >> 2)) {
-            const int ch = q >= (N >> 2), i = q - ch * (N >> 2);
-            rv[j] = ((const OgF4 *)coef_row)[ch * 240 + i];
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < 4; j++) {                       // what the comb filter reaches back to: CC * hgroups <= 512 pieces
-        const int q = tid + j * OG_WGT;
-        hv[j] = OgF4{0.f, 0.f, 0.f, 0.f};
-        if (q < CC * hgroups && !reset) {
-            const int ch = q >= hgroups, g = q - ch * hgroups;
-            hv[j] = *(const OgF4 *)&st->hist[ch][(pos0 - 4u * (uint32_t)(g + 1)) & 1023u];     // pos0 is a multiple of 8
-        }
-    }
-    if (tid < CC * 60 && !reset) ov = st->overlap[tid >= 60][tid >= 60 ? tid - 60 : tid];      // previous frame's tail
-    if (tid < CC && !reset) dm = st->deemph[tid];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int q = tid + j * OG_WGT;
-        if (q < CC * (N >> 2)) {
-            const int ch = q >= (N >> 2), i = q - ch * (N >> 2);
-            *(OgF4 *)&L.out[ch][OG_HIST + 60 + 4 * i] = rv[j];
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int q = tid + j * OG_WGT;
-        if (q < CC * hgroups) {
-            const int ch = q >= hgroups, g = q - ch * hgroups;
-            *(OgF4 *)&L.out[ch][OG_HIST - 4 * (g + 1)] = hv[j];
-        }
-    }
-    if (tid < CC * 60) L.out[tid >= 60][OG_HIST + (tid >= 60 ? tid - 60 : tid)] = ov;
-    if (tid < CC) L.dm[tid] = dm;
-    OG_TLANES_END
-    OG_TLANES_BEGIN(tid)
-    for (int q = tid; q < 2 * 960 / 4; q += OG_WGT) ((OgF4 *)coef_row)[q] = OgF4{0.f, 0.f, 0.f, 0.f};
-    for (int q = tid; q < CC * B * 60; q += OG_WGT) {                        // TDAC mirror (RFC 6716 mdct.c)
-        const int ch = q >= B * 60, r = q - ch * (B * 60), b = og_div(r, 1.f / 60.f), i = r - b * 60;
-        float *o = &L.out[ch][OG_HIST + NB * b];
-        const float x1 = o[119 - i], x2 = o[i];
-        const float w1 = L.window[i], w2 = L.window[119 - i];
-        o[i] = w2 * x2 - w1 * x1;
-        o[119 - i] = w1 * x2 + w2 * x1;
-    }
-    OG_TLANES_END
+    if (!og_pf_on(h)) return 0;
+    int reach = 0;
+    for (int k = 0; k < 3; k++) { int t = h.pf_period[k] < 15 ? 15 : h.pf_period[k]; if (t > reach) reach = t; }
+    reach += 2;
+    return reach > OG_HIST ? OG_HIST : reach;
+}
 
-    OG_STAMP(7)
-    // ---- comb filter, state write-back, then de-emphasis t[j] = y[j] + 0.85 t[j-1] in place as a blocked scan (N/15
-    //      lanes x 15 samples: an odd chunk length keeps the lanes' LDS accesses on distinct banks): one wave per channel,
-    //      no workgroup barrier in between
+struct OgTailRow { OgF4 v[4]; };      // a lane's share of a frame's sample row (CC * N / 4 <= 480 pieces over 128 lanes)
+
+template <class Lv>                   // rv: the lane's OgTailRow (OG_LV form)
+OG_DEV void og_tail_fetch_row(Lv &rv, const float *coef_row, int tid, int CC, int N)
+{
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int q = tid + j * OG_WGT;
+        rv.v[j] = OgF4{0.f, 0.f, 0.f, 0.f};
+        if (q < CC * (N >> 2)) {
+            const int ch = q >= (N >> 2), i = q - ch * (N >> 2);
+            rv.v[j] = ((const OgF4 *)coef_row)[ch * 240 + i];
+        }
+    }
+}
+
+// hg[0 .. nfr): consecutive frames of ONE stream, in time order; their sample rows are og_work_coef(work, f0 + t).
+// cycles: profiling stamps, [64] per frame from frame f0 on (may be null).
+OG_DEV void og_celt_tail_run(const OgCeltHdr *hg, uint32_t nfr, OgCeltState *states, float *pcm_base, size_t pcm_stride,
+                             OgTailLds &L, uint64_t *cycles, void *work, uint32_t f0)
+{
+    OgHdrHead hd = og_uniform(*(const OgHdrHead *)hg);
+    OgCeltState *st = states + hd.stream;
+    const bool reset0 = (hd.flags & OG_F_RESET) != 0;
+    const uint32_t pos_start = reset0 ? 0u : OG_U32(st->pos);
+    // what the run's comb filters read from before its first sample (frames after a reset inside the run read nothing older)
+    int R = 0;
+    {
+        int before = 0;
+        for (uint32_t t = 0; t < nfr; t++) {
+            const OgHdrHead ht = t ? og_uniform(*(const OgHdrHead *)(hg + t)) : hd;
+            if (t && (ht.flags & OG_F_RESET)) break;
+            const int need = og_pf_reach(ht) - before;
+            if (need > R) R = need;
+            before += 120 << (ht.lm & 3);
+            if (before >= OG_HIST) break;
+        }
+    }
+    const int hgroups = reset0 ? OG_HIST / 4 : (R + 3) >> 2;     // aligned groups of four samples; a reset clears the whole history
+    OG_LANE_VAR(OgTailRow, rv);
+    {
+        const int CC0 = (hd.flags & OG_F_OUT_STEREO) ? 2 : 1, N0 = 120 << (hd.lm & 3);
+        const float *row0 = og_work_coef(work, f0);
+        OG_TLANES_BEGIN(tid)
+        // every load first (independent: their latencies overlap), then the LDS stores
+        OgF4 hv[4];
+        float ov = 0.f, dm = 0.f;
+        og_tail_fetch_row(OG_LV(rv), row0, tid, CC0, N0);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {                   // CC * hgroups <= 512 pieces
+            const int q = tid + j * OG_WGT;
+            hv[j] = OgF4{0.f, 0.f, 0.f, 0.f};
+            if (q < CC0 * hgroups && !reset0) {
+                const int ch = q >= hgroups, g = q - ch * hgroups;
+                hv[j] = *(const OgF4 *)&st->hist[ch][(pos_start - 4u * (uint32_t)(g + 1)) & 1023u];     // pos is a multiple of 8
+            }
+        }
+        if (tid < CC0 * 60 && !reset0) ov = st->overlap[tid >= 60][tid >= 60 ? tid - 60 : tid];       // the previous frame's IMDCT tail
+        if (tid < CC0 && !reset0) dm = st->deemph[tid];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int q = tid + j * OG_WGT;
+            if (q < CC0 * hgroups) {
+                const int ch = q >= hgroups, g = q - ch * hgroups;
+                *(OgF4 *)&L.out[ch][OG_HIST - 4 * (g + 1)] = hv[j];
+            }
+        }
+        if (tid < CC0 * 60) L.out[tid >= 60][OG_HIST + (tid >= 60 ? tid - 60 : tid)] = ov;
+        if (tid < 2) L.dm[tid] = dm;
+        OG_TLANES_END
+    }
+
+    uint32_t pos = pos_start, total = 0;
+    bool reset_seen = reset0;
+    int CCrun = (hd.flags & OG_F_OUT_STEREO) ? 2 : 1;
     const float coef = 0.85000610f;
-    const int Lc = 15, nl = N / Lc;                     // 8 << lm lanes
+    const int Lc = 15;
     float aL = 1.f;
     for (int j = 0; j < Lc; j++) aL *= coef;            // coef^Lc
-    OG_TWAVES_BEGIN(w)
-    if (w < CC) {
-        const int ch = w;
-        float *y0 = &L.out[ch][OG_HIST];
-        if (pf_on) {
-            og_wave_comb_filter(y0, h->pf_period[0], h->pf_period[1], 120, pg0, pg1, h->pf_tapset[0], h->pf_tapset[1], L.window, L.taps);
-            if (lm != 0)
-                og_wave_comb_filter(y0 + 120, h->pf_period[1], h->pf_period[2], N - 120, pg1, pg2, h->pf_tapset[1], h->pf_tapset[2],
-                                    L.window, L.taps);
-        }
-        if (w == 0) OG_STAMP(20)
-        OG_WAVE_BEGIN(l)
-        // history ring (post-filtered, before de-emphasis): pos0 and N are multiples of 8, so groups of four samples
-        // never straddle the wrap; then the IMDCT tail for the next frame's overlap-add
-        for (int i = 4 * l; i < N; i += 256) *(OgF4 *)&st->hist[ch][(pos0 + (uint32_t)i) & 1023u] = *(const OgF4 *)&y0[i];
-        if (l < 15) *(OgF4 *)&st->overlap[ch][4 * l] = *(const OgF4 *)&y0[N + 4 * l];
-        if (reset)                                      // forget the ring's older samples
-            for (int i = N + 4 * l; i < 1024; i += 256) *(OgF4 *)&st->hist[ch][i] = OgF4{0.f, 0.f, 0.f, 0.f};
-        if (l < nl) {
-            const float *y = y0 + l * Lc;
-            float m = 0.f, t = 0.f;
-            for (int j = 0; j < Lc; j++) { t = y[j] + m; m = coef * t; }
-            L.carry[ch][l] = m;                         // chunk's own contribution to the running memory
-        }
-        OG_WAVE_END
-        // carry-in of chunk l = sum over earlier chunks q of carry[q] * coef^(Lc*(l-1-q)) (+ the stream's memory); terms
-        // more than `back` chunks back are below 1e-9 of their chunk's value and are dropped
-        const int back = 128 / Lc + 1;
-        OG_WAVE_BEGIN(l)
-        if (l < nl) {
-            const int q0 = l > back ? l - back : 0;
-            float m = q0 > 0 ? 0.f : L.dm[ch];          // the stream's de-emphasis memory (0 after a reset)
-            for (int q = q0; q < l; q++) m = m * aL + L.carry[ch][q];
-            float *y = y0 + l * Lc;
-            for (int j = 0; j < Lc; j++) { const float v = y[j] + m; m = coef * v; y[j] = v; }
-            if (l == nl - 1) st->deemph[ch] = m;
-        }
-        OG_WAVE_END
-    }
-    OG_TWAVES_END
-    OG_STAMP(21)
-    float *pcm = pcm_base + (size_t)h->stream * pcm_stride + (size_t)h->pcm_off * CC;
-    const bool accum = (flags & OG_F_ACCUM) != 0;
-    const bool vec = (((uintptr_t)pcm) & 15) == 0;      // 16-byte stores when the caller's row allows it
-    const float *t0 = &L.out[0][OG_HIST], *t1 = &L.out[1][OG_HIST];
-    OG_TLANES_BEGIN(tid)
-    if (vec) {
-        const float k = 1.f / 32768.f;
-        for (int q = tid; q < N * CC / 4; q += OG_WGT) {
-            OgF4 v;
-            if (CC == 2) {                              // two stereo samples
-                const int j = 2 * q;
-                v = OgF4{t0[j] * k, t1[j] * k, t0[j + 1] * k, t1[j + 1] * k};
-            } else {
-                const OgF4 u = ((const OgF4 *)t0)[q];
-                v = OgF4{u.x * k, u.y * k, u.z * k, u.w * k};
+    for (uint32_t t = 0; t < nfr; t++) {
+        uint64_t *cyc = cycles ? cycles + (size_t)t * 64 : nullptr;
+        const int lm = hd.lm & 3, M = 1 << lm, N = 120 << lm;
+        const uint32_t flags = hd.flags;
+        const int CC = (flags & OG_F_OUT_STEREO) ? 2 : 1;
+        const bool transient = (flags & OG_F_TRANSIENT) != 0;
+        const int B = transient ? M : 1, NB = N / B;
+        if (CC > CCrun) CCrun = CC;
+        if (t && (flags & OG_F_RESET)) {                // a reset inside the run: forget everything older
+            pos = 0;
+            reset_seen = true;
+            OG_TLANES_BEGIN(tid)
+            for (int q = tid; q < 2 * (OG_HIST + 60) / 4; q += OG_WGT) {
+                const int ch = q >= (OG_HIST + 60) / 4, g = q - ch * ((OG_HIST + 60) / 4);
+                *(OgF4 *)&L.out[ch][4 * g] = OgF4{0.f, 0.f, 0.f, 0.f};
             }
-            if (accum) { const OgF4 o = ((const OgF4 *)pcm)[q]; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
-            ((OgF4 *)pcm)[q] = v;
+            if (tid < 2) L.dm[tid] = 0.f;
+            OG_TLANES_END
         }
-    } else {
-        for (int q = tid; q < N * CC; q += OG_WGT) {
-            const int j = CC == 2 ? q >> 1 : q, ch = CC == 2 ? q & 1 : 0;
-            const float v = (ch ? t1 : t0)[j] * (1.f / 32768.f);
-            pcm[q] = accum ? pcm[q] + v : v;
+        OG_STAMP_TO(cyc, 12)
+        // ---- the frame's samples (og_celt_spectrum's output, before the window) behind the previous frame's IMDCT tail
+        OG_TLANES_BEGIN(tid)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int q = tid + j * OG_WGT;
+            if (q < CC * (N >> 2)) {
+                const int ch = q >= (N >> 2), i = q - ch * (N >> 2);
+                *(OgF4 *)&L.out[ch][OG_HIST + 60 + 4 * i] = OG_LV(rv).v[j];
+            }
+        }
+        OG_TLANES_END
+        // ---- the next frame's row starts its way in now; TDAC mirror (RFC 6716 mdct.c) of this one
+        const OgHdrHead hn = t + 1 < nfr ? og_uniform(*(const OgHdrHead *)(hg + t + 1)) : hd;
+        {
+            const bool more = t + 1 < nfr;
+            const int CCn = (hn.flags & OG_F_OUT_STEREO) ? 2 : 1, Nn = 120 << (hn.lm & 3);
+            const float *rown = og_work_coef(work, f0 + t + (more ? 1 : 0));
+            OG_TLANES_BEGIN(tid)
+            if (more) og_tail_fetch_row(OG_LV(rv), rown, tid, CCn, Nn);
+            for (int q = tid; q < CC * B * 60; q += OG_WGT) {
+                const int ch = q >= B * 60, r = q - ch * (B * 60), b = og_div(r, 1.f / 60.f), i = r - b * 60;
+                float *o = &L.out[ch][OG_HIST + NB * b];
+                const float x1 = o[119 - i], x2 = o[i];
+                const float w1 = L.window[i], w2 = L.window[119 - i];
+                o[i] = w2 * x2 - w1 * x1;
+                o[119 - i] = w1 * x2 + w2 * x1;
+            }
+            OG_TLANES_END
+        }
+        OG_STAMP_TO(cyc, 7)
+        // ---- per channel, by one wave, no workgroup barrier in between: comb filter in place; the slide; de-emphasis t[j] = y[j] +
+        //      0.85 t[j-1] as a blocked scan (N/15 lanes x 15 samples: an odd chunk length keeps the lanes' LDS accesses on
+        //      distinct banks) into the staging slots (the samples before de-emphasis stay: they are the next frames' history)
+        const float pg0 = 0.09375f * hd.pf_gain_q[0], pg1 = 0.09375f * hd.pf_gain_q[1], pg2 = 0.09375f * hd.pf_gain_q[2];
+        const bool pf_on = og_pf_on(hd);
+        const int nl = N / Lc;                          // 8 << lm lanes
+        OG_TWAVES_BEGIN(w)
+        if (w < CC) {
+            const int ch = w;
+            float *y0 = &L.out[ch][OG_HIST];
+            if (pf_on) {
+                og_wave_comb_filter(y0, hd.pf_period[0], hd.pf_period[1], 120, pg0, pg1, hd.pf_tapset[0], hd.pf_tapset[1], L.window, L.taps);
+                if (lm != 0)
+                    og_wave_comb_filter(y0 + 120, hd.pf_period[1], hd.pf_period[2], N - 120, pg1, pg2, hd.pf_tapset[1], hd.pf_tapset[2],
+                                        L.window, L.taps);
+            }
+            if (w == 0) OG_STAMP_TO(cyc, 20)
+            // the slide: the newest OG_HIST + 60 samples move down by N (every piece is read before any is written)
+            {
+                const int P = (OG_HIST + 60) / 4;       // 271 pieces of four samples, at most five per lane
+                struct OgSlide { OgF4 v[5]; };
+                OG_WAVE_VAR(OgSlide, mv);
+                OG_WAVE_BEGIN(lane)
+#pragma unroll
+                for (int j = 0; j < 5; j++) {
+                    const int g = lane + 64 * j;
+                    OG_WV(mv).v[j] = g < P ? *(const OgF4 *)&L.out[ch][N + 4 * g] : OgF4{0.f, 0.f, 0.f, 0.f};
+                }
+                OG_WAVE_END
+                OG_WAVE_BEGIN(lane)
+#pragma unroll
+                for (int j = 0; j < 5; j++) {
+                    const int g = lane + 64 * j;
+                    if (g < P) *(OgF4 *)&L.out[ch][4 * g] = OG_WV(mv).v[j];
+                }
+                OG_WAVE_END
+            }
+            // de-emphasis of the frame (now at [OG_HIST - N, OG_HIST)) into the staging slots behind the IMDCT tail, where the
+            // next frame's row will land
+            const float *ys = &L.out[ch][OG_HIST - N];
+            float *z0 = &L.out[ch][OG_HIST + 60];
+            struct OgChunk { float v[15]; };
+            OG_WAVE_VAR(OgChunk, yv);                   // the lane's 15 samples, read once for both passes
+            OG_WAVE_BEGIN(lane)
+            const int l = lane;
+            if (l < nl) {
+                const float *y = ys + l * Lc;
+                float m = 0.f, v = 0.f;
+#pragma unroll
+                for (int j = 0; j < 15; j++) { OG_WV(yv).v[j] = y[j]; v = y[j] + m; m = coef * v; }
+                L.carry[ch][l] = m;                     // chunk's own contribution to the running memory
+            }
+            OG_WAVE_END
+            // carry-in of chunk l = sum over earlier chunks q of carry[q] * coef^(Lc*(l-1-q)) (+ the stream's memory); terms
+            // more than `back` chunks back are below 1e-9 of their chunk's value and are dropped
+            const int back = 128 / Lc + 1;
+            OG_WAVE_BEGIN(lane)
+            const int l = lane;
+            if (l < nl) {
+                const int q0 = l > back ? l - back : 0;
+                float m = q0 > 0 ? 0.f : L.dm[ch];      // the stream's de-emphasis memory (0 after a reset)
+                for (int q = q0; q < l; q++) m = m * aL + L.carry[ch][q];
+                float *z = z0 + l * Lc;
+#pragma unroll
+                for (int j = 0; j < 15; j++) { const float v = OG_WV(yv).v[j] + m; m = coef * v; z[j] = v; }
+                if (l == nl - 1) L.dm[ch] = m;          // read above by every lane before this wave-ordered store
+            }
+            OG_WAVE_END
+        }
+        OG_TWAVES_END
+        OG_STAMP_TO(cyc, 21)
+        float *pcm = pcm_base + (size_t)hd.stream * pcm_stride + (size_t)hd.pcm_off * CC;
+        const bool accum = (flags & OG_F_ACCUM) != 0;
+        const bool vec = (((uintptr_t)pcm) & 15) == 0;  // 16-byte stores when the caller's row allows it
+        const float *t0 = &L.out[0][OG_HIST + 60], *t1 = &L.out[1][OG_HIST + 60];
+        OG_TLANES_BEGIN(tid)
+        const float k = 1.f / 32768.f;
+        if (vec) {
+            for (int q = tid; q < N * CC / 4; q += OG_WGT) {
+                OgF4 v;
+                if (CC == 2) {                          // two stereo samples
+                    const int j = 2 * q;
+                    v = OgF4{t0[j] * k, t1[j] * k, t0[j + 1] * k, t1[j + 1] * k};
+                } else {
+                    const OgF4 u = ((const OgF4 *)t0)[q];
+                    v = OgF4{u.x * k, u.y * k, u.z * k, u.w * k};
+                }
+                if (accum) { const OgF4 o = ((const OgF4 *)pcm)[q]; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+                ((OgF4 *)pcm)[q] = v;
+            }
+        } else {
+            for (int q = tid; q < N * CC; q += OG_WGT) {
+                const int j = CC == 2 ? q >> 1 : q, ch = CC == 2 ? q & 1 : 0;
+                const float v = (ch ? t1 : t0)[j] * k;
+                pcm[q] = accum ? pcm[q] + v : v;
+            }
+        }
+        OG_TLANES_END                                   // the staging slots are read before the next frame's row lands in them
+        pos += (uint32_t)N;
+        total += (uint32_t)N;
+        hd = hn;
+        OG_STAMP_TO(cyc, 8)
+    }
+
+    // ---- state write-back, once per run: the newest samples (all 1024 after a reset), the IMDCT tail awaiting the next
+    //      frame, the de-emphasis memory and the position
+    const int nh = (reset_seen || total > (uint32_t)OG_HIST) ? OG_HIST : (int)total, hq = nh >> 2;
+    OG_TLANES_BEGIN(tid)
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int q = tid + j * OG_WGT;
+        if (q < CCrun * hq) {
+            const int ch = q >= hq, g = q - ch * hq;
+            *(OgF4 *)&st->hist[ch][(pos - 4u * (uint32_t)(g + 1)) & 1023u] = *(const OgF4 *)&L.out[ch][OG_HIST - 4 * (g + 1)];
         }
     }
-    if (tid == 0) st->pos = pos0 + (uint32_t)N;
-    OG_TLANES_END
-    OG_STAMP(8)
+    if (tid < CCrun * 15) {
+        const int ch = tid >= 15, l = tid - 15 * ch;
+        *(OgF4 *)&st->overlap[ch][4 * l] = *(const OgF4 *)&L.out[ch][OG_HIST + 4 * l];
+    }
+    if (tid < CCrun) st->deemph[tid] = L.dm[tid];
+    if (tid == 0) st->pos = pos;
+    OG_TLANES_END                                       // the next run of the workgroup restages the buffer
+}
+
+// A group of the tail kernel: frames hg[0 .. nfr) in time order, cut into runs of one stream each.
+OG_DEV void og_celt_tail_group(const OgCeltHdr *hg, uint32_t nfr, OgCeltState *states, float *pcm_base, size_t pcm_stride,
+                               OgTailLds &L, uint64_t *cycles, void *work, uint32_t f0)
+{
+    uint32_t t = 0;
+    while (t < nfr) {
+        const uint32_t s = OG_U32(hg[t].stream);
+        uint32_t e = t + 1;
+        while (e < nfr && OG_U32(hg[e].stream) == s) e++;
+        og_celt_tail_run(hg + t, e - t, states, pcm_base, pcm_stride, L, cycles ? cycles + (size_t)t * 64 : nullptr, work, f0 + t);
+        t = e;
+    }
 }

@@ -118,14 +118,9 @@ __global__ __launch_bounds__(OG_WGT) void og_celt_tail_kernel(const OgCeltHdr *_
     if (threadIdx.x < 12) (&L.taps[0][0])[threadIdx.x] = (&T->k.pf_taps[0][0])[threadIdx.x];
     __syncthreads();
     const uint32_t f0 = blockIdx.x * frames_per_group;
-    OgTailCarry carry = {0, 0, 0};
-    for (uint32_t t = 0; t < frames_per_group; t++) {
-        const uint32_t f = f0 + t;
-        if (f >= nframes) break;
-        OgCeltDebug d = {nullptr, nullptr, nullptr, nullptr, nullptr};
-        d.cycles = dbg.cycles ? dbg.cycles + (size_t)f * 64 : nullptr;
-        og_celt_tail(hdr + f, state, pcm, pcm_stride, L, d, og_work_coef(work, f), carry);      // ends in a barrier: frame t's state
-    }                                                                                   // stores precede frame t + 1's loads
+    if (f0 >= nframes) return;
+    const uint32_t nfr = nframes - f0 < frames_per_group ? nframes - f0 : frames_per_group;
+    og_celt_tail_group(hdr + f0, nfr, state, pcm, pcm_stride, L, dbg.cycles ? dbg.cycles + (size_t)f0 * 64 : nullptr, work, f0);
 }
 
 // Scratch of opusgpu_launch_celt_noalloc (include/opusgpu.h): the `work` buffer of a launch of up to OG_NOALLOC_MAX_FRAMES

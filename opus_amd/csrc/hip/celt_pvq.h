@@ -190,6 +190,11 @@ OG_DEV void og_pvq_lane(const OgLeafRef ref, const OgCeltHdr *hdr, const OgCeltL
 {
     const OgCeltLeaf lf = leaves[ref.leaf];
     const int ch = (lf.meta & OG_L_CH_Y) ? 1 : 0;
+    if (lf.k == 0) {                                    // a zero-pulse leaf next to PVQ leaves in its (band, buffer): K1 owns the
+        float *z = og_work_coef(work, ref.frame) + ch * 960 + lf.pos;      // zeros there (live fill leaves are rewritten by the
+        for (int i = 0; i < lf.n; i++) z[i] = 0.f;                         // frame kernel); no collapse mask
+        return;
+    }
     const int spread = hdr[ref.frame].spread;
     int16_t *dbg = dbg_pulses ? dbg_pulses + (size_t)ref.frame * 1920 + ch * 960 + lf.pos : nullptr;
     const uint32_t cm = og_pvq_leaf(U2, lf, spread, xl, xs, dbg, stamps);

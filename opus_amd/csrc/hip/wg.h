@@ -50,6 +50,22 @@
 #define OG_LV(name) name
 // dst (a plain variable declared outside the OG_WAVE region) = lane 0's value of val, for every lane
 #define OG_WAVE_BCAST0(dst, val) dst = __builtin_amdgcn_readfirstlane((int)(val))
+// Register-only wave regions and cross-lane moves for recurrences that would otherwise pay an LDS round trip per step.  Used
+// OUTSIDE OG_WAVE regions, on OG_WAVE_VAR floats:
+//   OG_WAVE_SHR1(dst, src)        dst of lane l = src of lane l - 1 (lane 0: 0)         one DPP move (wave_shr:1)
+//   OG_WAVE_PULL(dst, src, IDX)   dst of lane `lane` = src of lane (IDX) & 63            one ds_bpermute; IDX may use `lane`
+// OG_WAVE_REGS_BEGIN / _END is an OG_WAVE region without the trailing fence: for code whose lanes exchange nothing through LDS
+// inside the region and between consecutive such regions (end the sequence with an ordinary OG_WAVE region or OG_WAVE_FENCE).
+OG_DEV float og_dpp_wave_shr1(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xF, 0xF, true));
+}
+#define OG_WAVE_SHR1(dst, src) dst = og_dpp_wave_shr1(src);
+#define OG_WAVE_PULL(dst, src, IDX) { const int lane = (int)(threadIdx.x & 63); \
+    dst = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((IDX) & 63) << 2, __builtin_bit_cast(int, src))); }
+#define OG_WAVE_REGS_BEGIN(lane) { const int lane = (int)(threadIdx.x & 63); {
+#define OG_WAVE_REGS_END } }
+#define OG_WAVE_FENCE __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
 #else
 #include <math.h>
 #define OG_DEV static inline
@@ -75,4 +91,11 @@
 #define OG_LANE_VAR(T, name) T name[OG_WG]
 #define OG_LV(name) name[tid]
 #define OG_WAVE_BCAST0(dst, val) { if (lane == 0) dst = (int)(val); }
+#define OG_WAVE_SHR1(dst, src) { float t_[64]; for (int l_ = 0; l_ < 64; l_++) t_[l_] = l_ ? src[l_ - 1] : 0.f; \
+    for (int l_ = 0; l_ < 64; l_++) dst[l_] = t_[l_]; }
+#define OG_WAVE_PULL(dst, src, IDX) { float t_[64]; for (int lane = 0; lane < 64; lane++) t_[lane] = src[(IDX) & 63]; \
+    for (int l_ = 0; l_ < 64; l_++) dst[l_] = t_[l_]; }
+#define OG_WAVE_REGS_BEGIN(lane) for (int lane = 0; lane < 64; lane++) { {
+#define OG_WAVE_REGS_END } }
+#define OG_WAVE_FENCE
 #endif

@@ -14,23 +14,28 @@ extern "C" int emu_launch_celt(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, u
     if (!init) { og_fill_celt_tables(&T); init = true; }
     static OgCeltLds L;
     static OgTailLds Lt;
-    (void)frames_per_group;
     // K1: every PVQ leaf of every frame (order is irrelevant to the result), the band plans, then K2+K3 frame by frame
-    std::vector<float> work(OG_WORK_BYTES(nframes) / 4 + 4, 0.f);
-    for (uint32_t f = 0; f < nframes; f++)
-        for (uint32_t l = 0; l < hdr[f].nleaves; l++) {
-            const OgCeltLeaf &lf = leaves[hdr[f].leaf_begin + l];
-            if (!lf.k || (lf.meta & OG_L_N1)) continue;
+    // the scratch starts out as garbage (NaN bit patterns) except the collapse-mask words, which the launch contract wants zero
+    std::vector<float> work(OG_WORK_BYTES(nframes) / 4 + 4);
+    std::memset(work.data(), 0xFF, work.size() * 4);
+    for (uint32_t f = 0; f < nframes; f++) std::memset(og_work_cm(work.data(), f), 0, 48 * 4);
+    {
+        uint32_t total = 0;
+        for (uint32_t f = 0; f < nframes; f++) total += hdr[f].nleaves;
+        std::vector<OgLeafRef> refs(total + 1);
+        uint32_t classes[4];
+        const uint32_t nref = opusgpu_sort_pvq_leaves(hdr, nframes, leaves, refs.data(), total + 1, classes);
+        for (uint32_t r = 0; r < nref; r++) {           // order is irrelevant to the result
             float x[176];
-            OgLeafRef ref = {hdr[f].leaf_begin + l, f};
-            og_pvq_lane(ref, hdr, leaves, nframes, work.data(), T.pvq_u2, x, 1, dbg ? dbg->pulses : nullptr, nullptr);
+            og_pvq_lane(refs[r], hdr, leaves, nframes, work.data(), T.pvq_u2, x, 1, dbg ? dbg->pulses : nullptr, nullptr);
         }
+    }
     for (uint32_t f = 0; f < nframes; f++) {
         uint16_t sc[OG_PLAN_SCRATCH];
         og_plan_frame(hdr + f, leaves, f, T.k, T.lcg_a, T.lcg_c, work.data(), OgLaneScratch{sc, 1});
     }
     for (uint32_t f = 0; f < nframes; f++) {
-        std::memset(&L, 0xA5, sizeof L);               // LDS starts undefined on the device
+        std::memset(&L, 0xFF, sizeof L);               // LDS starts undefined on the device
         OgCeltDebug d = {nullptr, nullptr, nullptr, nullptr, nullptr};
         if (dbg) {
             d.norm = dbg->norm ? dbg->norm + (size_t)f * 1920 : nullptr;
@@ -39,14 +44,12 @@ extern "C" int emu_launch_celt(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, u
         }
         og_celt_spectrum(hdr + f, og_work_plan(work.data(), f), &T, L, d, og_work_coef(work.data(), f));
     }
-    std::memset(&Lt, 0xA5, sizeof Lt);
+    std::memset(&Lt, 0xFF, sizeof Lt);
     std::memcpy(Lt.window, T.window, sizeof Lt.window);
     std::memcpy(Lt.taps, T.k.pf_taps, sizeof Lt.taps);
-    OgTailCarry carry = {0, 0, 0};
-    for (uint32_t f = 0; f < nframes; f++) {            // the tail kernel: frames in order
-        OgCeltDebug d = {nullptr, nullptr, nullptr, nullptr, nullptr};
-        og_celt_tail(hdr + f, state, pcm, pcm_stride, Lt, d, og_work_coef(work.data(), f), carry);
-    }
+    const uint32_t fpg = frames_per_group ? frames_per_group : 1;
+    for (uint32_t f = 0; f < nframes; f += fpg)         // the tail kernel: one workgroup per group, frames in order
+        og_celt_tail_group(hdr + f, nframes - f < fpg ? nframes - f : fpg, state, pcm, pcm_stride, Lt, nullptr, work.data(), f);
     return 0;
 }
 extern "C" size_t emu_lds_bytes(void) { return sizeof(OgCeltLds); }

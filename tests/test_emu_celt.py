@@ -47,6 +47,55 @@ def test_emu_vectors(emu, vid, n, ch):
     _run(emu, pk, ch)
 
 
+def _run_grouped(emu, packets, channels, per_group, reset_at=()):
+    """`per_group` packets (each of one or more frames, sizes may differ) go through one launch as ONE tail group: the run
+    keeps the stream's state in LDS across its frames.  reset_at: packet indices in front of which the stream is flushed
+    (a reset flag inside a run when the index is not a multiple of per_group)."""
+    hp = HostParser(channels)
+    ref = orc.Decoder(channels)
+    st = A.CeltState()
+    HS = C.sizeof(A.CeltHdr)
+    for g0 in range(0, len(packets), per_group):
+        hdrs, leaves, want, off = [], [], [], 0
+        for i in range(g0, min(g0 + per_group, len(packets))):
+            if i in reset_at:
+                hp.lib.opusgpu_parser_reset(hp.h)
+                ref = orc.Decoder(channels)
+            n, nc, nl, _ = hp.parse(packets[i])
+            assert n > 0 and nc == n
+            want.append(ref.decode(packets[i]))
+            base = sum(len(x) for x in leaves) // 16
+            for f in range(n):
+                hp.celt[f].stream = 0
+                hp.celt[f].pcm_off = off
+                hp.celt[f].leaf_begin += base
+                off += hp.fi[f].frame_size
+                hdrs.append(bytes(C.string_at(C.addressof(hp.celt[f]), HS)))
+            leaves.append(bytes(C.string_at(C.addressof(hp.leaves), nl * 16)))
+        hb, lb = b"".join(hdrs), b"".join(leaves) or bytes(16)
+        pcm = np.zeros(off * channels + 16, np.float32)
+        emu.emu_launch_celt(hb, lb, len(hdrs), len(hdrs), C.byref(st), pcm.ctypes.data, off * channels + 16, None)
+        r = np.concatenate(want)
+        check_pcm(r, pcm[: off * channels].reshape(off, channels), f"group at packet {g0}")
+
+
+@pytest.mark.parametrize("vid,n,ch,per_group", [(11, 96, 2, 8), (7, 2400, 2, 5), (7, 900, 1, 3), (1, 120, 2, 2)])
+def test_emu_runs_keep_state_in_lds(emu, vid, n, ch, per_group):
+    """several packets per tail group (vector 07: frame sizes 2.5 .. 20 ms change from packet to packet, transients,
+    post-filter on and off): ring history, IMDCT tail and de-emphasis memory carried in LDS across the run's frames,
+    written back once, picked up by the next launch"""
+    _, pk = orc.load_vectors(ids=[vid], max_packets=n)[vid]
+    _run_grouped(emu, pk, ch, per_group)
+
+
+def test_emu_reset_inside_a_run(emu):
+    pk = synth.celt_fb_stereo_packets(range(2), 24, 160)
+    for s in range(2):
+        _run_grouped(emu, [pk[s, f].tobytes() for f in range(24)], 2, 6, reset_at=(3, 8, 12, 17))
+    _, pk7 = orc.load_vectors(ids=[7], max_packets=600)[7]
+    _run_grouped(emu, pk7, 2, 4, reset_at=tuple(range(5, 600, 13)))
+
+
 @pytest.fixture(scope="module")
 def emu_small():
     """same kernel body with room for 4 fill ops in LDS: the rest are read from the plan in global memory"""

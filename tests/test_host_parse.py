@@ -190,8 +190,9 @@ def test_synth_generator_is_deterministic_per_stream():
 
 
 def test_sort_pvq_leaves_orders_by_size_then_pulses():
-    """opusgpu_sort_pvq_leaves (host helper of the K1 launch): every PVQ leaf (K > 0, N > 1) exactly once, key
-    (N, min(K, 63)) non-increasing, class counts = leaves with N > 64 / > 24 / > 8 / the rest"""
+    """opusgpu_sort_pvq_leaves (host helper of the K1 launch): every PVQ leaf (K > 0, N > 1) exactly once, and the zero-pulse
+    leaves that share a (band, buffer) with one (K1 stores their zeros), key (N, min(K, 63)) non-increasing, class counts =
+    leaves with N > 64 / > 24 / > 8 / the rest"""
     lib = A.load()
     hp = HostParser(2)
     pk = synth.celt_fb_stereo_packets(range(4), 6, 160)
@@ -204,7 +205,11 @@ def test_sort_pvq_leaves_orders_by_size_then_pulses():
             classes = (C.c_uint32 * 4)()
             got = lib.opusgpu_sort_pvq_leaves(hp.celt, 1, hp.leaves, refs, nl, classes)
             leaves = [hp.leaves[i] for i in range(nl)]
-            want = [i for i, lf in enumerate(leaves) if lf.k and not (lf.meta & N1)]
+            def shares_pvq(lf):
+                bd = hp.celt[0].band[lf.band]
+                return bd.ny > bd.fy if lf.meta & A.L_CH_Y else bd.nx > bd.fx
+            want = [i for i, lf in enumerate(leaves) if not (lf.meta & N1) and (lf.k or shares_pvq(lf))]
+            assert any(leaves[i].k == 0 for i in want) or s + f > 0
             assert got == len(want) and sorted(refs[i].leaf for i in range(got)) == want
             keys = [(leaves[refs[i].leaf].n, min(leaves[refs[i].leaf].k, 63)) for i in range(got)]
             assert keys == sorted(keys, reverse=True)
