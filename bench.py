@@ -42,6 +42,9 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames-per-step", type=int, default=8, help="consecutive frames of every stream decoded per step")
     ap.add_argument("--streams", type=int, default=STREAMS_PER_GPU, help="streams per GPU (BASELINE: 4096)")
+    ap.add_argument("--split", type=int, default=1,
+                    help="issue each step as this many independent sub-batches of streams, each on a HIP stream of its own "
+                         "(the sub-batches share nothing: their kernels may run side by side)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle comparison of the last step's PCM")
     ap.add_argument("--parse-only", action="store_true",
@@ -190,37 +193,52 @@ def main():
 
     # ---- host half (untimed here; its rate is reported separately): packets -> side-info, copied to HBM.
     # Per step the records are laid out [stream][t] (a tail workgroup walks one stream's T frames in time order).
-    parser = BatchDecoder(S, 2, local_rank)
-    host_steps, t_parse = stepmod.build_celt_steps(parser, packets, T, nsteps)
-    parser.close()
-    hdr_dev = [torch.from_numpy(st.hdr).to(dev) for st in host_steps]
-    leaf_dev = [torch.from_numpy(st.leaves).to(dev) for st in host_steps]
-    ref_dev = [torch.from_numpy(st.refs).to(dev) for st in host_steps]
-    ref_classes = [st.classes for st in host_steps]
-    alg_bytes = [int(S * T * ALG_BYTES_BASE + st.pf_on * ALG_BYTES_PF) for st in host_steps]
-    nleaves = [st.nleaves for st in host_steps]
-
+    # The streams are dealt to `P` sub-batches (contiguous blocks), each with its own scratch, HIP stream and launches.
+    P = max(1, a.split)
+    assert S % P == 0, "--split must divide --streams"
+    SP = S // P
+    parts = []
+    t_parse = 0.0
+    nleaves = [0] * nsteps
+    alg_bytes = [0] * nsteps
     state = torch.zeros(S * C.sizeof(A.CeltState), dtype=torch.uint8, device=dev)
-    work = torch.zeros(lib.opusgpu_celt_work_bytes(S * T), dtype=torch.uint8, device=dev)     # K1 -> plan -> frame-kernel scratch
     stride = T * 960 * 2
     pcm = torch.zeros(S * stride, dtype=torch.float32, device=dev)
-    s_frm = torch.cuda.Stream(dev)
-    p_frm = C.c_void_p(s_frm.cuda_stream)
-    evk = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nsteps)]   # around og_celt_kernel
+    SB = C.sizeof(A.CeltState)
+    for q in range(P):
+        parser = BatchDecoder(SP, 2, local_rank)
+        host_steps, tp = stepmod.build_celt_steps(parser, packets[q * SP:(q + 1) * SP], T, nsteps)
+        parser.close()
+        t_parse += tp
+        strm = torch.cuda.Stream(dev)
+        parts.append(dict(
+            hdr=[torch.from_numpy(st.hdr).to(dev) for st in host_steps], leaves=[torch.from_numpy(st.leaves).to(dev) for st in host_steps],
+            refs=[torch.from_numpy(st.refs).to(dev) for st in host_steps], classes=[st.classes for st in host_steps],
+            work=torch.zeros(lib.opusgpu_celt_work_bytes(SP * T), dtype=torch.uint8, device=dev),   # K1 -> plan -> frame-kernel scratch
+            state=state[q * SP * SB:(q + 1) * SP * SB], pcm=pcm[q * SP * stride:(q + 1) * SP * stride],
+            stream=strm, ps=C.c_void_p(strm.cuda_stream),
+            evk=[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nsteps)]))
+        for k, st in enumerate(host_steps):
+            nleaves[k] += st.nleaves
+            alg_bytes[k] += int(SP * T * ALG_BYTES_BASE + st.pf_on * ALG_BYTES_PF)
 
     def check(rc):
         if rc:
             raise RuntimeError(lib.opusgpu_last_error().decode())
 
     def step(f):
-        """step f = opusgpu_launch_celt, issued as its three parts; og_celt_kernel is bracketed by evk[f] on the stream it runs on"""
-        check(lib.opusgpu_launch_celt_pvq(hdr_dev[f].data_ptr(), leaf_dev[f].data_ptr(), S * T, ref_dev[f].data_ptr(), ref_classes[f],
-                                          work.data_ptr(), None, p_frm))
-        evk[f][0].record(s_frm)
-        check(lib.opusgpu_launch_celt_spectrum(hdr_dev[f].data_ptr(), S * T, work.data_ptr(), None, p_frm))
-        evk[f][1].record(s_frm)
-        check(lib.opusgpu_launch_celt_tail(hdr_dev[f].data_ptr(), S * T, T, work.data_ptr(), state.data_ptr(), pcm.data_ptr(), stride,
-                                           None, p_frm))
+        """step f = one opusgpu_launch_celt per sub-batch, issued as its three parts; og_celt_kernel is bracketed by evk[f] on
+        the stream it runs on"""
+        for pt in parts:
+            check(lib.opusgpu_launch_celt_pvq(pt["hdr"][f].data_ptr(), pt["leaves"][f].data_ptr(), SP * T, pt["refs"][f].data_ptr(), pt["classes"][f],
+                                              pt["work"].data_ptr(), None, pt["ps"]))
+        for pt in parts:
+            pt["evk"][f][0].record(pt["stream"])
+            check(lib.opusgpu_launch_celt_spectrum(pt["hdr"][f].data_ptr(), SP * T, pt["work"].data_ptr(), None, pt["ps"]))
+            pt["evk"][f][1].record(pt["stream"])
+        for pt in parts:
+            check(lib.opusgpu_launch_celt_tail(pt["hdr"][f].data_ptr(), SP * T, T, pt["work"].data_ptr(), pt["state"].data_ptr(),
+                                               pt["pcm"].data_ptr(), stride, None, pt["ps"]))
 
     torch.cuda.synchronize(dev)
     for f in range(W):
@@ -253,7 +271,7 @@ def main():
     avg_kernel_s = elapsed / K                               # the calls run back to back on one stream: per call = step time
     avg_alg = sum(alg_bytes[W:]) / K
     achieved = avg_alg / avg_kernel_s / 1e9
-    k2_s = sum(e0.elapsed_time(e1) for e0, e1 in evk[W:]) / K / 1e3       # og_celt_kernel alone
+    k2_s = sum(e0.elapsed_time(e1) for pt in parts for e0, e1 in pt["evk"][W:]) / K / 1e3       # og_celt_kernel alone (summed over sub-batches)
     k2_bytes = S * T * K2_BYTES
     traffic = k2_traffic = None
     tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")      # HBM bytes per launch from the rocprofv3 --pmc passes
@@ -277,7 +295,7 @@ def main():
             "config": {"workload": "BASELINE configs[1]: synthetic CELT-only FB 48 kHz stereo 20 ms frames (TOC 0xFC + "
                                    f"{PAYLOAD} random payload bytes), {S} streams per GPU, {T} consecutive frames per stream per step; "
                                    "device-only: side-info pre-parsed and resident in HBM, PCM stays in HBM",
-                       "streams_per_gpu": S, "frame_ms": 20, "frames_per_stream_per_step": T, "payload_bytes": PAYLOAD,
+                       "streams_per_gpu": S, "frame_ms": 20, "frames_per_stream_per_step": T, "payload_bytes": PAYLOAD, "sub_batches": P,
                        "parallelism": f"streams sharded over {world} GPU(s), one process per GPU, no collective in the data path; "
                                       "RCCL only for the barrier and the max of the elapsed times"},
             # the launch = every kernel of one opusgpu_launch_celt (K1, plan, og_celt_kernel, og_celt_tail_kernel),
