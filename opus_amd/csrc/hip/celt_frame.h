@@ -196,48 +196,17 @@ template <class T> OG_DEV T og_uniform(const T &v) { return v; }
 #endif
 
 // The transform of one quant_band call: the Haar steps of tf recombination / time-division (celt/decoder.rs:453-466,
-// :1708-1740, :1994-2019) are butterflies on the index bits `hm` (celt_plan.h) and commute; the Hadamard (de)interleave
-// (:472-538) is a permutation.  Both run in place -- the permutation through registers (every element is read before
-// any is written; K elements per lane) -- on the decoded band itself (POST: interleave, butterflies, then og_task_finish
-// scales and emits lowband_out) or on the wave's copy of the folding source (PRE: butterflies, then scale + deinterleave).
-// The pieces below each handle elements first, first + step, ... of the task for the calling lane (a whole wave:
-// first = lane, step = 64, K = 3, task record in scalar registers; a 16-lane group: first = lane & 15, step = 16, K = 11);
-// the caller separates them with wave-level fences.
+// :1708-1740, :1994-2019) are butterflies on the index bits `hm` (celt_plan.h; bits 0..3 only: tf changes are at most three
+// steps, celt/decoder.rs:221-226, on top of at most eight blocks) and commute; the Hadamard (de)interleave (:472-538) is a
+// permutation.  A lane group of STEP lanes (a whole wave, STEP = 64, or a quarter of one, STEP = 16) takes a task: the lane
+// with index `first` in the group holds elements first, first + STEP, ... (K of them at most) in registers, so
+//   * the permutation is the address the element is read from (POST: interleave on the way in) or written to (PRE:
+//     deinterleave on the way out).  og_reorder(p) for p = first + STEP k is affine in k -- STEP is a multiple of the
+//     permutation's stride 2^slog <= 16 -- so it costs one add per element (OgXfAddr);
+//   * the butterflies pair lanes l and l ^ 2^bit of a row of 16: DPP / ds_swizzle exchanges (wg.h OG_WAVE_XCH), no LDS traffic;
+//   * the 2^(-m/2) scale and lowband_out = sqrt(N0) x (celt/decoder.rs:2021-2028) are applied on the way out.
+// Same operations in the same order per element as the step-by-step form (butterflies from the lowest bit up).
 template <int K> struct OgXr { float v[K]; };
-
-template <int K, bool PRE>
-OG_DEV void og_xf_perm_read(const float *buf, const OgTask tk, float scale, int first, int step, OgXr<K> &r, int nmax)
-{
-    const int n = tk.n, slog = tk.slog, n0p = tk.n0p, had = (tk.flags & OG_T_LONG) != 0;
-#pragma unroll
-    for (int k = 0; k < K; k++) {
-        if (k * step >= nmax) break;                    // nmax: a uniform bound on n (the unrolled steps end on a scalar branch)
-        const int p = first + k * step;
-        r.v[k] = p < n ? (PRE ? buf[p] * scale : buf[og_reorder(slog, n0p, had, p)]) : 0.f;
-    }
-}
-template <int K, bool PRE>
-OG_DEV void og_xf_perm_write(float *buf, const OgTask tk, int first, int step, const OgXr<K> &r, int nmax)
-{
-    const int n = tk.n, slog = tk.slog, n0p = tk.n0p, had = (tk.flags & OG_T_LONG) != 0;
-#pragma unroll
-    for (int k = 0; k < K; k++) {
-        if (k * step >= nmax) break;
-        const int p = first + k * step;
-        if (p < n) buf[PRE ? og_reorder(slog, n0p, had, p) : p] = r.v[k];
-    }
-}
-
-OG_DEV void og_xf_bfly(float *buf, const OgTask tk, int bit, int first, int step)   // unscaled Haar step on index bit `bit`
-{
-    const int half = tk.n >> 1, low = (1 << bit) - 1;
-    for (int q = first; q < half; q += step) {
-        const int i0 = ((q & ~low) << 1) | (q & low), i1 = i0 | (1 << bit);
-        const float a = buf[i0], c = buf[i1];
-        buf[i0] = a + c;
-        buf[i1] = a - c;
-    }
-}
 
 OG_DEV float og_xf_scale(const OgTask tk)               // 2^(-m/2) for the m butterflies
 {
@@ -249,64 +218,89 @@ OG_DEV float og_xf_scale(const OgTask tk)               // 2^(-m/2) for the m bu
     return (m & 1 ? 0.70710678118654752440f : 1.f) * f;
 }
 
-// the s-th butterfly bit of a task, -1 when it has fewer (tf changes are at most 3 steps: celt/decoder.rs:221-226)
-OG_DEV int og_xf_bit(const OgTask tk, int s)
+struct OgXfAddr { int base, step; };  // og_reorder(first + STEP k) = base + step k
+OG_DEV OgXfAddr og_xf_addr(const OgTask tk, int first, int STEP)
 {
-    unsigned hm = tk.hm;
-    for (int k = 0; k < s; k++) hm &= hm - 1;
-    return hm ? __builtin_ctz(hm) : -1;
+    const int slog = tk.slog;
+    OgXfAddr a;
+    if (!slog) { a.base = first; a.step = STEP; return a; }
+    const int i = first & ((1 << slog) - 1);
+    a.base = OG_MUL24((tk.flags & OG_T_LONG) ? og_ordery(slog, i) : i, (int)tk.n0p) + (first >> slog);
+    a.step = STEP >> slog;
+    return a;
 }
 
-// by one wave, inside an OG_WAVES section.  PRE: lb = the wave's lowband buffer, filled from the folding source here.
+// the butterflies of the lanes' tasks on registers: hmv = the lane's task's hm (0 for lanes without one), hm_any = the OR of
+// hmv over the wave (uniform), nmax = a uniform bound on the tasks' n.  Lanes past their task's n hold zeros: their partners
+// are past it too (n is a multiple of every butterfly's span).
+#define OG_XF_BFLY_BIT(B)                                                                                           \
+    if (hm_any & (1 << (B))) {                                                                                      \
+        _Pragma("unroll") for (int k = 0; k < K; k++) {                                                             \
+            if (k * STEP < nmax) {                                                                                  \
+                OG_WAVE_XCH(ex, rv, .v[k], 1 << (B))                                                                \
+                OG_WAVE_REGS_BEGIN(lane)                                                                            \
+                if ((OG_WV(hmv) >> (B)) & 1)              /* lane bit clear: a + c; set: a - c, a = the lower lane's */ \
+                    OG_WV(rv).v[k] = ((lane >> (B)) & 1) ? OG_WV(ex) - OG_WV(rv).v[k] : OG_WV(rv).v[k] + OG_WV(ex);  \
+                OG_WAVE_REGS_END                                                                                    \
+            }                                                                                                       \
+        }                                                                                                           \
+    }
+template <int K, int STEP>
+OG_DEV void og_wave_bflies(OG_WAVE_REF(OgXr<K>, rv), OG_WAVE_REF(int, hmv), int hm_any, int nmax)
+{
+    OG_WAVE_VAR(float, ex);
+    OG_XF_BFLY_BIT(0)
+    OG_XF_BFLY_BIT(1)
+    OG_XF_BFLY_BIT(2)
+    OG_XF_BFLY_BIT(3)
+}
+
+// One task by one wave (inside an OG_WAVES section; tk uniform).  PRE: the folding source -> butterflies -> scale ->
+// deinterleave into the wave's lowband buffer lb.  POST: the decoded band -> interleave -> butterflies -> scale, in place, and
+// lowband_out.
 template <bool PRE>
-OG_DEV void og_task_xform(OgCeltLds &L, const OgTask tk, int slot, float *lb)
+OG_DEV void og_task_xform(OgCeltLds &L, const OgTask tk, int slot, float *lb, int norm_offset)
 {
-    float *buf = PRE ? lb : &L.X[0][0] + slot * 960 + tk.boff;
-    OG_WAVE_VAR(OgXr<3>, rv);
-    if (PRE) {
-        const float *src = og_norm(L, (tk.flags & OG_T_LB_ROW1) ? 1 : 0) + tk.lowpos;
-        OG_WAVE_BEGIN(lane)
-        for (int p = lane; p < tk.n; p += 64) buf[p] = src[p];
-        OG_WAVE_END
-    } else if (tk.slog) {
-        OG_WAVE_BEGIN(lane)
-        og_xf_perm_read<3, false>(buf, tk, 1.f, lane, 64, OG_WV(rv), tk.n);
-        OG_WAVE_END
-        OG_WAVE_BEGIN(lane)
-        og_xf_perm_write<3, false>(buf, tk, lane, 64, OG_WV(rv), tk.n);
-        OG_WAVE_END
-    }
-    for (int s = 0; s < 8; s++) {
-        const int bit = og_xf_bit(tk, s);
-        if (bit < 0) break;
-        OG_WAVE_BEGIN(lane)
-        og_xf_bfly(buf, tk, bit, lane, 64);
-        OG_WAVE_END
-    }
-    if (PRE) {
-        const float scale = og_xf_scale(tk);
-        OG_WAVE_BEGIN(lane)
-        og_xf_perm_read<3, true>(buf, tk, scale, lane, 64, OG_WV(rv), tk.n);
-        OG_WAVE_END
-        OG_WAVE_BEGIN(lane)
-        og_xf_perm_write<3, true>(buf, tk, lane, 64, OG_WV(rv), tk.n);
-        OG_WAVE_END
-    }
-}
-
-// scale of a transformed task (in place), and lowband_out = sqrt(N0) * x (celt/decoder.rs:2021-2028)
-OG_DEV void og_task_finish(OgCeltLds &L, const OgTask tk, int slot, int norm_offset, int first, int step)
-{
-    const bool xf = tk.hm != 0;                         // a pure reorder has scale 1
-    if (!xf && tk.norm_row == 0xFF) return;
     const int n = tk.n;
     float *x = &L.X[0][0] + slot * 960 + tk.boff;
-    float *nr = tk.norm_row != 0xFF ? og_norm(L, tk.norm_row) + (tk.boff - norm_offset) : nullptr;
-    const float sq = sqrtf((float)n), scale = og_xf_scale(tk);
-    for (int p = first; p < n; p += step) {
-        float v = x[p];
-        if (xf) { v = v * scale; x[p] = v; }
-        if (nr) nr[p] = sq * v;
+    OG_WAVE_VAR(OgXr<3>, rv);
+    OG_WAVE_VAR(int, hmv);
+    OG_WAVE_BEGIN(lane)
+    const OgXfAddr a = og_xf_addr(tk, lane, 64);
+    const float *src = PRE ? og_norm(L, (tk.flags & OG_T_LB_ROW1) ? 1 : 0) + tk.lowpos : x;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int p = lane + 64 * k;
+        OG_WV(rv).v[k] = p < n ? src[PRE ? p : a.base + a.step * k] : 0.f;
+    }
+    OG_WV(hmv) = tk.hm;
+    OG_WAVE_END                                         // every element is in a register before any is written
+    if (tk.hm) og_wave_bflies<3, 64>(rv, hmv, tk.hm, n);
+    const float scale = og_xf_scale(tk);
+    if (PRE) {
+        OG_WAVE_BEGIN(lane)
+        const OgXfAddr a = og_xf_addr(tk, lane, 64);
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            if (lane + 64 * k < n) lb[a.base + a.step * k] = OG_WV(rv).v[k] * scale;
+        }
+        OG_WAVE_END
+    } else {
+        const bool xf = tk.hm != 0, wr = xf || tk.slog;
+        float *nr = tk.norm_row != 0xFF ? og_norm(L, tk.norm_row) + (tk.boff - norm_offset) : nullptr;
+        const float sq = sqrtf((float)n);
+        OG_WAVE_BEGIN(lane)
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int p = lane + 64 * k;
+            if (p < n) {
+                float v = OG_WV(rv).v[k];
+                if (xf) v = v * scale;
+                if (wr) x[p] = v;
+                if (nr) nr[p] = sq * v;
+            }
+        }
+        OG_WAVE_END
     }
 }
 
@@ -405,14 +399,14 @@ OG_DEV void og_celt_bands(OgBandCtx &c)
             // calls take three rounds per wave instead of ten
             OG_WAVES_BEGIN(w)
             const int t0 = (int)OG_U32(PL->task_start[0]), t1 = (int)OG_U32(PL->task_start[1]);
-            const int maxb = (int)OG_U32(PL->lvl_maxcnt[0]);        // most butterflies of a level-0 call
             for (int base = 0; base < t1 - t0; base += 4 * (OG_WG / 64)) {
                 OG_WAVE_VAR(OgTask, tkv);                           // the group's task: fetched once per round
-                OG_WAVE_VAR(int, slotv);
-                OG_WAVE_VAR(OgXr<11>, rv);                          // the in-place reorder's elements in flight
+                OG_WAVE_VAR(int, xoffv);                            // where its band starts in X
+                OG_WAVE_VAR(int, hmv);
+                OG_WAVE_VAR(OgXr<11>, rv);                          // its elements l, l + 16, ... (l = lane & 15)
                 int nmax = 0;                                       // widest task of the wave's four: group 0's (largest first)
                 OG_WAVE_BEGIN(lane)
-                const int k = base + 4 * w + (lane >> 4);
+                const int k = base + 4 * w + (lane >> 4), l = lane & 15;
                 OgTask tk;
                 tk.boff = tk.n = tk.n0p = tk.lowpos = tk.ops = 0; tk.flags = tk.hm = tk.slog = tk.rctd = tk.level = 0; tk.norm_row = 0xFF;
                 int slot = 0;
@@ -422,22 +416,36 @@ OG_DEV void og_celt_bands(OgBandCtx &c)
                     slot = id & 1;
                 }
                 OG_WAVE_BCAST0(nmax, tk.n);
-                if (tk.slog) og_xf_perm_read<11, false>(&L.X[0][0] + slot * 960 + tk.boff, tk, 1.f, lane & 15, 16, OG_WV(rv), nmax);
-                OG_WV(tkv) = tk;
-                OG_WV(slotv) = slot;
-                OG_WAVE_END
-                OG_WAVE_BEGIN(lane)
-                if (OG_WV(tkv).slog)
-                    og_xf_perm_write<11, false>(&L.X[0][0] + OG_WV(slotv) * 960 + OG_WV(tkv).boff, OG_WV(tkv), lane & 15, 16, OG_WV(rv), nmax);
-                OG_WAVE_END
-                for (int s = 0; s < maxb; s++) {
-                    OG_WAVE_BEGIN(lane)
-                    const int bit = og_xf_bit(OG_WV(tkv), s);
-                    if (bit >= 0) og_xf_bfly(&L.X[0][0] + OG_WV(slotv) * 960 + OG_WV(tkv).boff, OG_WV(tkv), bit, lane & 15, 16);
-                    OG_WAVE_END
+                const int xoff = slot * 960 + tk.boff, n = tk.n;
+                const float *x = &L.X[0][0] + xoff;
+                const OgXfAddr a = og_xf_addr(tk, l, 16);
+#pragma unroll
+                for (int j = 0; j < 11; j++) {
+                    if (j * 16 < nmax) OG_WV(rv).v[j] = l + 16 * j < n ? x[a.base + a.step * j] : 0.f;
                 }
+                OG_WV(tkv) = tk;
+                OG_WV(xoffv) = xoff;
+                OG_WV(hmv) = tk.hm;
+                OG_WAVE_END                                         // every element is in a register before any is written
+                const int hm_any = OG_WAVE_GET(hmv, 0) | OG_WAVE_GET(hmv, 16) | OG_WAVE_GET(hmv, 32) | OG_WAVE_GET(hmv, 48);
+                if (hm_any) og_wave_bflies<11, 16>(rv, hmv, hm_any, nmax);
                 OG_WAVE_BEGIN(lane)
-                og_task_finish(L, OG_WV(tkv), OG_WV(slotv), norm_offset, lane & 15, 16);     // n = 0 for lanes without a task
+                const OgTask tk = OG_WV(tkv);
+                const int l = lane & 15, n = tk.n;
+                const bool xf = tk.hm != 0, wr = xf || tk.slog;
+                float *x = &L.X[0][0] + OG_WV(xoffv);
+                float *nr = tk.norm_row != 0xFF ? og_norm(L, tk.norm_row) + (tk.boff - norm_offset) : nullptr;
+                const float sq = sqrtf((float)n), scale = og_xf_scale(tk);
+#pragma unroll
+                for (int j = 0; j < 11; j++) {
+                    const int p = l + 16 * j;
+                    if (j * 16 < nmax && p < n) {                   // n = 0 for lanes without a task
+                        float v = OG_WV(rv).v[j];
+                        if (xf) v = v * scale;
+                        if (wr) x[p] = v;
+                        if (nr) nr[p] = sq * v;
+                    }
+                }
                 OG_WAVE_END
             }
             OG_WAVES_END
@@ -450,13 +458,10 @@ OG_DEV void og_celt_bands(OgBandCtx &c)
         for (int ti = (int)OG_U32(PL->task_start[lvl]) + w; ti < t1; ti += OG_WG / 64) {
             const int id = (int)OG_U32(PL->order[ti]), slot = id & 1;
             const OgTask tk = og_uniform(tasks[id]);
-            if (tk.flags & OG_T_NEED_LB) og_task_xform<true>(L, tk, slot, L.w.b.s.lb[w]);
+            if (tk.flags & OG_T_NEED_LB) og_task_xform<true>(L, tk, slot, L.w.b.s.lb[w], norm_offset);
             const int k0 = tk.ops & 1023, k1 = k0 + (tk.ops >> 10);
             for (int k = k0; k < k1; k++) og_fill_op(c, k, w, slot * 960 + tk.boff);
-            if (tk.hm | tk.slog) og_task_xform<false>(L, tk, slot, nullptr);
-            OG_WAVE_BEGIN(lane)
-            og_task_finish(L, tk, slot, norm_offset, lane, 64);
-            OG_WAVE_END
+            if (tk.hm | tk.slog | (tk.norm_row != 0xFF)) og_task_xform<false>(L, tk, slot, nullptr, norm_offset);
         }
         OG_WAVES_END
         if (lvl == 0) OG_STAMP_TO(c.cycles, 17)
@@ -464,26 +469,83 @@ OG_DEV void og_celt_bands(OgBandCtx &c)
 
     OG_STAMP_TO(c.cycles, 18)
     if (c.stop == 3) return;
-    // ---- merges: stereo_merge (celt/decoder.rs:796-827) + the N == 2 case (:1826-1862): a band per 16-lane group,
-    //      four bands per wave at a time (the dot products reduce inside the group, no barrier)
+    // ---- merges: stereo_merge (celt/decoder.rs:796-827) + the N == 2 case (:1826-1862).  A band of 64 bins or more takes a
+    //      whole wave, the others a 16-lane group each, four to a wave (bands come in increasing width, so a wave's four are
+    //      alike); both kinds are dealt round-robin to the waves.  A lane holds its (at most three) bin pairs in registers from
+    //      the dot products to the rotation; the sums reduce inside the wave / group, no workgroup barrier.
     if (C == 2) {
+        uint32_t jm = OG_U32(PL->joint);
+        jm &= end > start ? (((end >= 21 ? (1u << 21) : (1u << end)) - 1u) & ~((1u << start) - 1u)) : 0u;
+        const uint32_t widem = lm == 3 ? 0x1E0000u : lm == 2 ? 0x180000u : 0u;      // M * width >= 64 (celt/decoder.rs:281-283)
         OG_WAVES_BEGIN(w)
-        for (int i0 = start + 4 * w; i0 < end; i0 += 4 * (OG_WG / 64)) {
-            float *pa = L.w.b.s.mrg[w][0], *pb = L.w.b.s.mrg[w][1];
+        float *pa = L.w.b.s.mrg[w][0], *pb = L.w.b.s.mrg[w][1];
+        int turn = 0;                                   // whose turn the next piece of work is
+        for (uint32_t m = jm & widem; m; m &= m - 1u, turn++) {
+            if ((turn & (OG_WG / 64 - 1)) != w) continue;
+            const int i = __builtin_ctz(m), n = M * L.k.width[i], off = M * L.k.ebands[i];
+            const OgCeltBand bd = og_uniform(h->band[i]);
+            float *x = L.X[0] + off, *y = L.X[1] + off;
+            OG_WAVE_VAR(OgXr<3>, xv); OG_WAVE_VAR(OgXr<3>, yv);
+            OG_WAVE_BEGIN(lane)
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                if (64 * k < n) {                       // (uniform)
+                    const int p = lane + 64 * k;
+                    const float xe = p < n ? x[p] : 0.f, ye = p < n ? y[p] : 0.f;
+                    OG_WV(xv).v[k] = xe; OG_WV(yv).v[k] = ye;
+                    a += xe * ye; b += ye * ye;
+                }
+            }
+            pa[lane] = a; pb[lane] = b;
+            OG_WAVE_END
+            const float xy = og_wave_tree_sum(pa), yy = og_wave_tree_sum(pb);
+            const float mid = (1.f / 32768) * bd.imid, inv = (bd.flags & OG_B_INV) ? -1.f : 1.f;
+            const float xp = mid * xy, e = mid * mid + yy, e0 = e - 2.f * xp, e1 = e + 2.f * xp;
+            float ax = 1.f, bx = 0.f, ay = inv, by = 0.f;              // degenerate: y = x
+            if (!(e0 < 6e-4f || e1 < 6e-4f)) {
+                const float g0 = 1.f / sqrtf(e0), g1 = 1.f / sqrtf(e1);
+                ax = g0 * mid; bx = -g0; ay = inv * g1 * mid; by = inv * g1;
+            }
+            OG_WAVE_BEGIN(lane)
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const int p = lane + 64 * k;
+                if (64 * k < n && p < n) {
+                    const float xe = OG_WV(xv).v[k], ye = OG_WV(yv).v[k];
+                    x[p] = ax * xe + bx * ye;
+                    y[p] = ay * xe + by * ye;
+                }
+            }
+            OG_WAVE_END
+        }
+        for (uint32_t m = jm & ~widem; m; turn++) {
+            int ib[4], nmaxr = 0;                       // the round's four bands (-1: none); the widest one's bins
+            for (int g = 0; g < 4; g++) {
+                ib[g] = m ? __builtin_ctz(m) : -1;
+                if (m) nmaxr = M * L.k.width[ib[g]];
+                m &= m - 1u;
+            }
+            if ((turn & (OG_WG / 64 - 1)) != w) continue;
             OG_WAVE_VAR(OgCeltBand, bdv);                            // the group's band: fetched once
             OG_WAVE_VAR(int, nv);                                    // its width, 0 = nothing to merge
             OG_WAVE_VAR(int, offv);
+            OG_WAVE_VAR(OgXr<3>, xv); OG_WAVE_VAR(OgXr<3>, yv);
             OG_WAVE_BEGIN(lane)
-            const int i = i0 + (lane >> 4), l = lane & 15;
+            const int g = lane >> 4, l = lane & 15;
+            const int i = g == 0 ? ib[0] : g == 1 ? ib[1] : g == 2 ? ib[2] : ib[3];
             float a = 0.f, b = 0.f;
-            OgCeltBand bd = h->band[i < end ? i : start];
-            int n = 0, off = 0;
-            if (i < end && (bd.flags & OG_B_JOINT)) {
-                n = M * L.k.width[i];
-                off = M * L.k.ebands[i];
-                const float *x = L.X[0] + off, *y = L.X[1] + off;
-                if (n > 2)
-                    for (int p = l; p < n; p += 16) { a += x[p] * y[p]; b += y[p] * y[p]; }
+            const OgCeltBand bd = h->band[i >= 0 ? i : start];
+            const int n = i >= 0 ? M * L.k.width[i] : 0, off = i >= 0 ? M * L.k.ebands[i] : 0;
+            const float *x = L.X[0] + off, *y = L.X[1] + off;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                if (16 * k < nmaxr) {                   // (uniform)
+                    const int p = l + 16 * k;
+                    const float xe = p < n ? x[p] : 0.f, ye = p < n ? y[p] : 0.f;
+                    OG_WV(xv).v[k] = xe; OG_WV(yv).v[k] = ye;
+                    if (n > 2) { a += xe * ye; b += ye * ye; }
+                }
             }
             OG_WV(bdv) = bd; OG_WV(nv) = n; OG_WV(offv) = off;
             pa[lane] = a; pb[lane] = b;
@@ -515,10 +577,14 @@ OG_DEV void og_celt_bands(OgBandCtx &c)
                         const float g0 = 1.f / sqrtf(e0), g1 = 1.f / sqrtf(e1);
                         ax = g0 * mid; bx = -g0; ay = inv * g1 * mid; by = inv * g1;
                     }
-                    for (int p = l; p < n; p += 16) {
-                        const float xv = x[p], yv = y[p];
-                        x[p] = ax * xv + bx * yv;
-                        y[p] = ay * xv + by * yv;
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {
+                        const int p = l + 16 * k;
+                        if (16 * k < nmaxr && p < n) {
+                            const float xe = OG_WV(xv).v[k], ye = OG_WV(yv).v[k];
+                            x[p] = ax * xe + bx * ye;
+                            y[p] = ay * xe + by * ye;
+                        }
                     }
                 }
             }
@@ -769,8 +835,23 @@ OG_DEV void og_celt_spectrum(const OgCeltHdr *hg, const OgBandPlan *plan, const 
     //      Everything else in the row is left over from earlier launches and is replaced by zero here, so nobody has to hand
     //      the rows back zero-filled.
     const int lm0 = hg->lm & 3;
-    struct OgRow2 { OgF4 v[2]; uint32_t bb[2]; };
+    struct OgRow2 { OgF4 v[2], sq[2]; uint32_t bb[2]; };
     OG_LANE_VAR(OgRow2, rowv);
+    // which (buffer, band)s of the row K1 / the plan wrote: the plan's keep masks, cut to the coded bands (a silent frame's row
+    // is untouched); uniform
+    //      The calls with nothing to transform (most of a non-transient frame's) are finished here as well: their lowband_out
+    //      = sqrt(N0) x goes to the folding source rows, zero everywhere else (the plan's `plain` masks).
+    uint32_t keepm[2], plainm[2];
+    int norm_off0;
+    {
+        const uint32_t flags0 = OG_U32(hg->flags), b_lo = OG_U32(hg->start), b_hi = (flags0 & OG_F_SILENCE) ? 0u : OG_U32(hg->end);
+        const uint32_t coded = b_hi > b_lo ? ((b_hi >= 21u ? (1u << 21) : (1u << b_hi)) - 1u) & ~((1u << b_lo) - 1u) : 0u;
+        keepm[0] = OG_U32(plan->keep[0]) & coded;
+        keepm[1] = OG_U32(plan->keep[1]) & coded;
+        plainm[0] = OG_U32(plan->plain[0]) & coded;
+        plainm[1] = OG_U32(plan->plain[1]) & coded;
+        norm_off0 = (int)(OG_U32(T->k.ebands[b_lo < 21u ? b_lo : 20u]) << lm0);
+    }
     OG_LANES_BEGIN(tid)
     {
         const uint32_t *src = (const uint32_t *)hg;
@@ -790,30 +871,35 @@ OG_DEV void og_celt_spectrum(const OgCeltHdr *hg, const OgBandPlan *plan, const 
         if (p < 480) {
             OG_LV(rowv).v[j] = ((const OgF4 *)coef_row)[p];
             OG_LV(rowv).bb[j] = ((const uint32_t *)T->bin2band[lm0])[p >= 240 ? p - 240 : p];     // the four bins' bands
+            OG_LV(rowv).sq[j] = ((const OgF4 *)T->bin2sq[lm0])[p >= 240 ? p - 240 : p];
         }
     }
-    for (int p = tid; p < 2 * 800; p += OG_WG) L.R[p] = 0.f;
-    OG_LANES_END
-    OG_LANES_BEGIN(tid)
+    for (int p = tid + (960 - norm_off0); p < 800; p += OG_WG) L.R[p] = L.R[800 + p] = 0.f;   // norm bins no piece below covers (none when the frame starts at band 0)
 #pragma unroll
     for (int j = 0; j < 2; j++) {
         const int p = tid + j * OG_WG;
         if (p < 480) {
-            const int slot = p >= 240;
             const OgF4 v = OG_LV(rowv).v[j];
-            const uint32_t bb = OG_LV(rowv).bb[j];
-            float e[4] = {v.x, v.y, v.z, v.w};
-            const int b_lo = L.hdr.start, b_hi = (L.hdr.flags & OG_F_SILENCE) ? 0 : (int)L.hdr.end;   // (a silent frame's row is untouched)
+            const OgF4 sq = OG_LV(rowv).sq[j];
+            const int slot = p >= 240;
+            const uint32_t bb = OG_LV(rowv).bb[j], m = keepm[slot], pm = plainm[slot];
+            float e[4] = {v.x, v.y, v.z, v.w}, nv[4] = {sq.x, sq.y, sq.z, sq.w};
 #pragma unroll
-            for (int k = 0; k < 4; k++) {               // branch-free on purpose: one LDS read and one select per bin
-                const int b = (int)((bb >> (8 * k)) & 255u);
-                const OgCeltBand bd = L.hdr.band[b < 21 ? b : 20];
-                // leaves of this band that write this buffer with pulses (or a sign): all of them but the fill-path ones
-                const int cnt = slot ? (int)bd.ny - (int)bd.fy : (int)bd.nx - (int)bd.fx;
-                const int keep = (int)(b >= b_lo) & (int)(b < b_hi) & (int)(b < 21) & (int)(cnt > 0);
-                e[k] = keep ? e[k] : 0.f;
+            for (int k = 0; k < 4; k++) {               // band 255 (above band 20) reads bit 31, which is clear
+                const uint32_t b = (bb >> (8 * k)) & 255u;
+                e[k] = ((m >> (b & 31u)) & 1u) ? e[k] : 0.f;
+                nv[k] = ((pm >> (b & 31u)) & 1u) ? nv[k] * e[k] : 0.f;
             }
             ((OgF4 *)&L.X[0][0])[p] = OgF4{e[0], e[1], e[2], e[3]};
+            const int ni = 4 * (p - 240 * slot) - norm_off0;            // the piece's place in the norm row
+            float *nr = og_norm(L, slot);
+            if ((norm_off0 & 3) == 0) {
+                if (ni >= 0 && ni < 800) *(OgF4 *)(nr + ni) = OgF4{nv[0], nv[1], nv[2], nv[3]};
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (ni + k >= 0 && ni + k < 800) nr[ni + k] = nv[k];
+            }
         }
     }
     OG_LANES_END
@@ -852,15 +938,16 @@ OG_DEV void og_celt_spectrum(const OgCeltHdr *hg, const OgBandPlan *plan, const 
     OG_BARRIER                                          // the uniform reads of the band-walk tables above are done in every wave
                                                         // before the twiddles below replace them
 
-    // ---- phase 4: denormalise (RFC 6716 4.3.6) + channel up/down-mix into MDCT bins; the first region also stages the
-    //      FFT twiddles and the bin -> band map over the (now dead) band-walk tables and fetches the lane's IMDCT pre / post
-    //      twiddles (the same for both: work item q of either pass has the same bin index) into registers
+    // ---- phase 4: denormalise (RFC 6716 4.3.6) + channel up/down-mix, fused into the IMDCT's pre-twiddle.  The first region
+    //      stages the FFT twiddles over the (now dead) band-walk tables and the per-(channel, band) gains, and fetches what a
+    //      lane's work items need into registers: the IMDCT pre / post twiddle (the same for both: work item q of either pass
+    //      has the same bin index) and the bands of the item's two bins
     const int B = transient ? M : 1, NB = N >> (transient ? lm : 0), n4 = NB >> 1;
     OgCf *ldsW = L.w.t.W;
     // the CC * B transforms of the frame are interleaved in the FFT buffers: work item q = bin i of transform t = ch * B + b
-    // at q = i * TT + t, TT = CC * B = 2^tsh
+    // at q = i * TT + t, TT = CC * B = 2^tsh; it reads MDCT bins 2i and NB-1-2i of block b, which sit at j1, j2 in X[ch]
     const int bsh = transient ? lm : 0, tsh = bsh + (CC == 2), tmask = (1 << tsh) - 1;
-    struct OgTw4 { OgCf w[4]; };
+    struct OgTw4 { OgCf w[4]; uint32_t bands[4]; };
     OG_LANE_VAR(OgTw4, twr);
     OG_LANES_BEGIN(tid)
     for (int t = tid; t < 48; t += OG_WG) {             // per-(channel, band) gains 2^(E + mean), zero outside [start, end)
@@ -873,46 +960,34 @@ OG_DEV void og_celt_spectrum(const OgCeltHdr *hg, const OgBandPlan *plan, const 
         L.gband[ch][b] = g;
     }
     for (int p = tid; p < 960; p += OG_WG) ((float *)ldsW)[p] = ((const float *)T->fft_w)[p];
-    for (int p = tid; p < 960 / 4; p += OG_WG) ((uint32_t *)L.R)[p] = ((const uint32_t *)T->bin2band[lm0])[p];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int q = tid + j * OG_WG;
         OG_LV(twr).w[j] = OgCf{0.f, 0.f};
-        if (q < CC * (N >> 1)) OG_LV(twr).w[j] = T->tw[(n4 - 60) + (q >> tsh)];
+        OG_LV(twr).bands[j] = 0;
+        if (q < CC * (N >> 1)) {
+            const int i = q >> tsh, b = (q & tmask) & (B - 1);
+            const int j1 = ((2 * i) << bsh) + b, j2 = N - B - ((2 * i) << bsh) + b;
+            OG_LV(twr).w[j] = T->tw[(n4 - 60) + i];
+            const uint32_t b1 = T->bin2band[lm0][j1], b2 = T->bin2band[lm0][j2];
+            OG_LV(twr).bands[j] = (b1 == 255u ? 23u : b1) | (b2 == 255u ? 23u : b2) << 8;       // gband[.][21..23] = 0
+        }
     }
     OG_LANES_END
     OG_STAMP(9)
-    OG_LANES_BEGIN(tid)
-    int bb[4];
-    float x0[4], x1[4], g0[4], g1[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {                       // loads first (independent), then arithmetic: the LDS latencies overlap
-        const int j = tid + k * OG_WG < 960 ? tid + k * OG_WG : 959;
-        bb[k] = ((const uint8_t *)L.R)[j];
-        x0[k] = L.X[0][j];
-        x1[k] = L.X[1][j];
-    }
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int b = bb[k] == 255 ? 23 : bb[k];        // gband[.][21..23] = 0
-        g0[k] = L.gband[0][b];
-        g1[k] = L.gband[1][b];
-    }
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int j = tid + k * OG_WG;
-        float v0 = x0[k] * g0[k];
-        const float v1 = C == 2 ? x1[k] * g1[k] : v0;
-        if (CC == 1 && C == 2) v0 = 0.5f * v0 + 0.5f * v1;
-        if (j < 960) { L.X[0][j] = v0; L.X[1][j] = v1; }
-    }
-    OG_LANES_END
-    OG_STAMP(10)
-    if (dbg_freq) {
+    if (dbg_freq) {                                     // stage dump: the denormalised spectrum as the separate pass would leave it
         OG_LANES_BEGIN(tid)
-        for (int p = tid; p < 2 * 960; p += OG_WG) dbg_freq[p] = (&L.X[0][0])[p];
+        for (int j = tid; j < 960; j += OG_WG) {
+            const int bb = T->bin2band[lm0][j], b = bb == 255 ? 23 : bb;
+            float v0 = L.X[0][j] * L.gband[0][b];
+            const float v1 = C == 2 ? L.X[1][j] * L.gband[1][b] : v0;
+            if (CC == 1 && C == 2) v0 = 0.5f * v0 + 0.5f * v1;
+            dbg_freq[j] = v0;
+            dbg_freq[960 + j] = v1;
+        }
         OG_LANES_END
     }
+    OG_STAMP(10)
 
     OG_STAMP(5)
     if (stop == 7) return;
@@ -920,11 +995,23 @@ OG_DEV void og_celt_spectrum(const OgCeltHdr *hg, const OgBandPlan *plan, const 
     OgCf *bufA = (OgCf *)L.R, *bufB = (OgCf *)&L.X[0][0];
     OG_LANES_BEGIN(tid)
 #pragma unroll
-    for (int j = 0; j < 4; j++) {                                            // pre-twiddle
+    for (int j = 0; j < 4; j++) {                                            // denormalise + pre-twiddle
         const int q = tid + j * OG_WG;
         if (q < CC * (N >> 1)) {
             const int t = q & tmask, i = q >> tsh, ch = t >> bsh, b = t & (B - 1);
-            const float x1 = L.X[ch][((2 * i) << bsh) + b], x2 = L.X[ch][N - B - ((2 * i) << bsh) + b];    // bins 2i and NB-1-2i of block b
+            const int j1 = ((2 * i) << bsh) + b, j2 = N - B - ((2 * i) << bsh) + b;
+            const int b1 = (int)(OG_LV(twr).bands[j] & 255u), b2 = (int)(OG_LV(twr).bands[j] >> 8);
+            float x1, x2;
+            if (C == 2 && CC == 2) {
+                x1 = L.X[ch][j1] * L.gband[ch][b1];
+                x2 = L.X[ch][j2] * L.gband[ch][b2];
+            } else if (C == 2) {                                             // stereo coded, mono out
+                x1 = 0.5f * (L.X[0][j1] * L.gband[0][b1]) + 0.5f * (L.X[1][j1] * L.gband[1][b1]);
+                x2 = 0.5f * (L.X[0][j2] * L.gband[0][b2]) + 0.5f * (L.X[1][j2] * L.gband[1][b2]);
+            } else {                                                         // mono coded: both outputs from buffer 0
+                x1 = L.X[0][j1] * L.gband[0][b1];
+                x2 = L.X[0][j2] * L.gband[0][b2];
+            }
             const OgCf w = OG_LV(twr).w[j];
             OgCf z;
             z.r = x1 * w.r + x2 * w.i;

@@ -41,8 +41,12 @@ struct alignas(16) OgBandPlan {
     uint32_t seed_out;
     uint16_t nops, merge_cnt;         // live fill leaves; norm bins below the dual -> intensity switch
     uint8_t nlevels, merge_level;     // highest level in use; level the switch precedes (0xFF = none)
-    uint8_t lvl_maxcnt[OG_MAXLEVEL + 1];   // per level: the most Haar butterflies (0..3) any of its tasks has
     uint8_t pad_[2];
+    uint32_t plain[2];                // per buffer, bit = band: a call with no fill leaves and no transform whose lowband_out goes to
+                                      // the norm row of its buffer's number: the frame kernel does it while staging (not in `order`)
+    uint32_t joint;                   // bit = band: coded jointly (mid / side), i.e. the frame kernel has a stereo merge to do
+    uint32_t keep[2];                 // per buffer, bit = band: K1 (or the plan, for one-bin bands) wrote this band of the frame's
+                                      // scratch row; the frame kernel reads every other bin as zero (bits 21..31 are zero)
     uint16_t op_start[OG_MAXLEVEL + 2];    // ops of level l: op[op_start[l]] .. op[op_start[l + 1]]
     uint8_t order[44];                // active task ids sorted by level (band order inside a level)
     uint8_t task_start[OG_MAXLEVEL + 3];   // tasks of level l: order[task_start[l]] .. order[task_start[l + 1]]
@@ -95,7 +99,7 @@ struct OgLaneScratch {                // u16 cells, cell i at p[i * stride] (lan
 OG_DEV void og_band_plan(const OgCeltHdr *h, const OgCeltLeaf *lv, const OgCeltConst &K, const uint32_t *la, const uint32_t *lc,
                          const uint32_t *cm_row, float *coef_row, OgBandPlan *P, OgLaneScratch sc)
 {
-    const OgLaneScratch tl = sc.at(0), blevel = sc.at(44), col0 = sc.at(65), col1 = sc.at(86), maxcnt = sc.at(107),
+    const OgLaneScratch tl = sc.at(0), blevel = sc.at(44), col0 = sc.at(65), col1 = sc.at(86),
                         cursor = sc.at(131), tcur = sc.at(157);
     const int lm = h->lm, M = 1 << lm, start = h->start, end = h->end;
     const int C = (h->flags & OG_F_STEREO) ? 2 : 1;
@@ -103,8 +107,7 @@ OG_DEV void og_band_plan(const OgCeltHdr *h, const OgCeltLeaf *lv, const OgCeltC
     const int nleaves = h->nleaves < OG_MAXLEAF ? h->nleaves : OG_MAXLEAF;
     const int norm_offset = M * K.ebands[start < 21 ? start : 20];
     for (int i = 0; i < 21; i++) blevel[i] = col0[i] = col1[i] = 0;
-    for (int l = 0; l <= OG_MAXLEVEL; l++) maxcnt[l] = 0;
-    uint32_t seed = h->seed;
+    uint32_t seed = h->seed, keep0 = 0, keep1 = 0, joint = 0, plain0 = 0, plain1 = 0;
     int floor_lvl = 1, maxlvl = 0, merge_level = 0xFF, merge_cnt = 0, nops = 0;
     const bool silence = (h->flags & OG_F_SILENCE) != 0;
 
@@ -123,6 +126,10 @@ OG_DEV void og_band_plan(const OgCeltHdr *h, const OgCeltLeaf *lv, const OgCeltC
         }
         const OgCeltBand bd = h->band[i];
         const int n = M * K.width[i], boff = M * K.ebands[i];
+        // leaves of this band that write a buffer with pulses (or a sign): all of them but the fill-path ones
+        if (C == 2 && (bd.flags & OG_B_JOINT)) joint |= 1u << i;
+        if ((int)bd.nx - (int)bd.fx > 0) keep0 |= 1u << i;
+        if ((int)bd.ny - (int)bd.fy > 0) keep1 |= 1u << i;
         const bool dual = (bd.flags & OG_B_DUAL) != 0;
         bool any_chain = false;
         int rc[2] = {0, 0}, td[2] = {0, 0}, B0[2] = {1, 1};
@@ -223,18 +230,20 @@ OG_DEV void og_band_plan(const OgCeltHdr *h, const OgCeltLeaf *lv, const OgCeltC
             if (any_chain) blevel[i] = (uint8_t)lvl;
             if (lvl > maxlvl) maxlvl = lvl;
         }
-        for (int slot = 0; slot < 2; slot++) {          // transform sizes per level (non-fill tasks are level 0)
-            const OgTask &t = tk[slot];
-            if (!(t.flags & OG_T_ACTIVE) || t.n == 1) continue;
-            const int cnt = (t.rctd & 15) + (t.rctd >> 4);      // Haar butterflies of the call
-            if (cnt > maxcnt[t.level]) maxcnt[t.level] = (uint8_t)cnt;
-        }
         col0[i] = (uint8_t)(dual || C == 1 ? cm[0] : (cm[0] | cm[1]));
         col1[i] = (uint8_t)(dual ? cm[1] : C == 1 ? cm[0] : (cm[0] | cm[1]));
         P->task[2 * i] = tk[0];
         P->task[2 * i + 1] = tk[1];
-        for (int slot = 0; slot < 2; slot++)            // level of the active tasks, kept where the sort below reads it cheaply
-            tl[2 * i + slot] = (tk[slot].flags & OG_T_ACTIVE) ? tk[slot].level : 0xFF;
+        for (int slot = 0; slot < 2; slot++) {          // level of the active tasks, kept where the sort below reads it cheaply
+            const OgTask &t = tk[slot];
+            int lv = (t.flags & OG_T_ACTIVE) ? t.level : 0xFF;
+            if (lv == 0 && !(t.hm | t.slog) && (t.norm_row == 0xFF || t.norm_row == slot)) {
+                // nothing to transform: at most lowband_out = sqrt(N0) x, which the frame kernel writes while staging
+                if (t.norm_row == slot) { if (slot) plain1 |= 1u << i; else plain0 |= 1u << i; }
+                lv = 0xFF;
+            }
+            tl[2 * i + slot] = (uint16_t)lv;
+        }
     }
     for (int i = 0; i < 24; i++) {
         P->collapse[0][i] = i < 21 ? col0[i] : 0;
@@ -243,8 +252,8 @@ OG_DEV void og_band_plan(const OgCeltHdr *h, const OgCeltLeaf *lv, const OgCeltC
     P->seed_out = seed;
     P->nops = (uint16_t)nops; P->merge_cnt = (uint16_t)merge_cnt;
     P->nlevels = (uint8_t)maxlvl; P->merge_level = (uint8_t)merge_level;
-    for (int l = 0; l <= OG_MAXLEVEL; l++) P->lvl_maxcnt[l] = (uint8_t)maxcnt[l];
     P->pad_[0] = P->pad_[1] = 0;
+    P->keep[0] = keep0; P->keep[1] = keep1; P->joint = joint; P->plain[0] = plain0; P->plain[1] = plain1;
     // counting sort of the ops by level (stable)
     for (int l = 0; l <= OG_MAXLEVEL + 1; l++) cursor[l] = 0;
     for (int j = 0; j < nops; j++) cursor[P->op_decode[j].level + 1]++;

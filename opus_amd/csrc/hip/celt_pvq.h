@@ -6,6 +6,7 @@
 #include "celt_frame_types.h"
 #include "../../../include/opusgpu.h"
 
+struct alignas(16) OgF4s { float x, y, z, w; };
 OG_DEV uint32_t og_lcg(uint32_t s) { return 1664525u * s + 1013904223u; }   // celt/decoder.rs:1595-1599
 
 // ------------------------------------------------------------------------------------------------
@@ -15,7 +16,7 @@ OG_DEV uint32_t og_lcg(uint32_t s) { return 1664525u * s + 1013904223u; }   // c
 OG_DEV uint32_t og_u2(const uint32_t *U2, int n, int k)
 {
     const int lo = n < k ? n : k, hi = n < k ? k : n;
-    return U2[lo * OG_U2_STRIDE + hi];
+    return U2[OG_MUL24(lo, OG_U2_STRIDE) + hi];         // (small factors: the full-rate 24-bit multiply)
 }
 
 // cwrsi (celt/decoder.rs:541-660) as one branch-uniform loop, so that the 64 leaves of a wavefront -- each in a
@@ -87,8 +88,9 @@ OG_DEV uint32_t og_cwrsi(const uint32_t *U2, int n, int k, uint32_t i, float *x,
 
 // RFC 6716 vq.c exp_rotation1 (celt/decoder.rs:676-692).  The reference loops walk x[i], x[i+stride] in place; the
 // `stride` residue classes are independent first-order recurrences, so each runs with its carry in a register
-// (same arithmetic, same order within a class).  Eight steps are loaded, rotated and stored at a time so that the
-// LDS latency is paid per block, not per coefficient.
+// (same order within a class; each step's two outputs are one multiply and one fused multiply-add, so the carried value
+// sees one operation per step).  Eight steps are loaded, rotated and stored at a time so that the LDS latency is paid per
+// block, not per coefficient.
 OG_DEV void og_rot_fwd(float *x, int xs, int i, int stride, int cnt, float c, float s)      // steps at i, i+stride, ...
 {
     float t = x[i * xs];
@@ -97,7 +99,7 @@ OG_DEV void og_rot_fwd(float *x, int xs, int i, int stride, int cnt, float c, fl
 #pragma unroll
         for (int j = 0; j < 8; j++) v[j] = x[(i + (j + 1) * stride) * xs];
 #pragma unroll
-        for (int j = 0; j < 8; j++) { const float x2 = v[j]; v[j] = c * t - s * x2; t = c * x2 + s * t; }
+        for (int j = 0; j < 8; j++) { const float x2 = v[j]; v[j] = fmaf(c, t, -(s * x2)); t = fmaf(s, t, c * x2); }
 #pragma unroll
         for (int j = 0; j < 8; j++) x[(i + j * stride) * xs] = v[j];
         i += 8 * stride;
@@ -105,8 +107,8 @@ OG_DEV void og_rot_fwd(float *x, int xs, int i, int stride, int cnt, float c, fl
     }
     for (; cnt > 0; cnt--, i += stride) {
         const float x2 = x[(i + stride) * xs];
-        x[i * xs] = c * t - s * x2;
-        t = c * x2 + s * t;
+        x[i * xs] = fmaf(c, t, -(s * x2));
+        t = fmaf(s, t, c * x2);
     }
     x[i * xs] = t;
 }
@@ -119,7 +121,7 @@ OG_DEV void og_rot_bwd(float *x, int xs, int i, int stride, int cnt, float c, fl
 #pragma unroll
         for (int j = 0; j < 8; j++) v[j] = x[(i - j * stride) * xs];
 #pragma unroll
-        for (int j = 0; j < 8; j++) { const float x1 = v[j]; v[j] = c * u + s * x1; u = c * x1 - s * u; }
+        for (int j = 0; j < 8; j++) { const float x1 = v[j]; v[j] = fmaf(c, u, s * x1); u = fmaf(-s, u, c * x1); }
 #pragma unroll
         for (int j = 0; j < 8; j++) x[(i - j * stride + stride) * xs] = v[j];
         i -= 8 * stride;
@@ -127,8 +129,8 @@ OG_DEV void og_rot_bwd(float *x, int xs, int i, int stride, int cnt, float c, fl
     }
     for (; cnt > 0; cnt--, i -= stride) {
         const float x1 = x[i * xs];
-        x[(i + stride) * xs] = c * u + s * x1;
-        u = c * x1 - s * u;
+        x[(i + stride) * xs] = fmaf(c, u, s * x1);
+        u = fmaf(-s, u, c * x1);
     }
     x[(i + stride) * xs] = u;
 }
@@ -199,7 +201,10 @@ OG_DEV void og_pvq_lane(const OgLeafRef ref, const OgCeltHdr *hdr, const OgCeltL
     int16_t *dbg = dbg_pulses ? dbg_pulses + (size_t)ref.frame * 1920 + ch * 960 + lf.pos : nullptr;
     const uint32_t cm = og_pvq_leaf(U2, lf, spread, xl, xs, dbg, stamps);
     float *dst = og_work_coef(work, ref.frame) + ch * 960 + lf.pos;
-    for (int i = 0; i < lf.n; i++) dst[i] = xl[i * xs];
+    int i = 0;
+    if ((lf.pos & 3) == 0)                              // 16-byte stores where the leaf's place in the row allows them
+        for (; i + 4 <= lf.n; i += 4) *(OgF4s *)(dst + i) = OgF4s{xl[i * xs], xl[(i + 1) * xs], xl[(i + 2) * xs], xl[(i + 3) * xs]};
+    for (; i < lf.n; i++) dst[i] = xl[i * xs];
     OG_ATOMIC_OR(og_work_cm(work, ref.frame) + ch * 24 + lf.band, cm);
     OG_PVQ_STAMP(3)
 }

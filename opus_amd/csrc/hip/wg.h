@@ -66,6 +66,24 @@ OG_DEV float og_dpp_wave_shr1(float v)
 #define OG_WAVE_REGS_BEGIN(lane) { const int lane = (int)(threadIdx.x & 63); {
 #define OG_WAVE_REGS_END } }
 #define OG_WAVE_FENCE __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+// Lane exchanges for butterflies whose two inputs sit in lanes l and l ^ MASK (MASK = 1, 2, 4, 8: inside a row of 16 lanes):
+//   OG_WAVE_XCH(dst, src, MEMBER, MASK)   dst of lane l = src MEMBER of lane l ^ MASK     (src: an OG_WAVE_VAR; MEMBER: e.g. .v[3] or empty)
+// MASK 1, 2: DPP quad_perm; 8: DPP row_ror:8; 4: ds_swizzle (bit mode) -- no memory is touched by any of them.
+// OG_WAVE_GET(src, L): lane L's value of an int OG_WAVE_VAR, as a uniform value.  OG_WAVE_REF(T, name): an OG_WAVE_VAR as a function parameter.
+template <int MASK> OG_DEV float og_lane_xor(float v)
+{
+    static_assert(MASK == 1 || MASK == 2 || MASK == 4 || MASK == 8, "inside a row of 16 lanes");
+    const int x = __builtin_bit_cast(int, v);
+    int r;
+    if (MASK == 1) r = __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true);            // quad_perm [1,0,3,2]
+    else if (MASK == 2) r = __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true);       // quad_perm [2,3,0,1]
+    else if (MASK == 8) r = __builtin_amdgcn_update_dpp(0, x, 0x128, 0xF, 0xF, true);      // row_ror:8
+    else r = __builtin_amdgcn_ds_swizzle(x, 0x101F);                                       // and 0x1F, or 0, xor 4
+    return __builtin_bit_cast(float, r);
+}
+#define OG_WAVE_XCH(dst, src, MEMBER, MASK) dst = og_lane_xor<MASK>(src MEMBER);
+#define OG_WAVE_GET(src, L) __builtin_amdgcn_readlane((int)(src), (L))
+#define OG_WAVE_REF(T, name) T &name
 #else
 #include <math.h>
 #define OG_DEV static inline
@@ -98,4 +116,7 @@ OG_DEV float og_dpp_wave_shr1(float v)
 #define OG_WAVE_REGS_BEGIN(lane) for (int lane = 0; lane < 64; lane++) { {
 #define OG_WAVE_REGS_END } }
 #define OG_WAVE_FENCE
+#define OG_WAVE_XCH(dst, src, MEMBER, MASK) { for (int l_ = 0; l_ < 64; l_++) dst[l_] = src[l_ ^ (MASK)] MEMBER; }
+#define OG_WAVE_GET(src, L) ((int)src[L])
+#define OG_WAVE_REF(T, name) T (&name)[64]
 #endif

@@ -49,5 +49,6 @@ void og_fill_celt_tables(OgCeltTables *t)
             for (int i = 0; i < 21; i++)
                 if (j >= (CELT_EBANDS[i] << lm) && j < (CELT_EBANDS[i + 1] << lm)) b = i;
             t->bin2band[lm][j] = (uint8_t)b;
+            t->bin2sq[lm][j] = b < 21 ? sqrtf((float)(CELT_BAND_WIDTH[b] << lm)) : 0.f;
         }
 }

@@ -74,8 +74,12 @@ extern "C" void emu_plan_stats(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, u
         if (k.hm | k.slog) { if (k.level == 0) xf0++; else xfn++; }
     }
     out[3] = act; out[4] = xf0; out[5] = xfn;
-    int mc = 0;
-    for (int l = 0; l <= OG_MAXLEVEL; l++) if (P->lvl_maxcnt[l] > mc) mc = P->lvl_maxcnt[l];
+    int mc = 0;                                         // most Haar butterflies of any call
+    for (int t = 0; t < 42; t++) {
+        const OgTask &k = P->task[t];
+        const int cnt = (k.rctd & 15) + (k.rctd >> 4);
+        if ((k.flags & OG_T_ACTIVE) && k.n != 1 && cnt > mc) mc = cnt;
+    }
     out[6] = mc; out[7] = hdr[f].nleaves;
 }
 
