@@ -73,8 +73,11 @@ typedef struct {             /* one decode_band_no_split / decode_band_1 call, 1
 
 typedef struct {             /* one PVQ leaf (K > 0) to expand: the unit of work of the K1 kernel */
     uint32_t leaf;           /* index into the launch's leaf array */
-    uint32_t frame;          /* index into the launch's OgCeltHdr array */
+    uint32_t frame;          /* bits 0..29: index into the launch's OgCeltHdr array; bits 30..31: that frame's `spread`
+                                (copied here by opusgpu_sort_pvq_leaves so that K1 does not have to fetch the header) */
 } OgLeafRef;
+#define OG_REF_FRAME_MASK 0x3FFFFFFFu
+#define OG_REF_SPREAD_SHIFT 30
 
 typedef struct {             /* one CELT frame; fixed stride */
     uint32_t stream;         /* state slot / PCM row of the stream this frame belongs to */

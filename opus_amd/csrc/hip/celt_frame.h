@@ -134,7 +134,7 @@ OG_DEV void og_uniform_dot2(const float *x, const float *y, int n, float *xy, fl
 // x *= gain / ||x||  (celt/decoder.rs:788-794)
 OG_DEV void og_wg_renormalize(float *x, int n, float gain)
 {
-    const float g = gain / sqrtf(1e-15f + og_uniform_sumsq(x, n));
+    const float g = gain * og_frsq(1e-15f + og_uniform_sumsq(x, n));
     OG_BARRIER                                          // every wave has read x before anyone scales it
     OG_LANES_BEGIN(tid)
     for (int p = tid; p < n; p += OG_WG) x[p] *= g;
@@ -288,7 +288,7 @@ OG_DEV void og_task_xform(OgCeltLds &L, const OgTask tk, int slot, float *lb, in
     } else {
         const bool xf = tk.hm != 0, wr = xf || tk.slog;
         float *nr = tk.norm_row != 0xFF ? og_norm(L, tk.norm_row) + (tk.boff - norm_offset) : nullptr;
-        const float sq = sqrtf((float)n);
+        const float sq = og_fsqrt((float)n);
         OG_WAVE_BEGIN(lane)
 #pragma unroll
         for (int k = 0; k < 3; k++) {
@@ -360,7 +360,7 @@ OG_DEV void og_fill_op(OgBandCtx &c, int k, int w, int task_pos)     // task_pos
         part[lane] = e;
         OG_WAVE_END
     }
-    const float g = op.gain / sqrtf(1e-15f + og_wave_tree_sum(part));
+    const float g = op.gain * og_frsq(1e-15f + og_wave_tree_sum(part));
     OG_WAVE_BEGIN(lane)
     for (int p = lane; p < nn; p += 64) xl[p] *= g;
     OG_WAVE_END
@@ -435,7 +435,7 @@ OG_DEV void og_celt_bands(OgBandCtx &c)
                 const bool xf = tk.hm != 0, wr = xf || tk.slog;
                 float *x = &L.X[0][0] + OG_WV(xoffv);
                 float *nr = tk.norm_row != 0xFF ? og_norm(L, tk.norm_row) + (tk.boff - norm_offset) : nullptr;
-                const float sq = sqrtf((float)n), scale = og_xf_scale(tk);
+                const float sq = og_fsqrt((float)n), scale = og_xf_scale(tk);
 #pragma unroll
                 for (int j = 0; j < 11; j++) {
                     const int p = l + 16 * j;
@@ -504,7 +504,7 @@ OG_DEV void og_celt_bands(OgBandCtx &c)
             const float xp = mid * xy, e = mid * mid + yy, e0 = e - 2.f * xp, e1 = e + 2.f * xp;
             float ax = 1.f, bx = 0.f, ay = inv, by = 0.f;              // degenerate: y = x
             if (!(e0 < 6e-4f || e1 < 6e-4f)) {
-                const float g0 = 1.f / sqrtf(e0), g1 = 1.f / sqrtf(e1);
+                const float g0 = og_frsq(e0), g1 = og_frsq(e1);
                 ax = g0 * mid; bx = -g0; ay = inv * g1 * mid; by = inv * g1;
             }
             OG_WAVE_BEGIN(lane)
@@ -574,7 +574,7 @@ OG_DEV void og_celt_bands(OgBandCtx &c)
                     const float e = mid * mid + sd, e0 = e - 2.f * xp, e1 = e + 2.f * xp;
                     float ax = 1.f, bx = 0.f, ay = inv, by = 0.f;      // degenerate: y = x
                     if (!(e0 < 6e-4f || e1 < 6e-4f)) {
-                        const float g0 = 1.f / sqrtf(e0), g1 = 1.f / sqrtf(e1);
+                        const float g0 = og_frsq(e0), g1 = og_frsq(e1);
                         ax = g0 * mid; bx = -g0; ay = inv * g1 * mid; by = inv * g1;
                     }
 #pragma unroll
@@ -615,11 +615,11 @@ OG_DEV void og_anti_collapse(OgBandCtx &c)
     if (tid < npairs) {
         const int i = start + (C == 2 ? tid >> 1 : tid), ch = C == 2 ? tid & 1 : 0;
         const int n0 = L.k.width[i];
-        const float thresh = 0.5f * exp2f(-0.125f * (float)h->pulses_depth[i]);
-        const float sqrt_1 = 1.f / sqrtf((float)(n0 << lm));
+        const float thresh = 0.5f * og_fexp2(-0.125f * (float)h->pulses_depth[i]);
+        const float sqrt_1 = og_frsq((float)(n0 << lm));
         float ediff = h->energy[ch][i] - h->prev_min[ch][i];
         if (ediff < 0) ediff = 0;
-        float r = 2.f * exp2f(-ediff);
+        float r = 2.f * og_fexp2(-ediff);
         if (lm == 3) r *= 1.41421356f;
         if (r > thresh) r = thresh;
         A.r[tid] = r * sqrt_1;
@@ -658,7 +658,7 @@ OG_DEV void og_anti_collapse(OgBandCtx &c)
         }
         part[lane] = e;
         OG_WAVE_END
-        const float g = 1.f / sqrtf(1e-15f + og_wave_tree_sum(part));
+        const float g = og_frsq(1e-15f + og_wave_tree_sum(part));
         OG_WAVE_BEGIN(lane)
         for (int p = lane; p < n; p += 64) x[p] *= g;
         OG_WAVE_END
@@ -955,7 +955,7 @@ OG_DEV void og_celt_spectrum(const OgCeltHdr *hg, const OgBandPlan *plan, const 
         float g = 0.f;
         if (!silence && b >= h->start && b < h->end && b < 21) {
             const float lg = h->energy[ch < C ? ch : 0][b] + L.k.emeans[b];
-            g = exp2f(lg < 32.f ? lg : 32.f);
+            g = og_fexp2(lg < 32.f ? lg : 32.f);
         }
         L.gband[ch][b] = g;
     }
@@ -1201,7 +1201,7 @@ OG_DEV void og_celt_tail_run(const OgCeltHdr *hg, uint32_t nfr, OgCeltState *sta
         const uint32_t flags = hd.flags;
         const int CC = (flags & OG_F_OUT_STEREO) ? 2 : 1;
         const bool transient = (flags & OG_F_TRANSIENT) != 0;
-        const int B = transient ? M : 1, NB = N / B;
+        const int B = transient ? M : 1, NB = N >> (transient ? lm : 0);
         if (CC > CCrun) CCrun = CC;
         if (t && (flags & OG_F_RESET)) {                // a reset inside the run: forget everything older
             pos = 0;

@@ -9,12 +9,16 @@
 
 // K1: one lane per PVQ leaf, all four size classes in one launch: 256-thread workgroups, each serving one class with as many
 // lanes as fit a common LDS budget -- 16 lanes for N <= 176, 32 for N <= 64, 128 for N <= 24, 256 for N <= 8 (12 KB of
-// vectors + the 10.6 KB U table: seven workgroups per CU); wavefronts without a leaf leave at once.  A wave's vectors are
-// lane-interleaved in LDS with the stride of its live lanes (16 / 32 / 64: element i of lane l at x[i * stride + l], one bank
-// per lane, conflict-free).  refs are sorted by decreasing size, so a class is a contiguous range.
+// vectors + the 10.6 KB U table); wavefronts without a leaf leave at once.  A wave's vectors are lane-interleaved in LDS
+// with the stride of its live lanes (16 / 32 / 64: element i of lane l at x[i * stride + l], one bank per lane,
+// conflict-free).  refs are sorted by decreasing size, so a class is a contiguous range, cut into batches of `lanes` leaves.
+// OG_K1_BATCHES(c) consecutive batches per workgroup of class c: 1 everywhere.  (Measured, r2n: four batches per workgroup
+// for N <= 8 and two for N <= 24 -- table staged once, next batch's records prefetched -- made the kernel 25 % slower, 250 us
+// against 201: fewer, longer workgroups balance worse over the CUs than the table staging costs.)
 struct OgPvqClasses { uint32_t cnt[4], wg0[4]; };      // leaves per class (largest first); first workgroup of each class
+#define OG_K1_BATCHES(c) 1u
 __global__ __launch_bounds__(256) void og_pvq_all_kernel(const OgLeafRef *__restrict__ refs, OgPvqClasses cl,
-                                                         const OgCeltHdr *__restrict__ hdr, const OgCeltLeaf *__restrict__ leaves,
+                                                         const OgCeltLeaf *__restrict__ leaves,
                                                          uint32_t nframes, const OgCeltTables *__restrict__ T, void *work,
                                                          int16_t *dbg_pulses, uint64_t *dbg_cycles)
 {
@@ -35,21 +39,31 @@ __global__ __launch_bounds__(256) void og_pvq_all_kernel(const OgLeafRef *__rest
     const int c = b >= cl.wg0[3] ? 3 : b >= cl.wg0[2] ? 2 : b >= cl.wg0[1] ? 1 : 0;
     const uint32_t lanes = c == 0 ? 16u : c == 1 ? 32u : c == 2 ? 128u : 256u;
     if (tid >= ((lanes + 63u) & ~63u)) return;          // whole wavefronts with nothing to do (no barrier after this point for them)
+    uint32_t base = 0;
+    for (int k = 0; k < c; k++) base += cl.cnt[k];
+    const uint32_t nbat = OG_K1_BATCHES(c), cnt = cl.cnt[c];
+    uint32_t g = (b - cl.wg0[c]) * nbat * lanes + tid;  // this lane's leaf of the workgroup's first batch
+    const bool live = tid < lanes;
+    OgLeafRef ref = {0, 0};
+    OgCeltLeaf lf = {};
+    if (live && g < cnt) { ref = refs[base + g]; lf = leaves[ref.leaf]; }
     const uint32_t nw = (lanes + 63u) >> 6;             // wavefronts that stay: they share the table
     for (uint32_t p = tid; p < 15 * OG_U2_STRIDE; p += 64 * nw) U2[p] = T->pvq_u2[p];
     __syncthreads();                                    // wavefronts that have ended no longer take part in the barrier
-    uint32_t base = 0;
-    for (int k = 0; k < c; k++) base += cl.cnt[k];
-    const uint32_t g = (b - cl.wg0[c]) * lanes + tid;
-    if (tid >= lanes || g >= cl.cnt[c]) return;
+    if (!live) return;
     const int nmax = c == 0 ? 176 : c == 1 ? 64 : c == 2 ? 24 : 8;
     uint64_t *stamps = dbg_cycles && tid == 0 && (b - cl.wg0[c]) < 4096 ? dbg_cycles + (size_t)nframes * 64 + ((size_t)nmax * 4096 + (b - cl.wg0[c])) * 4 : nullptr;
-    const OgLeafRef ref = refs[base + g];
-    switch (c) {
-    case 0: og_pvq_lane(ref, hdr, leaves, nframes, work, U2, x + tid, 16, dbg_pulses, stamps); break;
-    case 1: og_pvq_lane(ref, hdr, leaves, nframes, work, U2, x + tid, 32, dbg_pulses, stamps); break;
-    case 2: og_pvq_lane(ref, hdr, leaves, nframes, work, U2, x + (tid >> 6) * (24 * 64) + (tid & 63), 64, dbg_pulses, stamps); break;
-    default: og_pvq_lane(ref, hdr, leaves, nframes, work, U2, x + (tid >> 6) * (8 * 64) + (tid & 63), 64, dbg_pulses, stamps); break;
+    for (uint32_t r = 0; r < nbat && g < cnt; r++, g += lanes) {       // (no barrier inside: the lanes are independent)
+        const OgLeafRef cur = ref;
+        const OgCeltLeaf clf = lf;
+        if (r + 1 < nbat && g + lanes < cnt) { ref = refs[base + g + lanes]; lf = leaves[ref.leaf]; }     // in flight during this batch
+        switch (c) {
+        case 0: og_pvq_lane(cur, clf, work, U2, x + tid, 16, dbg_pulses, stamps); break;
+        case 1: og_pvq_lane(cur, clf, work, U2, x + tid, 32, dbg_pulses, stamps); break;
+        case 2: og_pvq_lane(cur, clf, work, U2, x + (tid >> 6) * (24 * 64) + (tid & 63), 64, dbg_pulses, stamps); break;
+        default: og_pvq_lane(cur, clf, work, U2, x + (tid >> 6) * (8 * 64) + (tid & 63), 64, dbg_pulses, stamps); break;
+        }
+        stamps = nullptr;
     }
 }
 
@@ -216,8 +230,15 @@ int opusgpu_launch_celt_pvq(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, uint
         OgPvqClasses cl;
         static const uint32_t lanes[4] = {16, 32, 128, 256};
         uint32_t wg = 0;
-        for (int c = 0; c < 4; c++) { cl.cnt[c] = class_counts[c]; cl.wg0[c] = wg; wg += (class_counts[c] + lanes[c] - 1) / lanes[c]; }
-        hipLaunchKernelGGL(og_pvq_all_kernel, dim3(wg), dim3(256), 0, st, refs, cl, hdr, leaves, nframes, T, work, dbg.pulses, dbg.cycles);
+        // profiling aid: OPUSGPU_K1_CLASSES = bit mask of the size classes to run (the output is then incomplete)
+        static const int only = getenv("OPUSGPU_K1_CLASSES") ? atoi(getenv("OPUSGPU_K1_CLASSES")) : 15;
+        for (int c = 0; c < 4; c++) {
+            cl.cnt[c] = class_counts[c];
+            cl.wg0[c] = wg;
+            const uint32_t per_wg = lanes[c] * OG_K1_BATCHES(c);
+            if ((only >> c) & 1) wg += (class_counts[c] + per_wg - 1) / per_wg;
+        }
+        if (wg) hipLaunchKernelGGL(og_pvq_all_kernel, dim3(wg), dim3(256), 0, st, refs, cl, leaves, nframes, T, work, dbg.pulses, dbg.cycles);
     }
     hipLaunchKernelGGL(og_plan_kernel, dim3((nframes + OG_PLAN_FPW - 1) / OG_PLAN_FPW), dim3(64), 0, st, hdr, leaves, nframes, T, work);
     OG_HIP(hipGetLastError());

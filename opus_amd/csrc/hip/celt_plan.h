@@ -70,7 +70,7 @@ struct OgXform {
 OG_DEV void og_make_xform(int n, int B, int tf_change, OgXform *t, int *recombine_out, int *time_divide_out, int *B0_out)
 {
     const int long_blocks = B == 1;
-    int n_b = n / B, recombine = tf_change > 0 ? tf_change : 0, time_divide = 0;
+    int n_b = n >> (31 - __builtin_clz((unsigned)B)), recombine = tf_change > 0 ? tf_change : 0, time_divide = 0;
     B >>= recombine;
     n_b <<= recombine;
     const int b1 = 31 - __builtin_clz((unsigned)B);

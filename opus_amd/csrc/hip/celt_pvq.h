@@ -27,11 +27,11 @@ OG_DEV uint32_t og_u2(const uint32_t *U2, int n, int k)
 //   phase 0 (new coefficient): U(n, k) and U(n, k+1) -> sign, and a zero coefficient is finished in this iteration;
 //   phase 1 (search):          U(n, kk) and U(n, kk-1) -> two candidates per iteration.
 // Writes the pulse vector as floats to x[0], x[xs], ...; returns ||y||^2; *cm_out = collapse mask over `blocks` blocks.
-OG_DEV uint32_t og_cwrsi(const uint32_t *U2, int n, int k, uint32_t i, float *x, int xs, int blocks, int *cm_out, int16_t *dbg)
+OG_DEV uint32_t og_cwrsi(const uint32_t *U2, int n, int k, uint32_t i, float *x, int xs, int logb, int *cm_out, int16_t *dbg)
 {
     uint32_t yy = 0;
     int cm = 0, pos = 0, s = 0, k0 = k, kk = k, phase = 0;
-    const int nb = n / blocks;
+    const int nb = n >> logb, blocks = 1 << logb;
     int bl = nb, bi = 0;
 #define OG_PUT(v)                                                                                                   \
     {                                                                                                               \
@@ -137,27 +137,50 @@ OG_DEV void og_rot_bwd(float *x, int xs, int i, int stride, int cnt, float c, fl
 
 OG_DEV void og_exp_rotation1(float *x, int xs, int len, int stride, float c, float s)
 {
-    for (int r = 0; r < stride && r < len - stride; r++)                 // forward: i = 0 .. len-stride-1
-        og_rot_fwd(x, xs, r, stride, (len - stride - r + stride - 1) / stride, c, s);
-    const int top = len - 2 * stride - 1;                                // backward: i = top .. 0
-    for (int r = 0; r < stride && r <= top; r++) {
-        const int i = top - ((top - r) % stride);                        // largest i <= top with i = r (mod stride)
-        og_rot_bwd(x, xs, i, stride, (i - r) / stride + 1, c, s);
+    // class r of the forward pass (i = 0 .. len-stride-1) has q + (r < rem) steps, len - stride = q stride + rem; the backward
+    // pass (i = len-2 stride-1 .. 0) likewise with len - 2 stride: one division per pass, none per class
+    const int nf = len - stride;
+    if (nf > 0) {
+        const int q = stride == 1 ? nf : og_idiv_small(nf, stride), rem = nf - q * stride;
+        for (int r = 0; r < stride && r < nf; r++) og_rot_fwd(x, xs, r, stride, q + (r < rem), c, s);
+    }
+    const int nbk = len - 2 * stride;
+    if (nbk > 0) {
+        const int q = stride == 1 ? nbk : og_idiv_small(nbk, stride), rem = nbk - q * stride;
+        for (int r = 0; r < stride && r < nbk; r++) {
+            const int cnt = q + (r < rem);
+            og_rot_bwd(x, xs, r + (cnt - 1) * stride, stride, cnt, c, s);     // from the largest i < len - 2 stride with i = r (mod stride)
+        }
     }
 }
 
-OG_DEV void og_exp_rotation(float *x, int xs, int len, int stride, int k, int spread)   // celt/decoder.rs:694-721
+// cos(pi/2 t), 0 <= t <= 1: the Taylor series to x^14 (truncation < 1e-8 at x = pi/2), Horner in x^2
+OG_DEV float og_cos_halfpi(float t)
+{
+    const float x = 1.57079632679489661923f * t, z = x * x;
+    float p = -1.f / 87178291200.f;
+    p = fmaf(p, z, 1.f / 479001600.f);
+    p = fmaf(p, z, -1.f / 3628800.f);
+    p = fmaf(p, z, 1.f / 40320.f);
+    p = fmaf(p, z, -1.f / 720.f);
+    p = fmaf(p, z, 1.f / 24.f);
+    p = fmaf(p, z, -0.5f);
+    return fmaf(p, z, 1.f);
+}
+
+OG_DEV void og_exp_rotation(float *x, int xs, int len, int logb, int k, int spread)   // celt/decoder.rs:694-721, stride = 2^logb blocks
 {
     if (2 * k >= len || spread == 0) return;
-    const float gain = (float)len / (float)(len + (20 - 5 * spread) * k);
+    const int stride = 1 << logb;
+    const float gain = (float)len * og_frcp((float)(len + (20 - 5 * spread) * k));
     const float theta = 0.5f * gain * gain;
-    const float c = cosf(0.5f * 3.14159265358979323846f * theta), s = cosf(0.5f * 3.14159265358979323846f * (1.f - theta));
+    const float c = og_cos_halfpi(theta), s = og_cos_halfpi(1.f - theta);
     int stride2 = 0;
     if (len >= 8 * stride) {
         stride2 = 1;
         while ((stride2 * stride2 + stride2) * stride + (stride >> 2) < len) stride2++;
     }
-    len /= stride;
+    len >>= logb;
     for (int i = 0; i < stride; i++) {
         if (stride2) og_exp_rotation1(x + i * len * xs, xs, len, stride2, s, c);
         og_exp_rotation1(x + i * len * xs, xs, len, 1, c, s);
@@ -175,36 +198,37 @@ OG_DEV uint32_t og_pvq_leaf(const uint32_t *U2, const OgCeltLeaf &lf, int spread
                             uint64_t *stamps /* profiling aid, may be null */)
 {
     OG_PVQ_STAMP(0)
-    const int Bl = 1 << (lf.meta & OG_L_LOGB_MASK);
+    const int logb = lf.meta & OG_L_LOGB_MASK;
     int cm;
-    const uint32_t yy = og_cwrsi(U2, lf.n, lf.k, lf.index, x, xs, Bl, &cm, dbg);
+    const uint32_t yy = og_cwrsi(U2, lf.n, lf.k, lf.index, x, xs, logb, &cm, dbg);
     OG_PVQ_STAMP(1)
-    const float g = lf.gain / sqrtf((float)yy);
+    const float g = lf.gain * og_frsq((float)yy);
     for (int i = 0; i < lf.n; i++) x[i * xs] *= g;
     OG_PVQ_STAMP(2)
-    og_exp_rotation(x, xs, lf.n, Bl, lf.k, spread);
+    og_exp_rotation(x, xs, lf.n, logb, lf.k, spread);
     return (uint32_t)cm << lf.cmshift;
 }
 
 // K1 body for one lane.  xl = this lane's vector storage (element stride xs), at least lf.n elements.
-OG_DEV void og_pvq_lane(const OgLeafRef ref, const OgCeltHdr *hdr, const OgCeltLeaf *leaves, uint32_t nframes, void *work,
+// ref.frame carries the frame's `spread` in its top bits (opusgpu_sideinfo.h); lf = leaves[ref.leaf], fetched by the caller.
+OG_DEV void og_pvq_lane(const OgLeafRef ref, const OgCeltLeaf lf, void *work,
                         const uint32_t *U2, float *xl, int xs, int16_t *dbg_pulses, uint64_t *stamps)
 {
-    const OgCeltLeaf lf = leaves[ref.leaf];
+    const uint32_t frame = ref.frame & OG_REF_FRAME_MASK;
     const int ch = (lf.meta & OG_L_CH_Y) ? 1 : 0;
     if (lf.k == 0) {                                    // a zero-pulse leaf next to PVQ leaves in its (band, buffer): K1 owns the
-        float *z = og_work_coef(work, ref.frame) + ch * 960 + lf.pos;      // zeros there (live fill leaves are rewritten by the
+        float *z = og_work_coef(work, frame) + ch * 960 + lf.pos;          // zeros there (live fill leaves are rewritten by the
         for (int i = 0; i < lf.n; i++) z[i] = 0.f;                         // frame kernel); no collapse mask
         return;
     }
-    const int spread = hdr[ref.frame].spread;
-    int16_t *dbg = dbg_pulses ? dbg_pulses + (size_t)ref.frame * 1920 + ch * 960 + lf.pos : nullptr;
+    const int spread = (int)(ref.frame >> OG_REF_SPREAD_SHIFT);
+    int16_t *dbg = dbg_pulses ? dbg_pulses + (size_t)frame * 1920 + ch * 960 + lf.pos : nullptr;
     const uint32_t cm = og_pvq_leaf(U2, lf, spread, xl, xs, dbg, stamps);
-    float *dst = og_work_coef(work, ref.frame) + ch * 960 + lf.pos;
+    float *dst = og_work_coef(work, frame) + ch * 960 + lf.pos;
     int i = 0;
     if ((lf.pos & 3) == 0)                              // 16-byte stores where the leaf's place in the row allows them
         for (; i + 4 <= lf.n; i += 4) *(OgF4s *)(dst + i) = OgF4s{xl[i * xs], xl[(i + 1) * xs], xl[(i + 2) * xs], xl[(i + 3) * xs]};
     for (; i < lf.n; i++) dst[i] = xl[i * xs];
-    OG_ATOMIC_OR(og_work_cm(work, ref.frame) + ch * 24 + lf.band, cm);
+    OG_ATOMIC_OR(og_work_cm(work, frame) + ch * 24 + lf.band, cm);
     OG_PVQ_STAMP(3)
 }

@@ -84,6 +84,13 @@ template <int MASK> OG_DEV float og_lane_xor(float v)
 #define OG_WAVE_XCH(dst, src, MEMBER, MASK) dst = og_lane_xor<MASK>(src MEMBER);
 #define OG_WAVE_GET(src, L) __builtin_amdgcn_readlane((int)(src), (L))
 #define OG_WAVE_REF(T, name) T &name
+// One-instruction approximations (1 ulp) for the CELT kernels, whose results are compared with a tolerance (the library
+// forms expand to a dozen or more instructions each: range checks, Newton steps, denormal scaling).  Arguments are normal
+// numbers wherever these are used.  The SILK kernels, which are held to bit-exactness, do not use them.
+OG_DEV float og_frsq(float x) { return __builtin_amdgcn_rsqf(x); }
+OG_DEV float og_frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+OG_DEV float og_fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+OG_DEV float og_fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
 #else
 #include <math.h>
 #define OG_DEV static inline
@@ -119,4 +126,11 @@ template <int MASK> OG_DEV float og_lane_xor(float v)
 #define OG_WAVE_XCH(dst, src, MEMBER, MASK) { for (int l_ = 0; l_ < 64; l_++) dst[l_] = src[l_ ^ (MASK)] MEMBER; }
 #define OG_WAVE_GET(src, L) ((int)src[L])
 #define OG_WAVE_REF(T, name) T (&name)[64]
+OG_DEV float og_frsq(float x) { return 1.f / sqrtf(x); }
+OG_DEV float og_frcp(float x) { return 1.f / x; }
+OG_DEV float og_fsqrt(float x) { return sqrtf(x); }
+OG_DEV float og_fexp2(float x) { return exp2f(x); }
 #endif
+// floor(a / d) for small non-negative integers (a < 4096, 0 < d <= 1024) through the float reciprocal: (a + 1/2) / d is at
+// least 1 / (2d) away from an integer, far more than the product's rounding error
+OG_DEV int og_idiv_small(int a, int d) { return (int)(((float)a + 0.5f) * og_frcp((float)d)); }

@@ -13,7 +13,7 @@ uint32_t opusgpu_sort_pvq_leaves(const OgCeltHdr *hdr, uint32_t nframes, const O
     // counting sort by (dimension N, pulses K), largest first: a wavefront of the K1 kernel then holds leaves of (nearly)
     // one size and pulse count, so its lanes run the same loop trip counts (cwrsi walks N positions and searches ~K/2
     // table entries; the rotation walks N).  Key = N * 64 + min(K, 63).
-    if (!hdr || !leaves || !out) return 0;
+    if (!hdr || !leaves || !out || nframes > OG_REF_FRAME_MASK) return 0;
     enum { KQ = 64, NKEYS = 178 * KQ };
     std::vector<uint32_t> count(NKEYS + 1, 0);
     auto key_of = [](const OgCeltLeaf &lf) { return (uint32_t)lf.n * KQ + (lf.k < KQ ? lf.k : KQ - 1); };
@@ -42,7 +42,7 @@ uint32_t opusgpu_sort_pvq_leaves(const OgCeltHdr *hdr, uint32_t nframes, const O
         for (uint32_t l = 0; l < hdr[f].nleaves; l++) {
             const uint32_t idx = hdr[f].leaf_begin + l;
             const OgCeltLeaf &lf = leaves[idx];
-            if (wanted(hdr[f], lf)) { OgLeafRef &r = out[count[key_of(lf)]++]; r.leaf = idx; r.frame = f; }
+            if (wanted(hdr[f], lf)) { OgLeafRef &r = out[count[key_of(lf)]++]; r.leaf = idx; r.frame = f | (uint32_t)(hdr[f].spread & 3) << OG_REF_SPREAD_SHIFT; }
         }
     return total;
 }

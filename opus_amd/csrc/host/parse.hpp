@@ -55,7 +55,8 @@ struct SilkHostState {
     void flush();
 };
 // Parses the SILK part of one Opus frame (1-3 internal 20 ms frames); appends one OgSilkFrame each.
-// Returns number of internal frames, or <0 (OPUSGPU_UNSUPPORTED for LBRR, silk/decoder.rs:2070).
+// Returns number of internal frames, or <0.  LBRR frames (where the reference returns Unsupported, silk/decoder.rs:2070) are
+// parsed and dropped.
 int silk_parse(SilkHostState &st, RangeDec &rd, int bandwidth, int duration_ms, int stereo_pkt,
                std::vector<OgSilkFrame> &out);
 

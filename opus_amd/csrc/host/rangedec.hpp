@@ -68,9 +68,9 @@ public:
         normalize();
         return ret;
     }
-    int icdf(int pool_off)                                               // entropy.rs:357-372
+    int icdf(int pool_off) { return icdf_table(RFC_ICDF_POOL + pool_off); }   // entropy.rs:357-372
+    int icdf_table(const uint16_t *t)                                    // the same on a table outside the pool: {total, count, cumulative bounds ...}
     {
-        const uint16_t *t = RFC_ICDF_POOL + pool_off;
         uint32_t ft = t[0];
         uint32_t fs = decode(ft);
         int k = 0;

@@ -380,11 +380,38 @@ int silk_parse(SilkHostState &st, RangeDec &rd, int bw, int duration_ms, int ste
     const int subframes = duration_ms == 10 ? 2 : 4;
     const int sf_size = bw == 0 ? 40 : bw == 1 ? 60 : 80;
     bool mid_vad[3] = {false, false, false}, side_vad[3] = {false, false, false};
+    bool lbrr[2][3] = {{false, false, false}, {false, false, false}}, any_lbrr[2] = {false, false};
     for (int i = 0; i < frames; i++) mid_vad[i] = rd.bit_logp(1);            // silk/decoder.rs:2066-2081
-    if (rd.bit_logp(1)) return OPUSGPU_UNSUPPORTED;                          // LBRR: Error::Unsupported (:2070-2072)
+    any_lbrr[0] = rd.bit_logp(1);                                            // the reference stops here: Error::Unsupported (:2070-2072)
     if (stereo) {
         for (int i = 0; i < frames; i++) side_vad[i] = rd.bit_logp(1);
-        if (rd.bit_logp(1)) return OPUSGPU_UNSUPPORTED;
+        any_lbrr[1] = rd.bit_logp(1);
+    }
+    // RFC 6716 4.2.4: per-frame LBRR flags (Table 4: the symbol is the bit mask of the frames, frame 0 lowest, never 0), then
+    // 4.2.5-4.2.7 the LBRR (in-band FEC) frames, in front of the regular ones and interleaved mid / side per 20 ms.  An LBRR
+    // frame is coded like a regular frame with the VAD flag set, independently unless its channel had one 20 ms earlier.  A
+    // decoder that is not recovering a loss reads past them: they are parsed into scratch state and records and dropped
+    // (with the stereo weights they carry), so nothing of them reaches the device.
+    static const uint16_t kLbrr40[] = {256, 4, 0, 53, 106, 256}, kLbrr60[] = {256, 8, 0, 41, 61, 90, 131, 146, 174, 256};
+    for (int ch = 0; ch < (stereo ? 2 : 1); ch++) {
+        if (!any_lbrr[ch]) continue;
+        const int sym = frames == 1 ? 1 : rd.icdf_table(frames == 2 ? kLbrr40 : kLbrr60);
+        for (int i = 0; i < frames; i++) lbrr[ch][i] = (sym >> i) & 1;
+    }
+    if (any_lbrr[0] || any_lbrr[1]) {
+        SilkChanHost scratch[2];
+        OgSilkChan dropped;
+        for (int i = 0; i < frames; i++)
+            for (int ch = 0; ch < (stereo ? 2 : 1); ch++) {
+                if (!lbrr[ch][i]) continue;
+                if (stereo && ch == 0) {                                     // weights, and the mid-only flag unless the side has an LBRR frame too
+                    rd.icdf(ICDF_SILK_STEREO_STAGE1);
+                    rd.icdf(ICDF_SILK_STEREO_STAGE2); rd.icdf(ICDF_SILK_STEREO_STAGE3);
+                    rd.icdf(ICDF_SILK_STEREO_STAGE2); rd.icdf(ICDF_SILK_STEREO_STAGE3);
+                    if (!lbrr[1][i]) rd.icdf(ICDF_SILK_MID_ONLY);
+                }
+                ChanParser{scratch[ch], rd, dropped}.frame(bw, subframes, sf_size, true, i == 0 || !lbrr[ch][i - 1]);
+            }
     }
     for (int i = 0; i < frames; i++) {
         out.emplace_back();

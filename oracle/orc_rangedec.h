@@ -27,6 +27,18 @@ typedef struct {
     int size_bits;
 } OrcRd;
 
+/* Optional symbol trace (tests/test_lbrr.py re-encodes decoded symbols into new packets): when orc_trace_buf is set, every
+ * decoded symbol is logged as its (low, high, total) triple; (0, 0, tag) entries are markers. */
+extern uint32_t *orc_trace_buf;
+extern int orc_trace_cap, orc_trace_n;
+static inline void orc_trace3(uint32_t a, uint32_t b, uint32_t c)
+{
+    if (orc_trace_buf && orc_trace_n < orc_trace_cap) {
+        uint32_t *e = orc_trace_buf + 3 * orc_trace_n++;
+        e[0] = a; e[1] = b; e[2] = c;
+    }
+}
+
 static inline int orc_ilog(uint32_t v) { return v ? 32 - __builtin_clz(v) : 0; }  /* maths.rs:8-18 */
 
 static inline uint32_t orc_fwd_byte(OrcRd *rd)   /* entropy.rs:38-56 (8-bit get at any bit offset) */
@@ -78,6 +90,7 @@ static inline int orc_rd_avail(const OrcRd *rd) { return rd->size_bits - orc_rd_
 
 static inline void orc_rd_update(OrcRd *rd, uint32_t scale, uint32_t low, uint32_t high, uint32_t total)
 {   /* entropy.rs:318-330 */
+    orc_trace3(low, high, total);
     uint32_t s = scale * (total - high);
     rd->value -= s;
     rd->range = low ? scale * (high - low) : rd->range - s;
@@ -97,14 +110,17 @@ static inline int orc_rd_logp(OrcRd *rd, int logp)   /* entropy.rs:339-355 */
     int k;
     if (scale > rd->value) { rd->range = scale; k = 1; }
     else { rd->range -= scale; rd->value -= scale; k = 0; }
+    orc_trace3(k ? (1u << logp) - 1 : 0, k ? 1u << logp : (1u << logp) - 1, 1u << logp);
     orc_rd_normalize(rd);
     return k;
 }
 
 /* ICDF by pool offset (see rfc6716_tables.h). entropy.rs:357-372 */
-static inline int orc_rd_icdf(OrcRd *rd, int off)
+static inline int orc_rd_icdf_tab(OrcRd *rd, const uint16_t *t);
+static inline int orc_rd_icdf(OrcRd *rd, int off) { return orc_rd_icdf_tab(rd, RFC_ICDF_POOL + off); }
+/* the same on a table outside the pool: {total, count, cumulative upper bounds ...} */
+static inline int orc_rd_icdf_tab(OrcRd *rd, const uint16_t *t)
 {
-    const uint16_t *t = RFC_ICDF_POOL + off;
     uint32_t total = t[0], scale;
     uint32_t sym = orc_rd_symbol(rd, total, &scale);
     int k = 0;

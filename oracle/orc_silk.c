@@ -3,7 +3,9 @@
  * CPU restatement (plain C, f32, fixed operation order; build with -ffp-contract=off) of the reference's
  * SILK decoder, lu-zero/opus src/silk/decoder.rs.  Pinned bit-exactly by the reference's goldens:
  * src/silk/tests.rs:22-514 (480 samples), :516-845 (160+160), :847-870 (lsf_to_lpc).
- * Like the reference (silk/decoder.rs:2070-2072) LBRR frames are reported as unsupported.
+ * Where the reference stops with Error::Unsupported (silk/decoder.rs:2070-2072, LBRR frames) this follows RFC 6716 4.2.4-4.2.7.1:
+ * the per-frame LBRR flags are read and the LBRR (in-band FEC) frames in front of the regular frames are parsed and
+ * discarded -- what a decoder that is not recovering a loss does with them.
  */
 #include <math.h>
 #include <stdlib.h>
@@ -27,6 +29,7 @@ struct OrcSilk {
     int stereo_out;
     float weight0, weight1, prev0, prev1;     /* silk/decoder.rs:23-26 */
     SilkFrame mid, side;
+    SilkFrame lbrr[2];                        /* scratch channels the LBRR frames of a packet are parsed into */
 };
 
 static inline int32_t mul_shift(int32_t a, int32_t b, int bits) { return (int32_t)(((int64_t)a * b) >> bits); } /* :105 */
@@ -370,6 +373,7 @@ static inline float clampf(float v, float lo, float hi) { v = v > lo ? v : lo; r
 
 static void frame_parse(SilkFrame *f, OrcRd *rd, int bw, int subframes, int sf_size, int vad, int first)
 {   /* silk/decoder.rs:1664-1903 */
+    orc_trace3(0, 0, 1);                      /* marker: a SILK frame starts */
     int f_size = sf_size * subframes;
     if (vad) { int t = orc_rd_icdf(rd, ICDF_SILK_FRAME_TYPE_ACTIVE); f->active = 1; f->voiced = t >> 1; f->high = t & 1; }
     else { f->active = 0; f->voiced = 0; f->high = orc_rd_icdf(rd, ICDF_SILK_FRAME_TYPE_INACTIVE) != 0; }
@@ -430,6 +434,7 @@ static void frame_parse(SilkFrame *f, OrcRd *rd, int bw, int subframes, int sf_s
             out[j] = clampf(sum, -1.f, 1.f);
         }
     }
+    orc_trace3(0, 0, 2);                      /* marker: the frame's last symbol has been read */
     f->prev_voiced = f->voiced;
     for (int i = 0; i < LPC_HISTORY; i++) {
         f->lpc_history[i] = f->lpc_history[i + f_size];
@@ -438,6 +443,11 @@ static void frame_parse(SilkFrame *f, OrcRd *rd, int bw, int subframes, int sf_s
     f->coded = 1;
 }
 
+uint32_t *orc_trace_buf = 0;                 /* orc_rangedec.h: optional symbol trace */
+int orc_trace_cap = 0, orc_trace_n = 0;
+void orc_trace_set(uint32_t *buf, int cap) { orc_trace_buf = buf; orc_trace_cap = cap; orc_trace_n = 0; }
+int orc_trace_count(void) { return orc_trace_n; }
+long orc_silk_lbrr_packets = 0;              /* test statistics: SILK packets that carried LBRR frames */
 OrcSilk *orc_silk_create(int stereo_out) { OrcSilk *s = (OrcSilk *)calloc(1, sizeof *s); s->stereo_out = stereo_out; return s; }
 void orc_silk_destroy(OrcSilk *s) { free(s); }
 void orc_silk_flush(OrcSilk *s)   /* silk/decoder.rs:1934-1940 */
@@ -486,11 +496,36 @@ int orc_silk_decode(OrcSilk *s, OrcRd *rd, int bw, int duration_ms, int stereo, 
     int subframes = duration_ms == 10 ? 2 : 4;
     int sf_size = bw == 0 ? 40 : bw == 1 ? 60 : 80, f_size = sf_size * subframes;
     int mid_vad[3] = {0, 0, 0}, side_vad[3] = {0, 0, 0};
+    int lbrr[2][3] = {{0, 0, 0}, {0, 0, 0}}, any_lbrr[2] = {0, 0};
     for (int i = 0; i < frames; i++) mid_vad[i] = orc_rd_logp(rd, 1);
-    if (orc_rd_logp(rd, 1)) return -2;                       /* LBRR unsupported, :2070-2072 */
+    any_lbrr[0] = orc_rd_logp(rd, 1);                       /* the reference stops here with Unsupported, :2070-2072 */
     if (stereo) {
         for (int i = 0; i < frames; i++) side_vad[i] = orc_rd_logp(rd, 1);
-        if (orc_rd_logp(rd, 1)) return -2;
+        any_lbrr[1] = orc_rd_logp(rd, 1);
+    }
+    /* RFC 6716 4.2.4: per-frame LBRR flags (Table 4; symbol = bit mask of the frames, frame 0 in the lowest bit, never 0) */
+    static const uint16_t LBRR40[] = {256, 4, 0, 53, 106, 256}, LBRR60[] = {256, 8, 0, 41, 61, 90, 131, 146, 174, 256};
+    for (int ch = 0; ch < 1 + (stereo != 0); ch++) {
+        if (!any_lbrr[ch]) continue;
+        int sym = frames == 1 ? 1 : orc_rd_icdf_tab(rd, frames == 2 ? LBRR40 : LBRR60);
+        for (int i = 0; i < frames; i++) lbrr[ch][i] = (sym >> i) & 1;
+    }
+    /* RFC 6716 4.2.5-4.2.7: the LBRR frames come first, interleaved mid / side per 20 ms frame.  Each is coded like a regular
+       frame with the VAD flag set; it is coded independently unless the same channel had an LBRR frame in the previous 20 ms.
+       They are parsed into scratch channels and dropped; the stereo weights they carry are dropped too. */
+    if (any_lbrr[0] || any_lbrr[1]) {
+        orc_silk_lbrr_packets++;
+        memset(s->lbrr, 0, sizeof s->lbrr);
+        for (int i = 0; i < frames; i++)
+            for (int ch = 0; ch < 1 + (stereo != 0); ch++) {
+                if (!lbrr[ch][i]) continue;
+                if (stereo && ch == 0) {
+                    float w0 = s->weight0, w1 = s->weight1;
+                    (void)parse_stereo_weight(s, rd, lbrr[1][i]);      /* the mid-only flag follows unless the side has an LBRR frame */
+                    s->weight0 = w0; s->weight1 = w1;
+                }
+                frame_parse(&s->lbrr[ch], rd, bw, subframes, sf_size, 1, i == 0 || !lbrr[ch][i - 1]);
+            }
     }
     for (int i = 0; i < frames; i++) {
         int first = i == 0;

@@ -27,7 +27,7 @@ extern "C" int emu_launch_celt(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, u
         const uint32_t nref = opusgpu_sort_pvq_leaves(hdr, nframes, leaves, refs.data(), total + 1, classes);
         for (uint32_t r = 0; r < nref; r++) {           // order is irrelevant to the result
             float x[176];
-            og_pvq_lane(refs[r], hdr, leaves, nframes, work.data(), T.pvq_u2, x, 1, dbg ? dbg->pulses : nullptr, nullptr);
+            og_pvq_lane(refs[r], leaves[refs[r].leaf], work.data(), T.pvq_u2, x, 1, dbg ? dbg->pulses : nullptr, nullptr);
         }
     }
     for (uint32_t f = 0; f < nframes; f++) {
@@ -92,7 +92,9 @@ extern "C" uint32_t emu_cwrsi(int n, int k, uint32_t i, int blocks, int32_t *y, 
     float x[176];
     int16_t p[176];
     int m = 0;
-    const uint32_t yy = og_cwrsi(T.pvq_u2, n, k, i, x, 1, blocks, &m, p);
+    int logb = 0;
+    while ((1 << logb) < blocks) logb++;                // blocks is a power of two
+    const uint32_t yy = og_cwrsi(T.pvq_u2, n, k, i, x, 1, logb, &m, p);
     for (int j = 0; j < n; j++) y[j] = p[j];
     *cm = m;
     return yy;

@@ -97,17 +97,13 @@ def test_emu_hybrid_and_mode_switching(emu, vid, n):
         check_pcm(ref.decode(p), d.decode(p), f"vector {vid} packet {i}")
 
 
-def test_lbrr_is_unsupported_like_the_reference(emu):
-    """silk/decoder.rs:2070-2072: an LBRR flag is Error::Unsupported; the batch keeps going"""
-    # SILK NB 20 ms mono, first payload byte 0x40.. : VAD bit then LBRR bit set -> find one by brute force
+def test_lbrr_packets_decode(emu):
+    """silk/decoder.rs:2070-2072 stops at an LBRR flag with Error::Unsupported; here the LBRR frames are read past (RFC 6716
+    4.2.4-4.2.7, tests/test_lbrr.py): a packet whose LBRR flag is set decodes, and the same in the oracle"""
     hp = HostParser(2)
-    for b0 in range(256):
-        n, *_ = hp.parse(bytes([0x08, b0, 0, 0, 0, 0, 0, 0]))
-        if n == A.UNSUPPORTED:
-            break
-    else:
-        pytest.fail("no LBRR packet found")
-    L = orc.lib()
     d = orc.Decoder(2)
-    with pytest.raises(ValueError):
-        d.decode(bytes([0x08, b0, 0, 0, 0, 0, 0, 0]))
+    for b0 in range(256):                               # SILK NB 20 ms mono; find first bytes with the VAD and LBRR bits set
+        p = bytes([0x08, b0, 0x55, 0xAA, 0x0F, 0xF0, 0x33, 0xCC])
+        n, *_ = hp.parse(p)
+        assert n == 1
+        assert d.decode(p).shape == (960, 2)

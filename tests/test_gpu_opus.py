@@ -139,3 +139,27 @@ def test_silk_wb_mono_batch_c3_shape():
         for s in sample:
             out, r = dec.read(s), refs[s].decode(pk[s])
             assert np.array_equal(out, r), f"stream {s} step {t}"
+
+
+@pytest.mark.parametrize("stereo", [0, 1])
+def test_random_silk_payloads_with_lbrr_on_gpu(stereo):
+    """any bytes are a valid SILK packet and about half carry LBRR (in-band FEC) flags, where the reference returns
+    Unsupported (silk/decoder.rs:2070-2072): the LBRR frames are read past (RFC 6716 4.2.4-4.2.7; tests/test_lbrr.py pins
+    the layout with re-encoded packets).  One-stream C ABI -> HIP kernels, bit-exact against the oracle, all 12 SILK configs."""
+    L = orc.lib()
+    seen = C.c_long.in_dll(L, "orc_silk_lbrr_packets")
+    before = seen.value
+    rng = np.random.default_rng(77 + stereo)
+    extra, _ = orc.load_vectors(ids=[2], max_packets=1)[2]
+    d = Decoder(0)
+    d.set_extradata(extra)
+    d.configure()
+    ref = orc.Decoder(2)
+    for i in range(96):
+        config = i % 12
+        n = int(rng.integers(20, 120)) * (1, 1, 2, 3)[config & 3]
+        p = bytes([config << 3 | stereo << 2]) + rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        d.send_packet(p)
+        out, r = d.receive_frame(), ref.decode(p)
+        assert np.array_equal(out, r), f"packet {i} (config {config}): max diff {np.abs(out - r).max()}"
+    assert seen.value - before >= 20
