@@ -147,7 +147,9 @@ typedef struct {               /* one Opus frame of a packet */
     uint8_t stereo;            /* packet stereo flag */
     uint8_t nsilk;             /* SILK frames emitted for this Opus frame (0-3) */
     uint16_t frame_size;       /* samples per channel @ 48 kHz */
-    uint16_t has_celt;
+    uint16_t has_celt;         /* CELT records of this frame (0-3), consecutive from celt_index in decode order: a redundant
+                                  frame in front / an overlap flush, the frame's own CELT part, a redundant frame behind
+                                  (OgCeltHdr.spread holds each one's launch round and cross-fade) */
     uint32_t celt_index;       /* index into the celt[] output */
     uint32_t silk_index;       /* index of the first SILK frame in silk[] */
     uint32_t final_range;      /* range decoder state after the frame (celt/decoder.rs:2322) */

@@ -71,6 +71,22 @@ typedef struct {             /* one decode_band_no_split / decode_band_1 call, 1
     uint16_t pos;            /* first coefficient of the leaf inside its channel's 960-bin frame: (ebands[band] << LM) + off */
 } OgCeltLeaf;
 
+/* RFC 6716 4.5.1 redundant frames (the reference parses and drops them, decoder.rs:84-115): a 5 ms CELT frame from band 0
+ * that bridges a CELT <-> SILK / hybrid switch.  w = the CELT window (120 samples), i = sample inside the record:
+ *   OG_X_RED_HEAD        the redundant frame of a CELT -> SILK switch, decoded first, from the running CELT state, at the start
+ *                        of its Opus frame: pcm = v for i < 120, (1 - w^2) v + w^2 pcm for 120 <= i < 240 (pcm: the SILK part)
+ *   OG_X_AFTER_RED_HEAD  the hybrid frame's own CELT part behind such a frame: nothing for i < 120, pcm += w^2 v for
+ *                        120 <= i < 240, pcm += v after that
+ *   OG_X_RED_TAIL        the redundant frame of a SILK -> CELT switch, decoded last, from a reset CELT state, placed so that
+ *                        it ends with its Opus frame: nothing for i < 120, pcm = w^2 v + (1 - w^2) pcm for 120 <= i < 240 */
+enum { OG_X_NONE = 0, OG_X_RED_HEAD = 1, OG_X_AFTER_RED_HEAD = 2, OG_X_RED_TAIL = 3 };
+#define OG_SPREAD_MASK 3
+#define OG_X_SHIFT 4
+#define OG_ROUND_SHIFT 6
+/* launch rounds of one Opus frame: its SILK frames (up to three 20 ms pieces) take rounds 0-2, each round's CELT records run
+ * after its SILK frames: 0 = redundant frame in front / overlap flush, 2 = the frame's own CELT part, 3 = redundant frame behind */
+enum { OG_ROUND_HEAD = 0, OG_ROUND_MAIN = 2, OG_ROUND_TAIL = 3, OG_ROUNDS_PER_FRAME = 4 };
+
 typedef struct {             /* one PVQ leaf (K > 0) to expand: the unit of work of the K1 kernel */
     uint32_t leaf;           /* index into the launch's leaf array */
     uint32_t frame;          /* bits 0..29: index into the launch's OgCeltHdr array; bits 30..31: that frame's `spread`
@@ -81,14 +97,17 @@ typedef struct {             /* one PVQ leaf (K > 0) to expand: the unit of work
 
 typedef struct {             /* one CELT frame; fixed stride */
     uint32_t stream;         /* state slot / PCM row of the stream this frame belongs to */
-    uint32_t pcm_off;        /* first output sample (per channel) inside the stream's PCM row */
+    uint32_t pcm_off;        /* first output sample (per channel) inside the stream's PCM row (the host parser leaves the offset
+                                inside the record's Opus frame here: 0 but for OG_X_RED_TAIL; the caller adds the frame's place) */
     uint32_t leaf_begin;     /* first leaf in the batch leaf array */
     uint32_t seed;           /* LCG seed at frame entry = previous frame's final range (:2322) */
     uint16_t nleaves;
     uint8_t lm;              /* celt/decoder.rs:2233 */
     uint8_t flags;
     uint8_t start, end;      /* band range (decoder.rs:119-120) */
-    uint8_t spread;          /* celt/decoder.rs:1043 (decoded, used as RFC 6716 requires) */
+    uint8_t spread;          /* bits 0-1: celt/decoder.rs:1043 (decoded, used as RFC 6716 requires).  Bits 4-5: OG_X_* cross-fade of
+                                this record's PCM store (redundant frames, RFC 6716 4.5.1).  Bits 6-7: which of its Opus frame's
+                                four launch rounds the record belongs to (OG_ROUND_*), for a host that batches streams. */
     uint8_t intensity;       /* celt/decoder.rs:1331 */
     /* post-filter parameter sets: [0] = old, [1] = current, [2] = new (parsed in this frame, :876-901).
        gain_q = 0 means off, else gain = 0.09375 * gain_q */

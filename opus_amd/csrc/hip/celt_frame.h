@@ -1098,7 +1098,7 @@ struct alignas(16) OgTailLds {
 struct OgHdrHead {
     uint32_t stream, pcm_off, leaf_begin, seed;
     uint16_t nleaves;
-    uint8_t lm, flags, start, end, spread, intensity;
+    uint8_t lm, flags, start, end, spread, intensity;     // spread: also the cross-fade kind and launch round (opusgpu_sideinfo.h)
     uint16_t pf_period[3];
     uint8_t pf_gain_q[3], pf_tapset[3];
 };
@@ -1318,7 +1318,8 @@ OG_DEV void og_celt_tail_run(const OgCeltHdr *hg, uint32_t nfr, OgCeltState *sta
         OG_STAMP_TO(cyc, 21)
         float *pcm = pcm_base + (size_t)hd.stream * pcm_stride + (size_t)hd.pcm_off * CC;
         const bool accum = (flags & OG_F_ACCUM) != 0;
-        const bool vec = (((uintptr_t)pcm) & 15) == 0;  // 16-byte stores when the caller's row allows it
+        const int xfade = (hd.spread >> OG_X_SHIFT) & 3;   // redundant frames (opusgpu_sideinfo.h OG_X_*): rare, scalar stores
+        const bool vec = (((uintptr_t)pcm) & 15) == 0 && xfade == OG_X_NONE;      // 16-byte stores when the caller's row allows it
         const float *t0 = &L.out[0][OG_HIST + 60], *t1 = &L.out[1][OG_HIST + 60];
         OG_TLANES_BEGIN(tid)
         const float k = 1.f / 32768.f;
@@ -1339,7 +1340,17 @@ OG_DEV void og_celt_tail_run(const OgCeltHdr *hg, uint32_t nfr, OgCeltState *sta
             for (int q = tid; q < N * CC; q += OG_WGT) {
                 const int j = CC == 2 ? q >> 1 : q, ch = CC == 2 ? q & 1 : 0;
                 const float v = (ch ? t1 : t0)[j] * k;
-                pcm[q] = accum ? pcm[q] + v : v;
+                if (xfade == OG_X_NONE) {
+                    pcm[q] = accum ? pcm[q] + v : v;
+                } else {
+                    // out = a v + b pcm: the smooth_fade of RFC 6716 4.5.1.4 with the squared CELT window over samples 120 .. 239
+                    const float w = j >= 120 && j < 240 ? L.window[j - 120] * L.window[j - 120] : 0.f;
+                    float a, b;
+                    if (xfade == OG_X_RED_HEAD) { a = j < 120 ? 1.f : 1.f - w; b = j < 120 ? 0.f : w; }
+                    else if (xfade == OG_X_AFTER_RED_HEAD) { a = j < 120 ? 0.f : j < 240 ? w : 1.f; b = 1.f; }
+                    else { a = w; b = 1.f - w; }                            // OG_X_RED_TAIL (a = 0, b = 1 for j < 120)
+                    if (!(xfade == OG_X_RED_TAIL && j < 120) && j < (xfade == OG_X_AFTER_RED_HEAD ? N : 240)) pcm[q] = a * v + b * pcm[q];
+                }
             }
         }
         OG_TLANES_END                                   // the staging slots are read before the next frame's row lands in them

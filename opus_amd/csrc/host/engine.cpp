@@ -56,6 +56,7 @@ struct PinnedBuf {                       // grow-only pinned host array (H2D sou
 struct ParsedPacket {                    // one thread-local parse result
     int rc = 0;                          // number of frames or error
     uint32_t stream = 0;
+    int worker = 0;                      // whose local arrays fi[].celt_index / silk_index point into
     OgFrameInfo fi[48];
     size_t celt0 = 0, leaf0 = 0, silk0 = 0;   // offsets into the worker's local arrays
     size_t ncelt = 0, nleaf = 0, nsilk = 0;
@@ -187,6 +188,7 @@ int opusgpu_batch_send(opusgpu_batch *b, const uint8_t *const *pkts, const uint3
         for (uint32_t i = lo; i < hi; i++) {
             ParsedPacket &pp = parsed[i];
             pp.stream = stream_ids ? stream_ids[i] : i;
+            pp.worker = w;
             pp.celt0 = W.celt.size(); pp.leaf0 = W.leaves.size(); pp.silk0 = W.silk.size();
             pp.rc = b->parsers[pp.stream].parse(pkts[i], lens[i], pp.fi, W.celt, W.leaves, W.silk);
             if (pp.rc < 0) {                            // a bad packet never poisons the batch
@@ -220,16 +222,19 @@ int opusgpu_batch_send(opusgpu_batch *b, const uint8_t *const *pkts, const uint3
             std::memcpy(b->h_leaves.p + leaf_base[w], workers[w].leaves.data(), workers[w].leaves.size() * sizeof(OgCeltLeaf));
     b->h_leaves.n = leaf_base[nw];
 
-    // A stream's work must run in order: Opus frame f of a packet = rounds 3f .. 3f+2; its SILK frames (up to three
-    // 20 ms pieces) take rounds 3f+k, its CELT part (which adds onto the SILK output in hybrid mode) runs in 3f+2.
+    // A stream's work must run in order: Opus frame f of a packet = rounds 4f .. 4f+3 (OG_ROUNDS_PER_FRAME); its SILK frames (up
+    // to three 20 ms pieces) take rounds 4f+k, its CELT records run after the SILK frames of the round each names (OG_ROUND_*:
+    // the frame's own CELT part, which adds onto the SILK output in hybrid mode, in 4f+2; redundant frames in 4f+0 / 4f+3).
+    constexpr uint32_t RPF = OG_ROUNDS_PER_FRAME;
     uint32_t rounds = 0;
-    for (uint32_t i = 0; i < n; i++) if (parsed[i].rc > 0) rounds = std::max(rounds, 3 * uint32_t(parsed[i].rc));
+    for (uint32_t i = 0; i < n; i++) if (parsed[i].rc > 0) rounds = std::max(rounds, RPF * uint32_t(parsed[i].rc));
     std::vector<uint32_t> ccount(rounds + 1, 0), scount(rounds + 1, 0);
     for (uint32_t i = 0; i < n; i++) {
         const ParsedPacket &pp = parsed[i];
         for (int f = 0; f < pp.rc; f++) {
-            ccount[3 * f + 2] += pp.fi[f].has_celt;
-            for (uint32_t k = 0; k < pp.fi[f].nsilk; k++) scount[3 * f + k]++;
+            for (uint32_t c = 0; c < pp.fi[f].has_celt; c++)
+                ccount[RPF * f + (workers[pp.worker].celt[pp.fi[f].celt_index + c].spread >> OG_ROUND_SHIFT)]++;
+            for (uint32_t k = 0; k < pp.fi[f].nsilk; k++) scount[RPF * f + k]++;
         }
     }
     b->celt_round_off.assign(rounds + 1, 0);
@@ -253,14 +258,14 @@ int opusgpu_batch_send(opusgpu_batch *b, const uint8_t *const *pkts, const uint3
                     sf.stream = pp.stream;
                     sf.pcm_off = pcm_off + sub;
                     sub += uint32_t(sf.f_size) * (sf.bandwidth == 0 ? 6u : sf.bandwidth == 1 ? 4u : 3u);
-                    b->h_silk.p[sfill[3 * f + k]++] = sf;
+                    b->h_silk.p[sfill[RPF * f + k]++] = sf;
                 }
-                if (fi.has_celt) {
-                    OgCeltHdr hd = workers[w].celt[fi.celt_index];
+                for (uint32_t c = 0; c < fi.has_celt; c++) {
+                    OgCeltHdr hd = workers[w].celt[fi.celt_index + c];
                     hd.stream = pp.stream;
-                    hd.pcm_off = pcm_off;
+                    hd.pcm_off += pcm_off;              // the parser left the offset inside the Opus frame
                     hd.leaf_begin = uint32_t(hd.leaf_begin + leaf_base[w]);
-                    b->h_celt.p[cfill[3 * f + 2]++] = hd;
+                    b->h_celt.p[cfill[RPF * f + (hd.spread >> OG_ROUND_SHIFT)]++] = hd;
                 }
                 pcm_off += fi.frame_size;
             }

@@ -22,6 +22,7 @@ void StreamParser::reset()
     silk_.flush();
     silk_.resampler_reset = true;
     prev_mode_ = -1;
+    prev_redundancy_ = false;
 }
 
 int StreamParser::parse(const uint8_t *pkt, size_t len, OgFrameInfo *frames, std::vector<OgCeltHdr> &celt,
@@ -32,13 +33,13 @@ int StreamParser::parse(const uint8_t *pkt, size_t len, OgFrameInfo *frames, std
     int rc = parse_packet(pkt, int(len), &p);
     if (rc) return rc;
 
-    // mode transitions: decoder.rs:61-67, :79 (silk.flush() on CELT packets); CELT state restarts when
-    // CELT (re)joins after a SILK-only packet (RFC 6716 4.5.2; the reference keeps stale state)
-    if (p.mode != prev_mode_ && prev_mode_ >= 0) {
-        if (p.mode != MODE_SILK) celt_.reset();
-        if (prev_mode_ == MODE_CELT) { silk_.flush(); silk_.resampler_reset = true; }
-    }
+    // Mode transitions (decoder.rs:61-67, :79 and, where the reference parses and drops, RFC 6716 4.5): SILK restarts after
+    // CELT-only packets; CELT restarts when the mode changes -- unless the previous frame ended in a SILK -> CELT redundant
+    // frame, from which CELT continues -- and only after a CELT -> SILK redundant frame has been parsed from the old state.
+    bool celt_restart = p.mode != prev_mode_ && prev_mode_ >= 0 && !prev_redundancy_ && p.mode != MODE_SILK;
+    if (p.mode != prev_mode_ && prev_mode_ == MODE_CELT) { silk_.flush(); silk_.resampler_reset = true; }
 
+    auto tag = [](OgCeltHdr &h, int xfade, int round) { h.spread = uint8_t((h.spread & OG_SPREAD_MASK) | xfade << OG_X_SHIFT | round << OG_ROUND_SHIFT); };
     for (int f = 0; f < p.nframes; f++) {
         RangeDec rd(pkt + p.off[f], uint32_t(p.len[f]));
         const int flen = p.len[f], N = p.frame_size;
@@ -59,31 +60,69 @@ int StreamParser::parse(const uint8_t *pkt, size_t len, OgFrameInfo *frames, std
             silk_.flush();                                                  // decoder.rs:79
         }
 
-        // redundancy side information: parsed, then only used to shorten the CELT budget
-        // (decoder.rs:82-115; RFC 6716 4.5.1).  The 5 ms redundant frame itself is not decoded.
+        // redundancy side information (decoder.rs:82-115; RFC 6716 4.5.1)
         const int consumed = rd.tell();
-        bool redundancy = false;
+        bool redundancy = false, celt_to_silk = false;
+        int rbytes = 0;
+        const uint8_t *rdata = nullptr;
         if (p.mode == MODE_HYBRID && consumed + 37 <= flen * 8) redundancy = rd.bit_logp(12);
         else if (p.mode == MODE_SILK && consumed + 17 <= flen * 8) redundancy = true;
         if (redundancy) {
-            (void)rd.bit_logp(1);                                           // celt_to_silk position
-            int rbytes = p.mode == MODE_HYBRID ? int(rd.uint(256)) + 2 : flen - ((rd.tell() + 7) >> 3);
+            celt_to_silk = rd.bit_logp(1);                                  // position: 1 = the redundant frame belongs in front
+            rbytes = p.mode == MODE_HYBRID ? int(rd.uint(256)) + 2 : flen - ((rd.tell() + 7) >> 3);
             if (rbytes >= flen) return OPUSGPU_INVALID_DATA;                // decoder.rs:104
             int keep = flen - rbytes;
-            if (keep * 8 < rd.tell()) keep = 0;
+            if (keep * 8 < rd.tell()) { keep = 0; redundancy = false; rbytes = 0; }
+            else rdata = pkt + p.off[f] + keep;
             rd.set_storage(uint32_t(keep));
         }
+        // The redundant frame: 5 ms of CELT from band 0 (the reference drops it, decoder.rs:84-115).  CELT -> SILK: parsed first,
+        // from the running CELT state, and it opens the Opus frame.
+        uint32_t red_range = 0;
+        if (redundancy && celt_to_silk) {
+            RangeDec r2(rdata, uint32_t(rbytes));
+            celt.emplace_back();
+            (void)celt_parse_frame(celt_, r2, 240, 0, p.celt_end_band(), p.stereo + 1, &celt.back(), leaves);
+            tag(celt.back(), OG_X_RED_HEAD, OG_ROUND_HEAD);
+            red_range = r2.rng();
+            fi.has_celt++;
+        }
+        if (f == 0 && celt_restart) celt_.reset();
+        celt_restart = false;
 
         if (p.mode != MODE_SILK && N <= 960) {                              // decoder.rs:117-123
             const int start = p.mode == MODE_HYBRID ? 17 : 0;
             celt.emplace_back();
             (void)celt_parse_frame(celt_, rd, N, start, p.celt_end_band(), p.stereo + 1, &celt.back(), leaves);
             if (p.mode == MODE_HYBRID) celt.back().flags |= OG_F_ACCUM;
-            fi.has_celt = 1;
+            tag(celt.back(), redundancy && celt_to_silk ? OG_X_AFTER_RED_HEAD : OG_X_NONE, OG_ROUND_MAIN);
+            fi.has_celt++;
+        } else if (p.mode == MODE_SILK && prev_mode_ == MODE_HYBRID && !(redundancy && celt_to_silk && prev_redundancy_)) {
+            // hybrid -> SILK: a silent 2.5 ms CELT frame lets the MDCT overlap of the last hybrid frame fade out (RFC 6716 4.5.2)
+            static const uint8_t kSilence[2] = {0xFF, 0xFF};
+            RangeDec r3(kSilence, 2);
+            celt.emplace_back();
+            (void)celt_parse_frame(celt_, r3, 120, 0, p.celt_end_band(), p.stereo + 1, &celt.back(), leaves);
+            celt.back().flags |= OG_F_ACCUM;
+            tag(celt.back(), OG_X_NONE, OG_ROUND_HEAD);
+            fi.has_celt++;
         }
-        fi.final_range = rd.rng();
+        if (redundancy && !celt_to_silk) {
+            // SILK -> CELT: parsed last, from a fresh CELT state, which the next (CELT) packet continues; it closes the Opus frame
+            RangeDec r2(rdata, uint32_t(rbytes));
+            celt_.reset();
+            celt.emplace_back();
+            (void)celt_parse_frame(celt_, r2, 240, 0, p.celt_end_band(), p.stereo + 1, &celt.back(), leaves);
+            celt.back().pcm_off = uint32_t(N - 240);
+            tag(celt.back(), OG_X_RED_TAIL, OG_ROUND_TAIL);
+            red_range = r2.rng();
+            fi.has_celt++;
+        }
+        fi.final_range = rd.rng() ^ red_range;                              // RFC 6716 4.5.1.4
         fi.tell_bits = uint32_t(rd.tell());
         fi.budget_bits = uint32_t(rd.storage_bits());
+        prev_mode_ = p.mode;
+        prev_redundancy_ = redundancy && !celt_to_silk;
     }
     prev_mode_ = p.mode;
     return p.nframes;

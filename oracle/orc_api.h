@@ -91,6 +91,7 @@ int orc_packet_parse(const uint8_t *buf, int len, OrcPacket *p);
 typedef struct OrcDecoder OrcDecoder;
 OrcDecoder *orc_decoder_create(int channels);
 void orc_decoder_destroy(OrcDecoder *);
+uint32_t orc_decoder_final_range(const OrcDecoder *);   /* last frame: main range XOR the redundant frame's */
 void orc_decoder_set_celt_trace(OrcDecoder *, OrcCeltTrace *);
 /* decode one packet -> interleaved f32 @48 kHz; returns samples per channel, <0 on error */
 int orc_decoder_decode(OrcDecoder *, const uint8_t *pkt, int len, float *pcm, int cap_samples);

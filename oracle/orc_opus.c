@@ -162,8 +162,13 @@ void orc_resample_to_48k(const float *in, int n_in, int rate_khz, float *hist, f
 }
 
 /* ------------------------------------------------------------------ decoder.rs driver */
+int orc_drop_redundancy = 0;                 /* test switch: parse the redundant frames and drop them, as the reference does */
+void orc_set_drop_redundancy(int v) { orc_drop_redundancy = v; }
+long orc_redundant_frames[2] = {0, 0};       /* test statistics: redundant frames decoded, [0] SILK -> CELT, [1] CELT -> SILK */
 struct OrcDecoder {
     int channels, prev_mode;
+    int prev_redundancy;          /* the previous frame ended in a SILK -> CELT redundant frame: CELT continues from it */
+    uint32_t final_range;         /* of the last frame: the main decoder's range XOR the redundant frame's (RFC 6716 4.5.1.4) */
     OrcSilk *silk;
     OrcCelt *celt;
     float rs_hist[2][32];
@@ -178,6 +183,7 @@ OrcDecoder *orc_decoder_create(int channels)   /* decoder.rs:133-182 (configure)
     return d;
 }
 void orc_decoder_destroy(OrcDecoder *d) { orc_silk_destroy(d->silk); orc_celt_destroy(d->celt); free(d); }
+uint32_t orc_decoder_final_range(const OrcDecoder *d) { return d->final_range; }
 void orc_decoder_set_celt_trace(OrcDecoder *d, OrcCeltTrace *t) { orc_celt_set_trace(d->celt, t); }
 
 int orc_decoder_decode(OrcDecoder *d, const uint8_t *pkt, int len, float *pcm, int cap)
@@ -188,10 +194,12 @@ int orc_decoder_decode(OrcDecoder *d, const uint8_t *pkt, int len, float *pcm, i
     if (total > cap) return -3;
     static const int celt_end[5] = {13, 17, 17, 19, 21};     /* packet.rs:33-42 */
     static const int silk_rate[3] = {8, 12, 16};
-    if (p.mode != d->prev_mode && d->prev_mode >= 0) {
-        if (p.mode != 0) orc_celt_reset(d->celt);
-        if (d->prev_mode == 2) { orc_silk_flush(d->silk); memset(d->rs_hist, 0, sizeof d->rs_hist); }
-    }
+    /* Mode transitions (decoder.rs:61-67, :79 and, where the reference parses and drops, RFC 6716 4.5): SILK restarts after
+       CELT-only packets; CELT restarts when the mode changes -- unless the previous frame ended in a SILK -> CELT redundant
+       frame, from which CELT continues -- and only after a CELT -> SILK redundant frame has been decoded from the old state. */
+    int celt_restart = p.mode != d->prev_mode && d->prev_mode >= 0 && !d->prev_redundancy && p.mode != 0;
+    if (p.mode != d->prev_mode && d->prev_mode == 2) { orc_silk_flush(d->silk); memset(d->rs_hist, 0, sizeof d->rs_hist); }
+    const float *win = orc_celt_window();
     for (int f = 0; f < p.nframes; f++) {
         OrcRd rd;
         int flen = p.len[f], N = p.frame_size;
@@ -210,24 +218,73 @@ int orc_decoder_decode(OrcDecoder *d, const uint8_t *pkt, int len, float *pcm, i
                 orc_resample_to_48k(sr, n, silk_rate[bw], d->rs_hist[1], ch[1]);
             } else orc_resample_to_48k(sr, n, silk_rate[bw], d->rs_hist[0], ch[0]);
         } else orc_silk_flush(d->silk);                       /* decoder.rs:79 */
-        int consumed = orc_rd_tell(&rd), redundancy = 0;     /* decoder.rs:82-115 */
+        int consumed = orc_rd_tell(&rd), redundancy = 0, celt_to_silk = 0, rbytes = 0;     /* decoder.rs:82-115 */
+        const uint8_t *rdata = NULL;
         if (p.mode == 1 && consumed + 37 <= flen * 8) redundancy = orc_rd_logp(&rd, 12);
         else if (p.mode == 0 && consumed + 17 <= flen * 8) redundancy = 1;
         if (redundancy) {
-            (void)orc_rd_logp(&rd, 1);                        /* celt_to_silk position flag */
-            int rbytes = p.mode == 1 ? (int)orc_rd_uniform(&rd, 256) + 2 : flen - ((orc_rd_tell(&rd) + 7) >> 3);
+            celt_to_silk = orc_rd_logp(&rd, 1);               /* position flag: 1 = the redundant frame belongs in front */
+            rbytes = p.mode == 1 ? (int)orc_rd_uniform(&rd, 256) + 2 : flen - ((orc_rd_tell(&rd) + 7) >> 3);
             if (rbytes >= flen) return -1;
             int nl = flen - rbytes;
-            if (nl * 8 < orc_rd_tell(&rd)) { nl = 0; }
-            rd.len = nl; rd.size_bits = nl * 8;               /* RFC 6716 4.5.1: the 5 ms redundant frame is not decoded here */
+            if (nl * 8 < orc_rd_tell(&rd)) { nl = 0; redundancy = 0; rbytes = 0; }
+            else rdata = pkt + p.off[f] + nl;
+            rd.len = nl; rd.size_bits = nl * 8;
+            if (orc_drop_redundancy) redundancy = 0;
         }
+        /* RFC 6716 4.5.1: the redundant frame is a 5 ms CELT frame from band 0 (the reference drops it, decoder.rs:84-115) */
+        float red[2][240];
+        uint32_t red_range = 0;
+        memset(red, 0, sizeof red);
+        if (redundancy) orc_redundant_frames[celt_to_silk]++;
+        if (redundancy && celt_to_silk) {                     /* CELT -> SILK: decoded first, from the running CELT state */
+            OrcRd r2;
+            orc_rd_init(&r2, rdata, rbytes);
+            orc_celt_decode_frame(d->celt, &r2, 240, 0, celt_end[p.bandwidth], p.stereo + 1, red[0], red[1]);
+            red_range = r2.range;
+        }
+        if (f == 0 && celt_restart) orc_celt_reset(d->celt);
         if (p.mode != 0 && N <= 960) {
             float c0[960], c1[960];
             int start = p.mode == 1 ? 17 : 0;
             orc_celt_decode_frame(d->celt, &rd, N, start, celt_end[p.bandwidth], p.stereo + 1, c0, c1);
             for (int i = 0; i < N; i++) { ch[0][i] += c0[i]; if (CC == 2) ch[1][i] += c1[i]; }
+        } else if (p.mode == 0 && d->prev_mode == 1 && !(redundancy && celt_to_silk && d->prev_redundancy)) {
+            /* hybrid -> SILK: a 2.5 ms silent CELT frame lets the MDCT overlap of the last hybrid frame fade out (RFC 6716 4.5.2) */
+            static const uint8_t silence[2] = {0xFF, 0xFF};
+            float c0[960], c1[960];
+            OrcRd r3;
+            orc_rd_init(&r3, silence, 2);
+            orc_celt_decode_frame(d->celt, &r3, 120, 0, celt_end[p.bandwidth], p.stereo + 1, c0, c1);
+            for (int i = 0; i < 120; i++) { ch[0][i] += c0[i]; if (CC == 2) ch[1][i] += c1[i]; }
+        }
+        if (redundancy && !celt_to_silk) {                    /* SILK -> CELT: decoded last, from a fresh CELT state, which the next
+                                                                 (CELT) packet continues; cross-faded over the frame's last 2.5 ms */
+            OrcRd r2;
+            orc_rd_init(&r2, rdata, rbytes);
+            orc_celt_reset(d->celt);
+            orc_celt_decode_frame(d->celt, &r2, 240, 0, celt_end[p.bandwidth], p.stereo + 1, red[0], red[1]);
+            red_range = r2.range;
+            for (int c = 0; c < CC; c++)
+                for (int i = 0; i < 120; i++) {
+                    float w = win[i] * win[i];
+                    ch[c][N - 120 + i] = w * red[c][120 + i] + (1.f - w) * ch[c][N - 120 + i];
+                }
+        }
+        if (redundancy && celt_to_silk) {                     /* first 2.5 ms from the redundant frame, the next 2.5 ms cross-faded */
+            for (int c = 0; c < CC; c++) {
+                for (int i = 0; i < 120; i++) ch[c][i] = red[c][i];
+                for (int i = 0; i < 120; i++) {
+                    float w = win[i] * win[i];
+                    ch[c][120 + i] = w * ch[c][120 + i] + (1.f - w) * red[c][120 + i];
+                }
+            }
         }
         for (int i = 0; i < N; i++) for (int c = 0; c < CC; c++) dst[i * CC + c] = ch[c][i];
+        d->final_range = rd.range ^ red_range;
+        d->prev_mode = p.mode;
+        d->prev_redundancy = redundancy && !celt_to_silk;
+        celt_restart = 0;
     }
     d->prev_mode = p.mode;
     return total;

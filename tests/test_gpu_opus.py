@@ -155,11 +155,17 @@ def test_random_silk_payloads_with_lbrr_on_gpu(stereo):
     d.set_extradata(extra)
     d.configure()
     ref = orc.Decoder(2)
+    hp = HostParser(2)                  # the same parse on the side: tells which packets carry CELT records
     for i in range(96):
         config = i % 12
         n = int(rng.integers(20, 120)) * (1, 1, 2, 3)[config & 3]
         p = bytes([config << 3 | stereo << 2]) + rng.integers(0, 256, n, dtype=np.uint8).tobytes()
         d.send_packet(p)
         out, r = d.receive_frame(), ref.decode(p)
-        assert np.array_equal(out, r), f"packet {i} (config {config}): max diff {np.abs(out - r).max()}"
+        # most random payloads leave bits behind the SILK frames, i.e. carry a (random) redundant CELT frame: CELT bar there
+        nfr, *_ = hp.parse(p)
+        if not any(hp.fi[f].has_celt for f in range(nfr)):
+            assert np.array_equal(out, r), f"packet {i} (config {config}): max diff {np.abs(out - r).max()}"
+        else:
+            check_pcm(r, out, f"packet {i} (config {config})")
     assert seen.value - before >= 20

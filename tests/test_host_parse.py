@@ -124,7 +124,7 @@ def _compare_frame(hd, leaves, fi, t):
     assert (hd.lm, hd.start, hd.end) == (t.lm, t.start, t.end)
     assert bool(hd.flags & A.F_TRANSIENT) == bool(t.transient) and bool(hd.flags & A.F_SILENCE) == bool(t.silence)
     assert bool(hd.flags & A.F_ANTICOLLAPSE) == bool(t.anticollapse_on)
-    assert (hd.spread, hd.intensity, hd.seed, fi.final_range) == (t.spread, t.intensity, t.seed_in, t.seed_out)
+    assert (hd.spread & 3, hd.intensity, hd.seed, fi.final_range) == (t.spread, t.intensity, t.seed_in, t.seed_out)
     assert (hd.pf_period[2], hd.pf_tapset[2], hd.pf_gain_q[2]) == (t.pf_period, t.pf_tapset, t.pf_gain_q + 1 if t.pf_on else 0)
     for c in range(t.C):
         assert np.array_equal(np.array(hd.energy[c][:]), np.array(t.energy[c][:]))       # bit-exact f32
