@@ -62,7 +62,9 @@ int opusgpu_decoder_set_extradata(opusgpu_decoder *, const uint8_t *extra, size_
 /* Decoder::configure (decoder.rs:133-182): channels from byte 9; > 2 channels -> OPUSGPU_UNSUPPORTED
  * (the reference hits unimplemented!(), decoder.rs:170-171); no extradata -> 2 channels. */
 int opusgpu_decoder_configure(opusgpu_decoder *);
-/* Decoder::send_packet (decoder.rs:48-127): parse, decode on the GPU, queue the PCM. */
+/* Decoder::send_packet (decoder.rs:48-127): parse, decode on the GPU, queue the PCM.  len == 0 (pkt may be NULL) reports a
+ * lost packet: the span of the last frame is concealed (the previous frame's overlap fades out, then silence) and the decoder
+ * restarts on the next packet; the reference has no concealment and panics on an empty packet (packet.rs:215-225). */
 int opusgpu_decoder_send_packet(opusgpu_decoder *, const uint8_t *pkt, size_t len);
 /* Decoder::receive_frame (decoder.rs:128-132, unimplemented!() in the reference): pops the oldest
  * decoded packet as interleaved f32 @ 48 kHz.  OPUSGPU_MORE_DATA_NEEDED when the queue is empty. */
@@ -115,7 +117,8 @@ void opusgpu_batch_destroy(opusgpu_batch *);
 /* Host half of send_packet for n (stream, packet) pairs: framing + range decoding + side-info
  * emission (packet.rs, entropy.rs, the integer control of celt/decoder.rs and silk/decoder.rs).
  * A stream may appear at most once per call.  errors[i] (optional) receives the per-packet code: a
- * bad packet never poisons the batch.  Returns OPUSGPU_OK or a global failure. */
+ * bad packet never poisons the batch.  lens[i] == 0 reports that stream's packet as lost (concealment, as in
+ * opusgpu_decoder_send_packet).  Returns OPUSGPU_OK or a global failure. */
 int opusgpu_batch_send(opusgpu_batch *, const uint8_t *const *pkts, const uint32_t *lens,
                        const uint32_t *stream_ids, uint32_t n, int32_t *errors);
 /* Device half: H2D of the side-info, then the kernels, on the batch's HIP stream.  Asynchronous: the next batch_send

@@ -22,6 +22,7 @@ void StreamParser::reset()
     silk_.flush();
     silk_.resampler_reset = true;
     prev_mode_ = -1;
+    last_packet_samples_ = 960;
     prev_redundancy_ = false;
 }
 
@@ -30,6 +31,32 @@ int StreamParser::parse(const uint8_t *pkt, size_t len, OgFrameInfo *frames, std
 {
     Packet p;
     if (len > 0x7FFFFFFF) return OPUSGPU_INVALID_DATA;
+    if (len == 0) {
+        // A lost packet (or a DTX gap): minimal concealment; the reference has none (and panics on an empty packet,
+        // packet.rs:215-225).  The span of the last packet is filled by silent CELT frames -- on the device the MDCT overlap of
+        // the last decoded frame fades out over 2.5 ms, then zeros -- and SILK restarts.
+        static const uint8_t kSilence[2] = {0xFF, 0xFF};
+        int n = 0;
+        for (int o = 0, N; o < last_packet_samples_; o += N, n++) {         // reported as Opus frames, in CELT frame sizes, largest first
+            const int left = last_packet_samples_ - o;
+            N = left >= 960 ? 960 : left >= 480 ? 480 : left >= 240 ? 240 : 120;
+            OgFrameInfo &fi = frames[n];
+            std::memset(&fi, 0, sizeof fi);
+            fi.mode = uint8_t(prev_mode_ < 0 ? MODE_CELT : prev_mode_);
+            fi.frame_size = uint16_t(N);
+            fi.celt_index = uint32_t(celt.size());
+            fi.silk_index = uint32_t(silk.size());
+            RangeDec r(kSilence, 2);
+            celt.emplace_back();
+            (void)celt_parse_frame(celt_, r, fi.frame_size, 0, 21, channels_, &celt.back(), leaves);
+            celt.back().spread = uint8_t((celt.back().spread & OG_SPREAD_MASK) | OG_ROUND_MAIN << OG_ROUND_SHIFT);
+            fi.has_celt = 1;
+        }
+        silk_.flush();
+        silk_.resampler_reset = true;
+        prev_redundancy_ = false;
+        return n;
+    }
     int rc = parse_packet(pkt, int(len), &p);
     if (rc) return rc;
 
@@ -125,6 +152,7 @@ int StreamParser::parse(const uint8_t *pkt, size_t len, OgFrameInfo *frames, std
         prev_redundancy_ = redundancy && !celt_to_silk;
     }
     prev_mode_ = p.mode;
+    last_packet_samples_ = p.nframes * p.frame_size;
     return p.nframes;
 }
 

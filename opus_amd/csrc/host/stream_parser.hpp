@@ -20,6 +20,7 @@ public:
 private:
     int channels_;
     int prev_mode_ = -1;
+    int last_packet_samples_ = 960;                 // samples per channel of the last packet (what a lost packet is taken to span)
     bool prev_redundancy_ = false;                  // the previous frame ended in a SILK -> CELT redundant frame: CELT continues from it
     CeltHostState celt_;
     SilkHostState silk_;

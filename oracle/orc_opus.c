@@ -167,6 +167,7 @@ void orc_set_drop_redundancy(int v) { orc_drop_redundancy = v; }
 long orc_redundant_frames[2] = {0, 0};       /* test statistics: redundant frames decoded, [0] SILK -> CELT, [1] CELT -> SILK */
 struct OrcDecoder {
     int channels, prev_mode;
+    int last_frame_size;          /* samples per channel of the last packet (what a lost packet is taken to span) */
     int prev_redundancy;          /* the previous frame ended in a SILK -> CELT redundant frame: CELT continues from it */
     uint32_t final_range;         /* of the last frame: the main decoder's range XOR the redundant frame's (RFC 6716 4.5.1.4) */
     OrcSilk *silk;
@@ -177,7 +178,7 @@ struct OrcDecoder {
 OrcDecoder *orc_decoder_create(int channels)   /* decoder.rs:133-182 (configure) */
 {
     OrcDecoder *d = (OrcDecoder *)calloc(1, sizeof *d);
-    d->channels = channels; d->prev_mode = -1;
+    d->channels = channels; d->prev_mode = -1; d->last_frame_size = 960;
     d->silk = orc_silk_create(channels > 1);
     d->celt = orc_celt_create(channels);
     return d;
@@ -189,6 +190,28 @@ void orc_decoder_set_celt_trace(OrcDecoder *d, OrcCeltTrace *t) { orc_celt_set_t
 int orc_decoder_decode(OrcDecoder *d, const uint8_t *pkt, int len, float *pcm, int cap)
 {   /* decoder.rs:48-127 */
     OrcPacket p;
+    if (len == 0) {
+        /* A lost packet (or a DTX gap): minimal concealment, no counterpart in the reference (it panics on an empty packet,
+           packet.rs:215-225).  The span of the last packet is filled by silent CELT frames -- the MDCT overlap of the last
+           decoded frame fades out over 2.5 ms, then zeros -- and SILK restarts; the next packet is decoded as after a switch. */
+        static const uint8_t silence[2] = {0xFF, 0xFF};
+        int CC = d->channels, total = d->last_frame_size;
+        if (total > cap) return -3;
+        for (int o = 0, N; o < total; o += N) {             /* in CELT frame sizes, largest first */
+            int left = total - o;
+            N = left >= 960 ? 960 : left >= 480 ? 480 : left >= 240 ? 240 : 120;
+            float c0[960], c1[960];
+            OrcRd r;
+            orc_rd_init(&r, silence, 2);
+            orc_celt_decode_frame(d->celt, &r, N, 0, 21, CC, c0, c1);
+            for (int i = 0; i < N; i++) for (int c = 0; c < CC; c++) pcm[(size_t)(o + i) * CC + c] = c ? c1[i] : c0[i];
+        }
+        orc_silk_flush(d->silk);
+        memset(d->rs_hist, 0, sizeof d->rs_hist);
+        d->prev_redundancy = 0;
+        d->final_range = 0;
+        return total;
+    }
     if (orc_packet_parse(pkt, len, &p)) return -1;
     int CC = d->channels, total = p.nframes * p.frame_size;
     if (total > cap) return -3;
@@ -282,6 +305,7 @@ int orc_decoder_decode(OrcDecoder *d, const uint8_t *pkt, int len, float *pcm, i
         }
         for (int i = 0; i < N; i++) for (int c = 0; c < CC; c++) dst[i * CC + c] = ch[c][i];
         d->final_range = rd.range ^ red_range;
+        d->last_frame_size = total;
         d->prev_mode = p.mode;
         d->prev_redundancy = redundancy && !celt_to_silk;
         celt_restart = 0;

@@ -35,6 +35,7 @@ class EmuDecoder:
     def decode(self, p):
         hp = self.hp
         n, nc, nl, ns = hp.parse(p)
+        self.nframes = n
         if n < 0:
             return n
         off = 0

@@ -58,7 +58,7 @@ def test_batch_subset_and_bad_packet():
     V = orc.load_vectors(ids=[11], max_packets=8)[11][1]
     dec = BatchDecoder(4, 2, 0)
     refs = [orc.Decoder(2) for _ in range(4)]
-    errs = dec.send([V[0], b"", V[0]], stream_ids=[0, 1, 3])
+    errs = dec.send([V[0], b"\x03\x00", V[0]], stream_ids=[0, 1, 3])       # (code 3 with a frame count of zero, packet.rs:145)
     assert errs == [0, A.INVALID_DATA, 0]
     dec.decode()
     check_pcm(refs[0].decode(V[0]), dec.read(0))

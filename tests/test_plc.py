@@ -1,0 +1,34 @@
+"""Lost packets: minimal concealment (the previous frame's MDCT overlap fades out, then silence; SILK and the resampler
+restart).  The reference has none -- it panics on an empty packet (packet.rs:215-225) -- so there is no reference output: the
+oracle and the product implement the same stated behaviour and are compared with each other, plus the properties below."""
+import numpy as np
+import pytest
+
+import orc
+from gpu_util import check_pcm
+from test_emu_silk import EmuDecoder, emu  # noqa: F401  (fixture)
+
+
+@pytest.mark.parametrize("vid,npk", [(1, 300), (4, 300), (6, 300), (10, 300)])
+def test_lost_packets_are_concealed(emu, vid, npk):  # noqa: F811
+    _, pk = orc.load_vectors(ids=[vid], max_packets=npk)[vid]
+    d, ref = EmuDecoder(emu, 2), orc.Decoder(2)
+    last = None
+    for i, p in enumerate(pk):
+        lost = i % 37 == 20 or i % 37 == 21            # single and double losses
+        want = ref.decode(b"" if lost else p)
+        out = d.decode(b"" if lost else bytes(p))
+        assert not isinstance(out, int), (i, out)
+        assert out.shape == want.shape
+        check_pcm(want, out, f"vector {vid} packet {i}{' (lost)' if lost else ''}")
+        if lost:
+            assert last is not None and want.shape == last.shape, "a lost packet spans what the last packet spanned"
+            assert len(want) <= 480 or np.abs(want[480:]).max() < 1e-6, "silence once the overlap has faded out and the de-emphasis has rung down"
+            assert np.abs(want).max() <= max(1e-9, 1.5 * np.abs(last).max())
+        last = want
+
+
+def test_loss_before_any_packet(emu):  # noqa: F811
+    d, ref = EmuDecoder(emu, 2), orc.Decoder(2)
+    out, want = d.decode(b""), ref.decode(b"")
+    assert out.shape == want.shape == (960, 2) and not out.any() and not want.any()
