@@ -59,8 +59,9 @@ int opusgpu_decoder_create(opusgpu_decoder **out, int device);
 void opusgpu_decoder_destroy(opusgpu_decoder *);
 /* Decoder::set_extradata (decoder.rs:45-47): the OpusHead blob, copied. */
 int opusgpu_decoder_set_extradata(opusgpu_decoder *, const uint8_t *extra, size_t len);
-/* Decoder::configure (decoder.rs:133-182): channels from byte 9; > 2 channels -> OPUSGPU_UNSUPPORTED
- * (the reference hits unimplemented!(), decoder.rs:170-171); no extradata -> 2 channels. */
+/* Decoder::configure (decoder.rs:133-182): channels from byte 9; no extradata -> 2 channels.  Mapping families 1 and 255
+ * (where the reference hits unimplemented!(), decoder.rs:151-157, :170-171) configure a multistream decoder: send_packet
+ * then takes RFC 7845 5.1.1 multistream packets and receive_frame returns `channels` interleaved channels. */
 int opusgpu_decoder_configure(opusgpu_decoder *);
 /* Decoder::send_packet (decoder.rs:48-127): parse, decode on the GPU, queue the PCM.  len == 0 (pkt may be NULL) reports a
  * lost packet: the span of the last frame is concealed (the previous frame's overlap fades out, then silence) and the decoder
@@ -176,6 +177,10 @@ typedef struct {
     int32_t off[48], len[48];
 } OgPacket;
 int opusgpu_packet_parse(const uint8_t *pkt, size_t len, OgPacket *out);
+/* RFC 6716 Appendix B: the self-delimiting packet at pkt (every stream but the last of a multistream packet, RFC 7845 5.1.1;
+ * no counterpart in the reference, whose multistream configuration ends in unimplemented!(), decoder.rs:151-157) rewritten
+ * as the ordinary packet with the same frames: out[0 .. *out_len), and *consumed = the bytes it took at pkt. */
+int opusgpu_packet_undelimit(const uint8_t *pkt, size_t len, uint8_t *out, size_t out_cap, size_t *out_len, int *consumed);
 
 /* ------------------------------------------------------------------------------------------------
  * Layer 3b: raw kernel launches on caller-owned device memory.  `stream` is a hipStream_t passed as

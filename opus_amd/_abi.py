@@ -114,6 +114,7 @@ PROTOTYPES = {
                                       C.POINTER(C.c_uint32), C.POINTER(CeltLeaf), C.c_uint32, C.POINTER(C.c_uint32),
                                       C.POINTER(SilkFrame), C.c_uint32, C.POINTER(C.c_uint32)]),
     "opusgpu_packet_parse": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(Packet)]),
+    "opusgpu_packet_undelimit": (C.c_int, [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
     "opusgpu_init": (C.c_int, [C.c_int]),
     "opusgpu_launch_celt": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, _P, C.POINTER(C.c_uint32), _P, _P, _P, C.c_size_t, C.POINTER(CeltDebug), _P]),
     "opusgpu_launch_celt_pvq": (C.c_int, [_P, _P, C.c_uint32, _P, C.POINTER(C.c_uint32), _P, C.POINTER(CeltDebug), _P]),

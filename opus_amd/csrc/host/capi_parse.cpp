@@ -38,6 +38,18 @@ const char *opusgpu_strerror(int code)
     }
 }
 
+int opusgpu_packet_undelimit(const uint8_t *pkt, size_t len, uint8_t *out, size_t out_cap, size_t *out_len, int *consumed)
+{
+    if (!pkt || !out || !out_len || !consumed) return OPUSGPU_BAD_ARG;
+    std::vector<uint8_t> v;
+    const int rc = og::undelimit_packet(pkt, len > 0x7FFFFFFF ? 0x7FFFFFFF : int(len), v, consumed);
+    if (rc) return rc;
+    if (v.size() > out_cap) return OPUSGPU_BAD_ARG;
+    std::memcpy(out, v.data(), v.size());
+    *out_len = v.size();
+    return OPUSGPU_OK;
+}
+
 int opusgpu_packet_parse(const uint8_t *pkt, size_t len, OgPacket *out)
 {
     if (!out) return OPUSGPU_BAD_ARG;

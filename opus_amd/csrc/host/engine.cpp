@@ -391,7 +391,15 @@ struct opusgpu_decoder {
     uint32_t skip_left = 0;             // OpusHead pre-skip still to drop (48 kHz samples)
     uint32_t pre_skip = 0;
     float out_gain = 1.f;               // 10^(output_gain_q8 / (20 * 256))
-    ~opusgpu_decoder() { delete batch; }
+    // multistream (RFC 7845 5.1.1, mapping families 1 and 255; decoder.rs:151-157, :170-171 stop at unimplemented!()): the
+    // packet's `streams` Opus streams decode side by side -- the first `coupled` ones as the streams of a two-channel batch,
+    // the others as the streams of a one-channel batch (`batch_mono`; a stereo-coded packet in a mono stream is down-mixed, as
+    // by any mono decoder); output channel c is channel `mapping[c]` of the decoded set -- 2s, 2s+1 for coupled stream s,
+    // then one per mono stream -- or silence for 255
+    uint32_t streams = 1, coupled = 0;
+    std::vector<uint8_t> mapping;
+    opusgpu_batch *batch_mono = nullptr;
+    ~opusgpu_decoder() { delete batch; delete batch_mono; }
 };
 
 extern "C" {
@@ -424,13 +432,15 @@ int opusgpu_decoder_configure(opusgpu_decoder *d)
     if (!e.empty()) {
         OgOpusHead head;
         const int hrc = opusgpu_opus_head_parse(e.data(), e.size(), &head);
-        // decoder.rs:151-171: explicit stream maps / > 2 channels end in unimplemented!(); mono / stereo is everything
-        // the reference can configure
-        if (hrc == OPUSGPU_OK && (head.channels > 2 || head.stream_count != 1)) return OPUSGPU_UNSUPPORTED;
+        // decoder.rs:151-171: explicit stream maps / > 2 channels end in unimplemented!() in the reference; here mapping
+        // families 1 and 255 configure a multistream decoder
         if (hrc == OPUSGPU_CONFIG_INVALID && e.size() >= 19 && std::memcmp(e.data(), "OpusHead", 8) == 0 && e[9] > 2 && e[18] == 0)
-            return OPUSGPU_UNSUPPORTED;                 // family 0 with > 2 channels: same dead end (decoder.rs:170-171)
+            return OPUSGPU_UNSUPPORTED;                 // family 0 with > 2 channels: not a valid header (RFC 7845 5.1.1.1)
         if (hrc) return hrc;
         channels = head.channels;
+        d->streams = head.stream_count;
+        d->coupled = head.coupled_count;
+        d->mapping.assign(head.mapping, head.mapping + head.channels);
         d->pre_skip = head.pre_skip;
         d->out_gain = head.output_gain_q8 ? std::pow(10.f, float(head.output_gain_q8) / (20.f * 256.f)) : 1.f;
     }
@@ -439,9 +449,70 @@ int opusgpu_decoder_configure(opusgpu_decoder *d)
     d->queue.clear();
     d->skip_left = d->pre_skip;
     d->channels = channels;
-    int rc = opusgpu_batch_create(&d->batch, 1, channels, d->device);
+    if (e.empty()) { d->streams = 1; d->coupled = 1; d->mapping = {0, 1}; }
+    delete d->batch_mono;
+    d->batch_mono = nullptr;
+    const bool multi = d->streams > 1 || channels > 2;
+    int rc = OPUSGPU_OK;
+    if (!multi) rc = opusgpu_batch_create(&d->batch, 1, channels, d->device);
+    else {
+        if (d->coupled) rc = opusgpu_batch_create(&d->batch, d->coupled, 2, d->device);
+        if (!rc && d->streams > d->coupled) rc = opusgpu_batch_create(&d->batch_mono, d->streams - d->coupled, 1, d->device);
+    }
     d->configured = rc == OPUSGPU_OK;
     return rc;
+}
+
+// One multistream packet: `streams` Opus packets back to back, all but the last self-delimiting (RFC 7845 5.1.1 / RFC 6716
+// Appendix B), decoded side by side as the streams of the batch and dealt to the output channels by the mapping table.
+static int send_multistream(opusgpu_decoder *d, const uint8_t *pkt, size_t len, std::vector<float> &out, size_t *nsamples)
+{
+    const uint32_t S = d->streams;
+    std::vector<std::vector<uint8_t>> sub(S);
+    std::vector<const uint8_t *> pk(S, nullptr);
+    std::vector<uint32_t> ln(S, 0);
+    std::vector<int32_t> err(S, 0);
+    if (len) {                                          // (len == 0: the whole packet is lost -- every stream conceals)
+        size_t pos = 0;
+        for (uint32_t s = 0; s < S; s++) {
+            if (s + 1 < S) {
+                int used = 0;
+                const int rc = og::undelimit_packet(pkt + pos, int(std::min<size_t>(len - pos, 0x7FFFFFFF)), sub[s], &used);
+                if (rc) return rc;
+                pos += size_t(used);
+                if (pos >= len) return OPUSGPU_INVALID_DATA;
+            } else {
+                sub[s].assign(pkt + pos, pkt + len);
+            }
+            pk[s] = sub[s].data();
+            ln[s] = uint32_t(sub[s].size());
+        }
+    }
+    const uint32_t M = d->coupled;
+    int rc = OPUSGPU_OK;
+    if (M && (rc = opusgpu_batch_send(d->batch, pk.data(), ln.data(), nullptr, M, err.data()))) return rc;
+    if (S > M && (rc = opusgpu_batch_send(d->batch_mono, pk.data() + M, ln.data() + M, nullptr, S - M, err.data() + M))) return rc;
+    for (uint32_t s = 0; s < S; s++) if (err[s]) return err[s];
+    if (M && (rc = opusgpu_batch_decode(d->batch))) return rc;             // both batches' kernels are in flight before the first read
+    if (S > M && (rc = opusgpu_batch_decode(d->batch_mono))) return rc;
+    std::vector<float> dec(size_t(OPUSGPU_MAX_FRAME) * 2);
+    size_t n = 0;
+    for (uint32_t s = 0; s < S; s++) {
+        size_t ns = 0;
+        const int cs = s < M ? 2 : 1;                   // channels of this stream's decoder
+        if ((rc = opusgpu_batch_read(s < M ? d->batch : d->batch_mono, s < M ? s : s - M, dec.data(), dec.size(), &ns))) return rc;
+        if (s == 0) { n = ns; out.assign(n * d->channels, 0.f); }
+        else if (ns != n) return OPUSGPU_INVALID_DATA;  // RFC 7845 5.1.1: every stream of a packet has the same duration
+        for (int c = 0; c < d->channels; c++) {
+            const uint32_t m = d->mapping[c];
+            if (m == 255) continue;
+            const uint32_t src = m < 2 * M ? m >> 1 : m - M, chn = m < 2 * M ? m & 1 : 0;
+            if (src != s) continue;
+            for (size_t i = 0; i < n; i++) out[i * d->channels + c] = dec[cs * i + chn];
+        }
+    }
+    *nsamples = n;
+    return OPUSGPU_OK;
 }
 
 int opusgpu_decoder_send_packet(opusgpu_decoder *d, const uint8_t *pkt, size_t len)
@@ -449,17 +520,23 @@ int opusgpu_decoder_send_packet(opusgpu_decoder *d, const uint8_t *pkt, size_t l
     if (!d) return OPUSGPU_BAD_ARG;
     if (!d->configured) return OPUSGPU_CONFIG_INCOMPLETE;   // the reference unwraps None here (decoder.rs:49-50)
     if (len > 0xFFFFFFFFu) return OPUSGPU_INVALID_DATA;
-    const uint8_t *pk[1] = {pkt};
-    uint32_t ln[1] = {uint32_t(len)};
-    int32_t err = 0;
-    int rc = opusgpu_batch_send(d->batch, pk, ln, nullptr, 1, &err);
-    if (rc) return rc;
-    if (err) return err;
-    if ((rc = opusgpu_batch_decode(d->batch))) return rc;
-    std::vector<float> out(size_t(OPUSGPU_MAX_FRAME) * d->channels);
+    std::vector<float> out;
     size_t n = 0;
-    if ((rc = opusgpu_batch_read(d->batch, 0, out.data(), out.size(), &n))) return rc;
-    out.resize(n * d->channels);
+    int rc;
+    if (d->streams > 1 || d->channels > 2) {
+        if ((rc = send_multistream(d, pkt, len, out, &n))) return rc;
+    } else {
+        const uint8_t *pk[1] = {pkt};
+        uint32_t ln[1] = {uint32_t(len)};
+        int32_t err = 0;
+        rc = opusgpu_batch_send(d->batch, pk, ln, nullptr, 1, &err);
+        if (rc) return rc;
+        if (err) return err;
+        if ((rc = opusgpu_batch_decode(d->batch))) return rc;
+        out.resize(size_t(OPUSGPU_MAX_FRAME) * d->channels);
+        if ((rc = opusgpu_batch_read(d->batch, 0, out.data(), out.size(), &n))) return rc;
+        out.resize(n * d->channels);
+    }
     if (d->skip_left) {                                 // RFC 7845 4.2: the first pre_skip samples are decoder warm-up
         const size_t drop = std::min<size_t>(d->skip_left, n);
         out.erase(out.begin(), out.begin() + drop * d->channels);

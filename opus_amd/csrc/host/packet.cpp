@@ -114,4 +114,69 @@ int parse_packet(const uint8_t *buf, int len, Packet *pk)
     return OPUSGPU_OK;
 }
 
+// RFC 6716 Appendix B: a self-delimiting packet (every stream but the last of a multistream packet, RFC 7845 5.1.1) carries
+// the length of its last frame as well, so that its end can be found.  Rewrites the one at buf as the ordinary packet with
+// the same frames into `out` and reports how many bytes it took.  0 on success.
+int undelimit_packet(const uint8_t *buf, int len, std::vector<uint8_t> &out, int *consumed)
+{
+    out.clear();
+    if (!buf || len < 2) return OPUSGPU_INVALID_DATA;
+    Cursor c{buf, buf + 1, buf + len};
+    const int code = buf[0] & 3;
+    out.push_back(buf[0]);
+    auto copy = [&](int n) { if (n < 0 || n > c.left()) return false; out.insert(out.end(), c.p, c.p + n); c.p += n; return true; };
+    int n0, n1;
+    switch (code) {
+    case 0:
+        if (!c.frame_length(&n0) || !copy(n0)) return OPUSGPU_INVALID_DATA;
+        break;
+    case 1:
+        if (!c.frame_length(&n0) || !copy(2 * n0)) return OPUSGPU_INVALID_DATA;
+        break;
+    case 2: {
+        const uint8_t *l0 = c.p;
+        if (!c.frame_length(&n0)) return OPUSGPU_INVALID_DATA;
+        out.insert(out.end(), l0, c.p);                                    // the first frame's length stays
+        if (!c.frame_length(&n1) || !copy(n0 + n1)) return OPUSGPU_INVALID_DATA;
+        break;
+    }
+    default: {
+        if (c.left() < 1) return OPUSGPU_INVALID_DATA;
+        const int fc = *c.p;
+        const bool vbr = fc & 0x80, padded = fc & 0x40;
+        const int count = fc & 0x3F;
+        if (count == 0) return OPUSGPU_INVALID_DATA;
+        if (!copy(1)) return OPUSGPU_INVALID_DATA;
+        int padding = 0;
+        if (padded) {
+            int b;
+            do {
+                if (c.left() < 1) return OPUSGPU_INVALID_DATA;
+                b = *c.p;
+                padding += b == 255 ? 254 : b;
+                copy(1);
+            } while (b == 255);
+        }
+        int total = 0;
+        if (vbr) {
+            for (int i = 0; i + 1 < count; i++) {
+                const uint8_t *l = c.p;
+                if (!c.frame_length(&n0)) return OPUSGPU_INVALID_DATA;
+                out.insert(out.end(), l, c.p);
+                total += n0;
+            }
+            if (!c.frame_length(&n0)) return OPUSGPU_INVALID_DATA;          // the last frame's length: the added field
+            total += n0;
+        } else {
+            if (!c.frame_length(&n0)) return OPUSGPU_INVALID_DATA;          // every frame's length: the added field
+            total = n0 * count;
+        }
+        if (!copy(total) || !copy(padding)) return OPUSGPU_INVALID_DATA;
+        break;
+    }
+    }
+    *consumed = int(c.p - c.base);
+    return OPUSGPU_OK;
+}
+
 }  // namespace og

@@ -19,6 +19,9 @@ struct Packet {
 // 0 on success, negative OPUSGPU_* error otherwise (never aborts; packet.rs:215-225 panics instead)
 int parse_packet(const uint8_t *buf, int len, Packet *p);
 
+// RFC 6716 Appendix B self-delimiting packet at buf -> the ordinary packet with the same frames; *consumed = its size
+int undelimit_packet(const uint8_t *buf, int len, std::vector<uint8_t> &out, int *consumed);
+
 // ---- CELT: the sequential half of Celt::decode (src/celt/decoder.rs:2222-2323) ------------------
 struct CeltHostState {          // what must survive between frames on the host (celt/decoder.rs:34-88)
     int channels = 2;

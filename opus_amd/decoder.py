@@ -90,10 +90,12 @@ class Decoder:
         self._lib = A.load()
         self._h = C.c_void_p()
         _chk(self._lib.opusgpu_decoder_create(C.byref(self._h), device), "decoder_create")
-        self._buf = np.zeros(5760 * 2, np.float32)
+        self._buf = np.zeros(5760 * 8, np.float32)      # up to 8 channels (mapping family 1); grown on demand for family 255
 
     def set_extradata(self, extra):
         b = bytes(extra)
+        if len(b) > 9 and 5760 * b[9] > self._buf.size:
+            self._buf = np.zeros(5760 * b[9], np.float32)
         _chk(self._lib.opusgpu_decoder_set_extradata(self._h, b, len(b)), "set_extradata")
 
     def configure(self):

@@ -1,0 +1,111 @@
+"""Multistream packets and channel mapping families 1 / 255 (RFC 7845 5.1.1), where the reference ends in unimplemented!()
+(decoder.rs:151-157, :170-171).  The packets are assembled here from the reference's own vectors: one coupled (stereo)
+stream and one mono stream (fed stereo-coded packets, which its mono decoder down-mixes) per packet, the first made self-delimiting (RFC 6716 Appendix B) by the writer below; the
+expected output is the two streams decoded on their own by the oracle, dealt to the channels by the mapping table."""
+import struct
+
+import numpy as np
+import pytest
+
+import orc
+from gpu_util import check_pcm
+from opus_amd import Decoder, _abi as A, parse_packet
+
+
+def frame_len_bytes(n):
+    return bytes([n]) if n < 252 else bytes([252 + (n & 3), (n - (252 + (n & 3))) >> 2])
+
+
+def self_delimit(pkt):
+    """the ordinary packet pkt as a self-delimiting one (RFC 6716 Appendix B): the last frame's length is written as well"""
+    p = parse_packet(pkt)
+    toc, code = pkt[0], pkt[0] & 3
+    frames = [pkt[o: o + n] for o, n in p["frames"]]
+    if code == 0:
+        return bytes([toc]) + frame_len_bytes(len(frames[0])) + frames[0]
+    if code == 1:
+        return bytes([toc]) + frame_len_bytes(len(frames[0])) + frames[0] + frames[1]
+    if code == 2:
+        return bytes([toc]) + frame_len_bytes(len(frames[0])) + frame_len_bytes(len(frames[1])) + frames[0] + frames[1]
+    fc = pkt[1]
+    head = bytes([toc, fc])
+    pos = 2
+    if fc & 0x40:                                       # padding length bytes stay where they are
+        while True:
+            b = pkt[pos]
+            head += bytes([b])
+            pos += 1
+            if b != 255:
+                break
+    pad = pkt[len(pkt) - p["padding"]:] if p["padding"] else b""
+    if fc & 0x80:
+        lens = b"".join(frame_len_bytes(len(f)) for f in frames)
+    else:
+        lens = frame_len_bytes(len(frames[0]))
+    return head + lens + b"".join(frames) + pad
+
+
+def test_self_delimit_writer_lengths():
+    assert frame_len_bytes(0) == b"\x00" and frame_len_bytes(251) == b"\xfb"
+    for n in (252, 253, 255, 256, 1000, 1275):
+        b = frame_len_bytes(n)
+        assert len(b) == 2 and 252 <= b[0] and 4 * b[1] + b[0] == n
+
+
+def opus_head(channels, family, streams, coupled, mapping):
+    return b"OpusHead" + bytes([1, channels]) + struct.pack("<HIh", 0, 48000, 0) + bytes([family, streams, coupled]) + bytes(mapping)
+
+
+def pairs(n):
+    """(packet of the coupled stream, packet of the mono stream) of equal duration, both from vector 11 (stereo CELT, framing
+    codes 0-3, 20-60 ms per packet): the mono stream's are stereo-coded, so its mono decoder has to down-mix"""
+    v = [bytes(p) for p in orc.load_vectors(ids=[11])[11][1]]
+    dur = [parse_packet(p)["nframes"] * parse_packet(p)["frame_size"] for p in v]
+    out, used = [], set()
+    for i in range(len(v)):
+        j = next((j for j in range(len(v) // 2, len(v)) if j not in used and j != i and dur[j] == dur[i]), None)
+        if j is None:
+            continue
+        used.add(j)
+        out.append((v[i], v[j]))
+        if len(out) == n:
+            break
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("family,mapping", [(255, [0, 2, 1, 255]), (1, [0, 2, 1])])
+def test_multistream_packets(family, mapping):
+    pk = pairs(160)
+    assert len(pk) >= 100 and len({p[0][0] & 3 for p in pk}) >= 2, "several framing codes among the coupled stream's packets"
+    d = Decoder(0)
+    d.set_extradata(opus_head(len(mapping), family, 2, 1, mapping))
+    d.configure()
+    ra, rb = orc.Decoder(2), orc.Decoder(1)
+    for i, (pa, pb) in enumerate(pk):
+        lost = i % 53 == 40
+        d.send_packet(b"" if lost else self_delimit(pa) + pb)
+        out = d.receive_frame()
+        wa, wb = ra.decode(b"" if lost else pa), rb.decode(b"" if lost else pb)
+        dec = np.concatenate([wa, wb], axis=1)          # the decoded channel set: coupled stream L, R, then the mono stream
+        want = np.stack([dec[:, m] if m != 255 else np.zeros(len(dec), np.float32) for m in mapping], axis=1)
+        assert out.shape == want.shape, f"packet {i}"
+        check_pcm(want, out, f"packet {i}{' (lost)' if lost else ''}")
+
+
+def test_undelimit_round_trip():
+    """host framing: self-delimiting packet -> ordinary packet gives back the original bytes and the right length"""
+    import ctypes as C
+    lib = A.load()
+    for vid in (1, 10, 11):
+        for p in orc.load_vectors(ids=[vid], max_packets=400)[vid][1]:
+            p = bytes(p)
+            sd = self_delimit(p) + b"\xAA\xBB\xCC"      # something behind it, as the next stream would be
+            out = (C.c_uint8 * 2048)()
+            used, n = C.c_int(), C.c_size_t()
+            rc = lib.opusgpu_packet_undelimit(sd, len(sd), out, 2048, C.byref(n), C.byref(used))
+            assert rc == 0 and used.value == len(sd) - 3
+            got = bytes(out[: n.value])
+            a, b = parse_packet(got), parse_packet(p)
+            assert (a["nframes"], a["frame_size"], a["code"]) == (b["nframes"], b["frame_size"], b["code"])
+            assert [got[o: o + n] for o, n in a["frames"]] == [p[o: o + n] for o, n in b["frames"]]
