@@ -31,6 +31,13 @@ int StreamParser::parse(const uint8_t *pkt, size_t len, OgFrameInfo *frames, std
 {
     Packet p;
     if (len > 0x7FFFFFFF) return OPUSGPU_INVALID_DATA;
+    if (len > 0) {                                      // a packet of empty frames (TOC only: DTX, RFC 6716 3.2.1) is concealed as well,
+        int rc0 = parse_packet(pkt, int(len), &p);      // over the span its TOC names
+        if (rc0) return rc0;
+        bool empty = true;
+        for (int f = 0; f < p.nframes; f++) empty = empty && p.len[f] == 0;
+        if (empty) { last_packet_samples_ = p.nframes * p.frame_size; len = 0; }
+    }
     if (len == 0) {
         // A lost packet (or a DTX gap): minimal concealment; the reference has none (and panics on an empty packet,
         // packet.rs:215-225).  The span of the last packet is filled by silent CELT frames -- on the device the MDCT overlap of

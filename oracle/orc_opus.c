@@ -190,6 +190,12 @@ void orc_decoder_set_celt_trace(OrcDecoder *d, OrcCeltTrace *t) { orc_celt_set_t
 int orc_decoder_decode(OrcDecoder *d, const uint8_t *pkt, int len, float *pcm, int cap)
 {   /* decoder.rs:48-127 */
     OrcPacket p;
+    if (len > 0) {                                            /* a packet of empty frames (TOC only: DTX) is concealed as well */
+        if (orc_packet_parse(pkt, len, &p)) return -1;
+        int empty = 1;
+        for (int f = 0; f < p.nframes; f++) empty = empty && p.len[f] == 0;
+        if (empty) { d->last_frame_size = p.nframes * p.frame_size; len = 0; }
+    }
     if (len == 0) {
         /* A lost packet (or a DTX gap): minimal concealment, no counterpart in the reference (it panics on an empty packet,
            packet.rs:215-225).  The span of the last packet is filled by silent CELT frames -- the MDCT overlap of the last

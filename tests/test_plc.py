@@ -32,3 +32,15 @@ def test_loss_before_any_packet(emu):  # noqa: F811
     d, ref = EmuDecoder(emu, 2), orc.Decoder(2)
     out, want = d.decode(b""), ref.decode(b"")
     assert out.shape == want.shape == (960, 2) and not out.any() and not want.any()
+
+
+def test_dtx_packet_is_concealed_over_its_own_span(emu):  # noqa: F811
+    """a TOC-only packet (one empty frame: DTX, RFC 6716 3.2.1) conceals the duration its TOC names"""
+    _, pk = orc.load_vectors(ids=[4], max_packets=40)[4]
+    d, ref = EmuDecoder(emu, 2), orc.Decoder(2)
+    for p in pk:
+        check_pcm(ref.decode(p), d.decode(bytes(p)))
+    for toc, n in ((0x08, 960), (0x00, 480), (0x18, 2880), (0xF8, 960), (0xE0, 120)):
+        want, out = ref.decode(bytes([toc])), d.decode(bytes([toc]))
+        assert want.shape == out.shape == (n, 2)
+        check_pcm(want, out, f"TOC {toc:#x}")
