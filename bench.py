@@ -45,6 +45,9 @@ def parse_args():
     ap.add_argument("--split", type=int, default=1,
                     help="issue each step as this many independent sub-batches of streams, each on a HIP stream of its own "
                          "(the sub-batches share nothing: their kernels may run side by side)")
+    ap.add_argument("--workload", choices=["c2", "c3"], default="c2",
+                    help="c2 (default, the headline): BASELINE configs[1], synthetic CELT FB stereo 20 ms, 4096 streams per GPU; "
+                         "c3: BASELINE configs[2], SILK WB mono 20 ms, 16384 streams per GPU (SURVEY.md 8d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle comparison of the last step's PCM")
     ap.add_argument("--parse-only", action="store_true",
@@ -154,6 +157,153 @@ def parse_only(a, rank, world):
                                       f"{a.backend} only for the barrier and the max of the elapsed times"}}), flush=True)
 
 
+C3_STREAMS_PER_GPU = 16384
+# SURVEY.md 8(d), C3 (SILK WB mono 20 ms): side-info record 1 024 B (its stride there; the record here is 3 072 B)
+# + PCM write 960 x 4 + history `output` / `lpc_history` (322 + 16) f32 each, read + write, 5 408 B + resampler state 128 B
+C3_ALG_BYTES = 1024 + 3840 + 5408 + 128
+
+
+def c3_packets():
+    """the config-9 (SILK WB 20 ms) mono code-0 packets of RFC vectors 04 and 12, in file order"""
+    import struct
+    b = open(os.path.join(ROOT, "tests", "golden", "opus_vectors.bin"), "rb").read()
+    assert b[:8] == b"OPVEC1\0\0"
+    (nvec,) = struct.unpack_from("<I", b, 8)
+    p, pool = 12, {}
+    for _ in range(nvec):
+        vid, el = struct.unpack_from("<II", b, p); p += 8 + el
+        (npk,) = struct.unpack_from("<I", b, p); p += 4
+        for _ in range(npk):
+            (l,) = struct.unpack_from("<H", b, p); p += 2
+            pkt = b[p:p + l]; p += l
+            if vid in (4, 12) and (pkt[0] >> 3) == 9 and not (pkt[0] & 4) and (pkt[0] & 3) == 0:
+                pool.setdefault(vid, []).append(pkt)
+    return pool[4] + pool[12]
+
+
+def main_c3(a, rank, local_rank, world):
+    """--workload c3: one step = one 20 ms SILK frame of every stream = one opusgpu_launch_silk (og_silk_synth_kernel +
+    og_silk_output_kernel), side-info resident in HBM, mono PCM stays in HBM.  Same contract and fields as the headline."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from opus_amd import BatchDecoder, _abi as A, sharding
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(a.backend, device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    lib = A.load()
+    S = a.streams if a.streams != STREAMS_PER_GPU else C3_STREAMS_PER_GPU
+    K, W = a.steps, a.warmup
+    nsteps = K + W
+    pool = c3_packets()
+    ids = sharding.shard_stream_ids(rank, world, S)
+
+    def packet(s, k):                                   # stream s replays the pool from its own offset
+        return pool[(int(ids[s]) * 7919 + k) % len(pool)]
+
+    parser = BatchDecoder(S, 1, local_rank)             # host half only: packets -> OgSilkFrame records (stream, pcm_off filled in)
+    recs, t_parse = [], 0.0
+    for k in range(nsteps):
+        pk = [packet(s, k) for s in range(S)]
+        t0 = time.perf_counter()
+        errs = parser.send(pk)
+        t_parse += time.perf_counter() - t0
+        assert not any(errs)
+        _, _, silk = parser.sideinfo()
+        assert len(silk) == S
+        recs.append(torch.from_numpy(np.frombuffer(silk, dtype=np.uint8).copy()).to(dev))
+    parser.close()
+    state = torch.zeros(lib.opusgpu_silk_state_bytes(S), dtype=torch.uint8, device=dev)
+    pcm = torch.zeros(S * 960, dtype=torch.float32, device=dev)
+    strm = torch.cuda.Stream(dev)
+    ps = C.c_void_p(strm.cuda_stream)
+
+    def step(k):
+        rc = lib.opusgpu_launch_silk(recs[k].data_ptr(), S, state.data_ptr(), S, pcm.data_ptr(), 960, None, ps)
+        if rc:
+            raise RuntimeError(lib.opusgpu_last_error().decode())
+
+    torch.cuda.synchronize(dev)
+    for k in range(W):
+        step(k)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(strm)
+    for k in range(W, nsteps):
+        step(k)
+    ev1.record(strm)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    elapsed = sharding.max_over_ranks(time.perf_counter() - t0)
+    launch_s = ev0.elapsed_time(ev1) / K / 1e3          # both kernels of a launch, on the stream they run on
+    assert bool(torch.isfinite(pcm).all())
+    verify = None
+    if not a.no_verify:                                 # the last step's PCM of a few streams against the CPU oracle (bit-exact)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import orc
+        rows = pcm.view(S, 960).cpu().numpy()
+        sample = sorted({0, 1, S // 3, S // 2, 2 * S // 3, S - 1})
+        ok = True
+        for s in sample:
+            d = orc.Decoder(1)
+            for k in range(nsteps):
+                want = d.decode(packet(s, k))
+            ok = ok and bool(np.array_equal(want[:, 0], rows[s]))
+        verify = {"ok": ok, "streams": sample, "bar": "bit-exact vs the CPU oracle (SILK keeps the reference's operation order)"}
+        assert ok, "c3: PCM differs from the oracle"
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    alg = S * C3_ALG_BYTES
+    line = {"metric": "decoded audio-sec/sec (SILK WB mono 20 ms, 16384 streams)",
+            "value": round(sharding.aggregate_audio_seconds_per_second(world, S, K, FRAME_S, elapsed), 1), "unit": "audio-s/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "RFC 6716 vectors 04 / 12 replayed",
+            "verified": bool(verify and verify["ok"]), "verify": verify,
+            "config": {"workload": "BASELINE configs[2] (SURVEY.md 8d C3): SILK WB mono 20 ms, the config-9 mono packets of RFC vectors "
+                                   f"04 and 12 ({len(pool)} packets) looped with a per-stream offset, {S} streams per GPU, one frame per "
+                                   "stream per step; device-only: side-info pre-parsed and resident in HBM, mono PCM stays in HBM",
+                       "streams_per_gpu": S, "frame_ms": 20, "frames_per_stream_per_step": 1,
+                       "parallelism": f"streams sharded over {world} GPU(s), one process per GPU, no collective in the data path; "
+                                      "RCCL only for the barrier and the max of the elapsed times"},
+            "roofline": {"bound": "hbm", "achieved": round(alg / launch_s / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(alg / launch_s / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
+                         "kernel": "one opusgpu_launch_silk call: og_silk_synth_kernel + og_silk_output_kernel",
+                         "avg_launch_us": round(launch_s * 1e6, 2), "algorithmic_bytes_per_launch": alg},
+            "host_parse": {"value": round(S * nsteps * FRAME_S / t_parse, 1), "unit": "audio-s/s",
+                           "note": "packets -> side-info on the host threads (untimed in `value`)"}}
+    if not a.no_cpu_baseline:
+        from concurrent.futures import ThreadPoolExecutor
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import orc
+        cores = min(16, os.cpu_count() or 1)
+        nst, nfr = cores * 4, 400
+
+        def work(s):
+            d = orc.Decoder(1)
+            for k in range(nfr):
+                d.decode(packet(s, k))
+            return nfr
+        orc.lib()
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(cores) as ex:
+            done = sum(ex.map(work, range(nst)))
+        dt = time.perf_counter() - t0
+        line["cpu_baseline"] = {"value": round(done * FRAME_S / dt, 2), "unit": "audio-s/s", "cores": cores, "kind": "port",
+                                "sample": f"{nst} of the same streams x {nfr} frames on the CPU oracle (oracle/liborc.so, scalar C, -O2), "
+                                          "one stream per thread"}
+    print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     a = parse_args()
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
@@ -163,6 +313,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus:
         sys.exit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {a.gpus}")
+    if a.workload == "c3":
+        return main_c3(a, rank, local_rank, world)
     import numpy as np
     import torch
     import torch.distributed as dist

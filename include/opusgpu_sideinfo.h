@@ -158,6 +158,7 @@ typedef struct {             /* one SILK frame (mid + side) of one stream */
     float prev_w0, prev_w1;  /* the previous frame's weights, interpolated from (silk/decoder.rs:2015-2026) */
     uint32_t stream;         /* state slot / PCM row */
     uint32_t pcm_off;        /* first 48 kHz output sample (per channel) inside the stream's PCM row */
+    uint32_t pad_;           /* (32-byte head: the records, their channels and the excitation arrays are 16-byte aligned) */
     OgSilkChan ch[2];
 } OgSilkFrame;
 

@@ -45,7 +45,7 @@ class SilkChan(C.Structure):
 
 class SilkFrame(C.Structure):
     _fields_ = [("flags", C.c_uint8), ("bandwidth", C.c_uint8), ("f_size", C.c_uint16), ("w0", C.c_float),
-                ("w1", C.c_float), ("prev_w0", C.c_float), ("prev_w1", C.c_float), ("stream", C.c_uint32), ("pcm_off", C.c_uint32), ("ch", SilkChan * 2)]
+                ("w1", C.c_float), ("prev_w0", C.c_float), ("prev_w1", C.c_float), ("stream", C.c_uint32), ("pcm_off", C.c_uint32), ("pad_", C.c_uint32), ("ch", SilkChan * 2)]
 
 
 class FrameInfo(C.Structure):

@@ -44,13 +44,15 @@ static int silk_tables_for_device(int device, const OgSilkTables **out)
 OgSilkArrays silk_arrays(void *state, uint32_t nstreams)
 {
     OgSilkArrays A;
-    const size_t ns = 2 * size_t(nstreams);
+    const size_t ns = 2 * size_t(nstreams), nst = (ns + 63) / 64 * 64;      // slots, and slots rounded up to whole tiles
     float *p = (float *)state;
-    A.out = p; p += size_t(OG_SILK_OUT_ROWS) * ns;
-    A.lpc = p; p += 16 * ns;
-    A.res = p; p += size_t(OG_SILK_RES_ROWS) * ns;
-    A.rs_hist = p;
+    A.out = p; p += size_t(OG_SILK_OUT_ROWS) * nst;
+    A.lpc = p; p += 16 * nst;
+    A.res = p; p += size_t(OG_SILK_RES_ROWS) * nst;
+    A.rs_hist = p; p += size_t(nstreams) * 64;
+    A.frame = p;                                        // (16-byte aligned: every array before it is a multiple of four floats)
     A.nslots = uint32_t(ns);
+    A.nstreams = nstreams;
     return A;
 }
 
@@ -60,8 +62,8 @@ extern "C" {
 
 size_t opusgpu_silk_state_bytes(uint32_t nstreams)
 {
-    const size_t ns = 2 * size_t(nstreams);
-    return sizeof(float) * ((size_t(OG_SILK_OUT_ROWS) + 16 + OG_SILK_RES_ROWS) * ns + size_t(nstreams) * 64);
+    const size_t ns = 2 * size_t(nstreams), nst = (ns + 63) / 64 * 64;
+    return sizeof(float) * ((size_t(OG_SILK_OUT_ROWS) + 16 + OG_SILK_RES_ROWS) * nst + OG_SILK_FRAME_STRIDE * ns + size_t(nstreams) * 64);
 }
 
 int opusgpu_launch_silk(const OgSilkFrame *frames, uint32_t nframes, void *state, uint32_t nstreams, float *pcm,
