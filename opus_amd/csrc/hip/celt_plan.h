@@ -8,7 +8,7 @@
 //   * a task record per quant_band call (band, buffer): geometry of its fused Haar/Hadamard transform, where its
 //     lowband_out goes, where it folds from, and its dependency level (0 = no fill leaves; otherwise 1 + the level of
 //     any fill band it folds from, and past the dual -> intensity switch of `norm`);
-//   * the list of live fill leaves ("fill ops") with their starting seeds, ordered by level;
+//   * the list of live fill leaves ("fill ops") with their starting seeds, in decode order (a call's are consecutive);
 //   * the collapse masks of all bands and the seed the frame ends its bands with.
 // The frame kernel then runs level by level with no serial integer work left.
 #pragma once
@@ -16,12 +16,12 @@
 #include "../../../include/opusgpu.h"
 #include "celt_frame_types.h"
 
-struct OgTask {                       // one quant_band call = (band, buffer), task id = 2 * band + buffer; 16 bytes
+struct alignas(16) OgTask {           // one quant_band call = (band, buffer), task id = 2 * band + buffer; 16 bytes (one store)
     uint16_t boff, n;                 // first bin in the channel buffer, width
     uint16_t n0p, lowpos;             // OgXform.n0p; offset of the folding source in its norm row
     uint8_t flags, hm, slog, rctd;    // OG_T_*; OgXform.hm / .slog; recombine | time_divide << 4
     uint8_t norm_row, level;          // norm row lowband_out goes to (0xFF = none); dependency level
-    uint16_t ops;                     // its live fill leaves: first index in OgBandPlan.op | count << 10
+    uint16_t ops;                     // its live fill leaves (consecutive in OgBandPlan.op): first index | count << 10
 };
 enum { OG_T_ACTIVE = 1, OG_T_CHAIN = 2, OG_T_NEED_LB = 4, OG_T_LONG = 8, OG_T_LB_ROW1 = 16 };
 
@@ -47,12 +47,10 @@ struct alignas(16) OgBandPlan {
     uint32_t joint;                   // bit = band: coded jointly (mid / side), i.e. the frame kernel has a stereo merge to do
     uint32_t keep[2];                 // per buffer, bit = band: K1 (or the plan, for one-bin bands) wrote this band of the frame's
                                       // scratch row; the frame kernel reads every other bin as zero (bits 21..31 are zero)
-    uint16_t op_start[OG_MAXLEVEL + 2];    // ops of level l: op[op_start[l]] .. op[op_start[l + 1]]
     uint8_t order[44];                // active task ids sorted by level (band order inside a level)
     uint8_t task_start[OG_MAXLEVEL + 3];   // tasks of level l: order[task_start[l]] .. order[task_start[l + 1]]
     uint8_t pad2_[3];
-    OgFillOp op[OG_MAXLEAF];          // ordered by level, decode order inside a level
-    OgFillOp op_decode[OG_MAXLEAF];   // scratch: decode order
+    OgFillOp op[OG_MAXLEAF];          // decode order
 };
 #define OG_PLAN_HEAD_BYTES ((int)offsetof(OgBandPlan, op))
 
@@ -99,8 +97,7 @@ struct OgLaneScratch {                // u16 cells, cell i at p[i * stride] (lan
 OG_DEV void og_band_plan(const OgCeltHdr *h, const OgCeltLeaf *lv, const OgCeltConst &K, const uint32_t *la, const uint32_t *lc,
                          const uint32_t *cm_row, float *coef_row, OgBandPlan *P, OgLaneScratch sc)
 {
-    const OgLaneScratch tl = sc.at(0), blevel = sc.at(44), col0 = sc.at(65), col1 = sc.at(86),
-                        cursor = sc.at(131), tcur = sc.at(157);
+    const OgLaneScratch tl = sc.at(0), blevel = sc.at(44), col0 = sc.at(65), col1 = sc.at(86), tcur = sc.at(157);
     const int lm = h->lm, M = 1 << lm, start = h->start, end = h->end;
     const int C = (h->flags & OG_F_STEREO) ? 2 : 1;
     const int B = (h->flags & OG_F_TRANSIENT) ? M : 1;
@@ -202,6 +199,7 @@ OG_DEV void og_band_plan(const OgCeltHdr *h, const OgCeltLeaf *lv, const OgCeltC
                 const int g0 = bd.leaf0 + (slot ? bd.nx : 0), nfill = slot ? bd.fy : bd.fx;
                 int m = (int)cm_row[slot * 24 + i];     // PVQ leaves: expanded (and masks collected) by K1
                 int live = 0;
+                const int first_op = nops;
                 for (int l = 0; l < nfill && g0 + l < nleaves; l++) {
                     const OgCeltLeaf lf = lv[g0 + l];
                     const int Bl = 1 << (lf.meta & OG_L_LOGB_MASK), sh = lf.cmshift;
@@ -216,7 +214,7 @@ OG_DEV void og_band_plan(const OgCeltHdr *h, const OgCeltLeaf *lv, const OgCeltC
                         op.pos = (uint16_t)(slot * 960 + boff + lf.off);
                         op.n = (uint8_t)nn; op.flags = fold ? OG_OP_FOLD : 0;
                         op.level = (uint8_t)lvl; op.task = (uint8_t)(2 * i + slot); op.pad_[0] = op.pad_[1] = 0;
-                        P->op_decode[nops++] = op;
+                        P->op[nops++] = op;
                         live++;
                     }
                     m |= (fold ? fl : (1 << Bl) - 1) << sh;
@@ -225,7 +223,7 @@ OG_DEV void og_band_plan(const OgCeltHdr *h, const OgCeltLeaf *lv, const OgCeltC
                 for (int k = 0, Bk = B0[slot]; k < td[slot]; k++) { Bk >>= 1; m |= m >> Bk; }
                 for (int k = 0; k < rc[slot]; k++) m = K.bit_deinterleave[m & 255];
                 cm[slot] = m & ((1 << ((B0[slot] >> td[slot]) << rc[slot])) - 1);
-                t.ops = (uint16_t)(live << 10);     // the first index is filled in once the ops are sorted
+                t.ops = (uint16_t)(live << 10 | (live ? first_op : 0));
             }
             if (any_chain) blevel[i] = (uint8_t)lvl;
             if (lvl > maxlvl) maxlvl = lvl;
@@ -254,27 +252,13 @@ OG_DEV void og_band_plan(const OgCeltHdr *h, const OgCeltLeaf *lv, const OgCeltC
     P->nlevels = (uint8_t)maxlvl; P->merge_level = (uint8_t)merge_level;
     P->pad_[0] = P->pad_[1] = 0;
     P->keep[0] = keep0; P->keep[1] = keep1; P->joint = joint; P->plain[0] = plain0; P->plain[1] = plain1;
-    // counting sort of the ops by level (stable)
-    for (int l = 0; l <= OG_MAXLEVEL + 1; l++) cursor[l] = 0;
-    for (int j = 0; j < nops; j++) cursor[P->op_decode[j].level + 1]++;
-    for (int l = 0; l <= OG_MAXLEVEL; l++) cursor[l + 1] = (uint16_t)(cursor[l + 1] + cursor[l]);
-    for (int l = 0; l <= OG_MAXLEVEL + 1; l++) P->op_start[l] = cursor[l];
-    int prev_task = -1;
-    for (int j = 0; j < nops; j++) {
-        const OgFillOp op = P->op_decode[j];
-        const int at = cursor[op.level]++;
-        P->op[at] = op;
-        if (op.task != prev_task) {                     // a task's ops are consecutive before and after the (stable) sort
-            P->task[op.task].ops = (uint16_t)(P->task[op.task].ops | at);
-            prev_task = op.task;
-        }
-    }
     // counting sort of the active tasks by level (stable: band order inside a level)
-    for (int l = 0; l <= OG_MAXLEVEL + 2; l++) tcur[l] = 0;
+    // (levels above maxlvl hold nothing: the frame kernel reads task_start[0 .. nlevels + 1])
+    for (int l = 0; l <= maxlvl + 2; l++) tcur[l] = 0;
     for (int t = 0; t < 42; t++)
         if (tl[t] != 0xFF) tcur[tl[t] + 1]++;
-    for (int l = 0; l <= OG_MAXLEVEL + 1; l++) tcur[l + 1] = (uint16_t)(tcur[l + 1] + tcur[l]);
-    for (int l = 0; l <= OG_MAXLEVEL + 2; l++) P->task_start[l] = (uint8_t)tcur[l];
+    for (int l = 0; l <= maxlvl + 1; l++) tcur[l + 1] = (uint16_t)(tcur[l + 1] + tcur[l]);
+    for (int l = 0; l <= maxlvl + 2; l++) P->task_start[l] = (uint8_t)tcur[l];
     for (int t = 0; t < 42; t++)
         if (tl[t] != 0xFF) P->order[tcur[tl[t]]++] = (uint8_t)t;
     P->pad2_[0] = P->pad2_[1] = P->pad2_[2] = 0;

@@ -558,7 +558,17 @@ int celt_parse_frame(CeltHostState &st, RangeDec &rd, int N, int start, int end,
                     const bool fillleaf = l.k == 0 && !(l.meta & OG_L_N1);
                     return ((l.meta & OG_L_CH_Y) ? 2 : 0) + (fillleaf ? 0 : 1);
                 };
-                std::stable_sort(first, last, [&](const OgCeltLeaf &a, const OgCeltLeaf &c) { return key(a) < key(c); });
+                const size_t nl = size_t(last - first);
+                OgCeltLeaf tmp[64];
+                if (nl <= 64) {                         // stable four-bucket placement (a band has at most 2 x 16 leaves)
+                    int at[4] = {0, 0, 0, 0}, pos[4];
+                    for (size_t q = 0; q < nl; q++) at[key(first[q])]++;
+                    pos[0] = 0; pos[1] = at[0]; pos[2] = pos[1] + at[1]; pos[3] = pos[2] + at[2];
+                    for (size_t q = 0; q < nl; q++) tmp[pos[key(first[q])]++] = first[q];
+                    for (size_t q = 0; q < nl; q++) first[q] = tmp[q];
+                } else {
+                    std::stable_sort(first, last, [&](const OgCeltLeaf &a, const OgCeltLeaf &c) { return key(a) < key(c); });
+                }
                 int cnt[4] = {0, 0, 0, 0};
                 for (OgCeltLeaf *l = first; l != last; ++l) {
                     cnt[key(*l)]++;
