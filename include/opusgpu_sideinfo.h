@@ -36,8 +36,15 @@ enum {                       /* OgCeltBand.flags */
     OG_B_FOLD_Y = 512        /* same for the Y group (dual stereo only) */
 };
 
-typedef struct {             /* one band of one frame, 16 bytes */
-    uint16_t imid, iside;    /* Q15 cos/sin of theta (celt/decoder.rs:1564-1582) */
+#if defined(__cplusplus)
+#define OG_ALIGNED(n) alignas(n)
+#else
+#define OG_ALIGNED(n) _Alignas(n)
+#endif
+typedef struct {             /* one band of one frame, 16 bytes, dword-aligned (it sits at a multiple of 4 in OgCeltHdr: the
+                                kernels fetch it as four dwords instead of a dozen bytes and shorts) */
+    OG_ALIGNED(4) uint16_t imid;           /* Q15 cos/sin of theta (celt/decoder.rs:1564-1582) */
+    uint16_t iside;
     uint16_t flags;
     uint16_t leaf0;          /* the band's first leaf, relative to OgCeltHdr.leaf_begin.  The band's leaves are grouped:
                                 the nx leaves that write the X buffer, then the ny that write Y; inside each group the

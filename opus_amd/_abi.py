@@ -100,6 +100,8 @@ PROTOTYPES = {
     "opusgpu_batch_create": (C.c_int, [C.POINTER(_P), C.c_uint32, C.c_int, C.c_int]),
     "opusgpu_batch_destroy": (None, [_P]),
     "opusgpu_batch_send": (C.c_int, [_P, C.POINTER(C.c_char_p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_int32)]),
+    "opusgpu_batch_send_multi": (C.c_int, [_P, C.POINTER(C.c_char_p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32,
+                                           C.POINTER(C.c_int32)]),
     "opusgpu_batch_decode": (C.c_int, [_P]),
     "opusgpu_batch_sync": (C.c_int, [_P]),
     "opusgpu_batch_pcm": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_size_t), C.POINTER(C.POINTER(C.c_uint32))]),

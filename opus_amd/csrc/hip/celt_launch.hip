@@ -68,8 +68,8 @@ __global__ __launch_bounds__(256) void og_pvq_all_kernel(const OgLeafRef *__rest
 }
 
 // Band plan: one lane per frame (celt_plan.h), OG_PLAN_FPW frames per wavefront.  The per-lane code is one long serial
-// chain, so what it reads and indexes sits in LDS: the workgroup's headers (copied in coalesced; a lane's header is 167
-// dwords from its neighbour's, an odd stride, so the lanes' reads fall on distinct banks), the small constant tables, and
+// chain, so what it reads and indexes sits in LDS: the workgroup's headers (copied in coalesced; a lane's header is 188
+// dwords from its neighbour's), the small constant tables, and
 // a row of scratch cells per lane for the arrays it indexes at run time.
 #define OG_PLAN_FPW 16
 __global__ __launch_bounds__(64) void og_plan_kernel(const OgCeltHdr *__restrict__ hdr, const OgCeltLeaf *__restrict__ leaves,

@@ -61,6 +61,7 @@ struct ParsedPacket {                    // one thread-local parse result
     int rc = 0;                          // number of frames or error
     uint32_t stream = 0;
     int worker = 0;                      // whose local arrays fi[].celt_index / silk_index point into
+    uint32_t frame0 = 0;                 // Opus frames of the stream's earlier packets in this send (multi-packet sends)
     OgFrameInfo fi[48];
     size_t celt0 = 0, leaf0 = 0, silk0 = 0;   // offsets into the worker's local arrays
     size_t ncelt = 0, nleaf = 0, nsilk = 0;
@@ -167,6 +168,7 @@ struct opusgpu_batch {
     void *d_silk_state = nullptr;
     float *d_pcm = nullptr;
     size_t pcm_stride = 0;
+    uint32_t grouped_T = 0;                                 // the pending send is one launch of [stream][t] CELT records, t < grouped_T
     bool pending = false;
     hipEvent_t h2d_done = nullptr;                          // recorded behind the last H2D copy of batch_decode
     bool h2d_in_flight = false;                             // the pinned side-info may still be read by the copy engine
@@ -222,10 +224,11 @@ int opusgpu_batch_create(opusgpu_batch **out, uint32_t nstreams, int channels, i
 
 void opusgpu_batch_destroy(opusgpu_batch *b) { delete b; }
 
-int opusgpu_batch_send(opusgpu_batch *b, const uint8_t *const *pkts, const uint32_t *lens, const uint32_t *stream_ids,
-                       uint32_t n, int32_t *errors)
+// n streams, T consecutive packets each: packet t of the i-th stream of the call is pkts[i * T + t]
+static int batch_send_impl(opusgpu_batch *b, const uint8_t *const *pkts, const uint32_t *lens, const uint32_t *stream_ids,
+                           uint32_t n, uint32_t T, int32_t *errors)
 {
-    if (!b || (n && (!pkts || !lens))) return OPUSGPU_BAD_ARG;
+    if (!b || T == 0 || (n && (!pkts || !lens))) return OPUSGPU_BAD_ARG;
     std::fill(b->seen.begin(), b->seen.end(), 0);
     for (uint32_t i = 0; i < n; i++) {
         uint32_t s = stream_ids ? stream_ids[i] : i;
@@ -240,28 +243,48 @@ int opusgpu_batch_send(opusgpu_batch *b, const uint8_t *const *pkts, const uint3
         b->h2d_in_flight = false;
     }
     std::fill(b->nsamples.begin(), b->nsamples.end(), 0);
+    b->grouped_T = 0;
+    if (T > 1) {                                        // a stream's PCM row holds the whole send: T packets of up to 120 ms
+        const size_t need = size_t(T) * OPUSGPU_MAX_FRAME * b->channels;
+        if (need > b->pcm_stride) {
+            OG_HIP(hipSetDevice(b->device));
+            OG_HIP(hipStreamSynchronize(b->stream));
+            float *np = nullptr;
+            OG_HIP(hipMalloc((void **)&np, size_t(b->nstreams) * need * sizeof(float)));
+            OG_HIP(hipMemsetAsync(np, 0, size_t(b->nstreams) * need * sizeof(float), b->stream));
+            (void)hipFree(b->d_pcm);
+            b->d_pcm = np;
+            b->pcm_stride = need;
+        }
+    }
 
-    // ---- parse: static partition of the packets over the workers, one stream per task
+    // ---- parse: static partition of the streams over the workers, one stream per task
     if (!b->pool) b->pool.reset(new ParsePool(worker_count()));
     const int nw = std::max(1, std::min<int>(b->pool->size(), int(n)));
     std::vector<Worker> &workers = b->workers;
     std::vector<ParsedPacket> &parsed = b->parsed;
     if (int(workers.size()) < nw) workers.resize(nw);
-    if (parsed.size() < n) parsed.resize(n);
+    if (parsed.size() < size_t(n) * T) parsed.resize(size_t(n) * T);
     for (auto &W : workers) { W.celt.clear(); W.leaves.clear(); W.silk.clear(); }      // capacity stays
     const std::function<void(int)> run = [&](int w) {
         Worker &W = workers[w];
         const uint32_t lo = uint32_t(uint64_t(n) * w / nw), hi = uint32_t(uint64_t(n) * (w + 1) / nw);
         for (uint32_t i = lo; i < hi; i++) {
-            ParsedPacket &pp = parsed[i];
-            pp.stream = stream_ids ? stream_ids[i] : i;
-            pp.worker = w;
-            pp.celt0 = W.celt.size(); pp.leaf0 = W.leaves.size(); pp.silk0 = W.silk.size();
-            pp.rc = b->parsers[pp.stream].parse(pkts[i], lens[i], pp.fi, W.celt, W.leaves, W.silk);
-            if (pp.rc < 0) {                            // a bad packet never poisons the batch
-                W.celt.resize(pp.celt0); W.leaves.resize(pp.leaf0); W.silk.resize(pp.silk0);
+            uint32_t frames_before = 0;
+            for (uint32_t t = 0; t < T; t++) {
+                ParsedPacket &pp = parsed[size_t(i) * T + t];
+                pp.stream = stream_ids ? stream_ids[i] : i;
+                pp.worker = w;
+                pp.frame0 = frames_before;
+                pp.celt0 = W.celt.size(); pp.leaf0 = W.leaves.size(); pp.silk0 = W.silk.size();
+                pp.rc = b->parsers[pp.stream].parse(pkts[size_t(i) * T + t], lens[size_t(i) * T + t], pp.fi, W.celt, W.leaves, W.silk);
+                if (pp.rc < 0) {                        // a bad packet never poisons the batch
+                    W.celt.resize(pp.celt0); W.leaves.resize(pp.leaf0); W.silk.resize(pp.silk0);
+                } else {
+                    frames_before += uint32_t(pp.rc);
+                }
+                pp.ncelt = W.celt.size() - pp.celt0; pp.nleaf = W.leaves.size() - pp.leaf0; pp.nsilk = W.silk.size() - pp.silk0;
             }
-            pp.ncelt = W.celt.size() - pp.celt0; pp.nleaf = W.leaves.size() - pp.leaf0; pp.nsilk = W.silk.size() - pp.silk0;
         }
     };
     b->pool->run(nw, run);
@@ -289,14 +312,26 @@ int opusgpu_batch_send(opusgpu_batch *b, const uint8_t *const *pkts, const uint3
     // the frame's own CELT part, which adds onto the SILK output in hybrid mode, in 4f+2; redundant frames in 4f+0 / 4f+3).
     constexpr uint32_t RPF = OG_ROUNDS_PER_FRAME;
     uint32_t rounds = 0;
-    for (uint32_t i = 0; i < n; i++) if (parsed[i].rc > 0) rounds = std::max(rounds, RPF * uint32_t(parsed[i].rc));
+    const size_t np = size_t(n) * T;
+    for (size_t i = 0; i < np; i++) if (parsed[i].rc > 0) rounds = std::max(rounds, RPF * (parsed[i].frame0 + uint32_t(parsed[i].rc)));
+    // Fast path of a multi-packet send: every stream brought T packets of one CELT-only frame each (no SILK, no redundant
+    // frames).  The records are then laid out [stream][t] and the whole send is ONE launch in which a tail workgroup walks a
+    // stream's T frames in time order (frames_per_group = T), instead of T rounds of launches.
+    bool grouped = T > 1 && n > 0;
+    for (size_t i = 0; i < np && grouped; i++) {
+        const ParsedPacket &pp = parsed[i];
+        grouped = pp.rc == 1 && pp.fi[0].nsilk == 0 && pp.fi[0].has_celt == 1 &&
+                  (workers[pp.worker].celt[pp.fi[0].celt_index].spread >> OG_X_SHIFT) == (OG_ROUND_MAIN << (OG_ROUND_SHIFT - OG_X_SHIFT));
+    }
+    if (grouped) rounds = 1;
     std::vector<uint32_t> ccount(rounds + 1, 0), scount(rounds + 1, 0);
-    for (uint32_t i = 0; i < n; i++) {
+    for (size_t i = 0; i < np; i++) {
         const ParsedPacket &pp = parsed[i];
         for (int f = 0; f < pp.rc; f++) {
+            const uint32_t r0 = RPF * (pp.frame0 + uint32_t(f));
             for (uint32_t c = 0; c < pp.fi[f].has_celt; c++)
-                ccount[RPF * f + (workers[pp.worker].celt[pp.fi[f].celt_index + c].spread >> OG_ROUND_SHIFT)]++;
-            for (uint32_t k = 0; k < pp.fi[f].nsilk; k++) scount[RPF * f + k]++;
+                ccount[grouped ? 0 : r0 + (workers[pp.worker].celt[pp.fi[f].celt_index + c].spread >> OG_ROUND_SHIFT)]++;
+            for (uint32_t k = 0; k < pp.fi[f].nsilk; k++) scount[r0 + k]++;
         }
     }
     b->celt_round_off.assign(rounds + 1, 0);
@@ -309,11 +344,13 @@ int opusgpu_batch_send(opusgpu_batch *b, const uint8_t *const *pkts, const uint3
     for (int w = 0; w < nw; w++) {
         const uint32_t lo = uint32_t(uint64_t(n) * w / nw), hi = uint32_t(uint64_t(n) * (w + 1) / nw);
         for (uint32_t i = lo; i < hi; i++) {
-            const ParsedPacket &pp = parsed[i];
-            if (errors) errors[i] = pp.rc < 0 ? pp.rc : OPUSGPU_OK;
-            uint32_t pcm_off = 0;
-            for (int f = 0; f < pp.rc; f++) {
-                const OgFrameInfo &fi = pp.fi[f];
+          uint32_t pcm_off = 0;
+          for (uint32_t t = 0; t < T; t++) {
+            const ParsedPacket &pp = parsed[size_t(i) * T + t];
+            if (errors) errors[size_t(i) * T + t] = pp.rc < 0 ? pp.rc : OPUSGPU_OK;
+            for (int f0 = 0; f0 < pp.rc; f0++) {
+                const OgFrameInfo &fi = pp.fi[f0];
+                const uint32_t f = pp.frame0 + uint32_t(f0);
                 uint32_t sub = 0;                       // SILK frames of one Opus frame are consecutive 20 ms pieces
                 for (uint32_t k = 0; k < fi.nsilk; k++) {
                     OgSilkFrame sf = workers[w].silk[fi.silk_index + k];
@@ -327,11 +364,13 @@ int opusgpu_batch_send(opusgpu_batch *b, const uint8_t *const *pkts, const uint3
                     hd.stream = pp.stream;
                     hd.pcm_off += pcm_off;              // the parser left the offset inside the Opus frame
                     hd.leaf_begin = uint32_t(hd.leaf_begin + leaf_base[w]);
-                    b->h_celt.p[cfill[RPF * f + (hd.spread >> OG_ROUND_SHIFT)]++] = hd;
+                    // (grouped: the workers' blocks of streams are consecutive, so filling in order gives [stream][t])
+                    b->h_celt.p[cfill[grouped ? 0 : RPF * f + (hd.spread >> OG_ROUND_SHIFT)]++] = hd;
                 }
                 pcm_off += fi.frame_size;
             }
             b->nsamples[pp.stream] = pcm_off;
+          }
         }
     }
     b->h_celt.n = tot_celt;
@@ -348,8 +387,21 @@ int opusgpu_batch_send(opusgpu_batch *b, const uint8_t *const *pkts, const uint3
         b->ref_round_off[r + 1] = nref;
     }
     b->h_refs.n = nref;
+    b->grouped_T = grouped ? T : 0;
     b->pending = true;
     return OPUSGPU_OK;
+}
+
+extern "C" int opusgpu_batch_send(opusgpu_batch *b, const uint8_t *const *pkts, const uint32_t *lens, const uint32_t *stream_ids,
+                                  uint32_t n, int32_t *errors)
+{
+    return batch_send_impl(b, pkts, lens, stream_ids, n, 1, errors);
+}
+
+extern "C" int opusgpu_batch_send_multi(opusgpu_batch *b, const uint8_t *const *pkts, const uint32_t *lens, const uint32_t *stream_ids,
+                                        uint32_t nstreams, uint32_t packets_per_stream, int32_t *errors)
+{
+    return batch_send_impl(b, pkts, lens, stream_ids, nstreams, packets_per_stream, errors);
 }
 
 int opusgpu_batch_decode(opusgpu_batch *b)
@@ -381,7 +433,7 @@ int opusgpu_batch_decode(opusgpu_batch *b)
         if (sn && (rc = opusgpu_launch_silk(b->d_silk.p + s0, sn, b->d_silk_state, b->nstreams, b->d_pcm, b->pcm_stride, nullptr, b->stream)))
             return rc;
         const uint32_t c0 = b->celt_round_off[r], cn = b->celt_round_off[r + 1] - c0;
-        if (cn && (rc = opusgpu_launch_celt(b->d_celt.p + c0, b->d_leaves.p, cn, 1, b->d_refs.p + b->ref_round_off[r],
+        if (cn && (rc = opusgpu_launch_celt(b->d_celt.p + c0, b->d_leaves.p, cn, b->grouped_T ? b->grouped_T : 1, b->d_refs.p + b->ref_round_off[r],
                                             &b->ref_classes[4 * r], b->d_work.p, b->d_celt_state, b->d_pcm,
                                             b->pcm_stride, nullptr, b->stream)))
             return rc;

@@ -147,6 +147,20 @@ class BatchDecoder:
         _chk(self._lib.opusgpu_batch_send(self._h, arr, lens, ids, n, errs), "batch_send")
         return list(errs)
 
+    def send_multi(self, packets, stream_ids=None):
+        """packets: list (one entry per stream) of equally long lists of consecutive packets; returns per-stream lists of
+        error codes.  The stream's PCM row then holds the packets' output back to back."""
+        n, T = len(packets), len(packets[0])
+        assert all(len(p) == T for p in packets)
+        keep = [bytes(p) for row in packets for p in row]
+        arr = (C.c_char_p * (n * T))(*keep)
+        lens = (C.c_uint32 * (n * T))(*[len(p) for p in keep])
+        ids = (C.c_uint32 * n)(*stream_ids) if stream_ids is not None else None
+        errs = (C.c_int32 * (n * T))()
+        _chk(self._lib.opusgpu_batch_send_multi(self._h, arr, lens, ids, n, T, errs), "batch_send_multi")
+        self._cap = max(getattr(self, "_cap", 5760), 5760 * T)
+        return [list(errs[i * T:(i + 1) * T]) for i in range(n)]
+
     def decode(self, sync=True):
         _chk(self._lib.opusgpu_batch_decode(self._h), "batch_decode")
         if sync:
@@ -156,7 +170,7 @@ class BatchDecoder:
         _chk(self._lib.opusgpu_batch_sync(self._h), "batch_sync")
 
     def read(self, stream):
-        buf = np.zeros(5760 * self.channels, np.float32)
+        buf = np.zeros(getattr(self, "_cap", 5760) * self.channels, np.float32)
         n = C.c_size_t()
         _chk(self._lib.opusgpu_batch_read(self._h, stream, buf.ctypes.data, buf.size, C.byref(n)), "batch_read")
         return buf[: n.value * self.channels].reshape(n.value, self.channels).copy()

@@ -290,3 +290,36 @@ def test_bench_launch_shape_against_oracle():
         assert bool(torch.isfinite(pcm).all()), f"launch {k}"
         rows = pcm.view(S, stride)[sample].cpu().numpy()
         oracle_check_last_step({s: rows[i] for i, s in enumerate(sample)}, pk, sample, (k + 1) * T, T, f"launch {k}")
+
+
+@pytest.mark.parametrize("kind", ["celt", "mixed"])
+def test_multi_packet_send(kind):
+    """opusgpu_batch_send_multi: T consecutive packets per stream in one call.  CELT-only single-frame packets take the
+    one-launch path (a tail workgroup walks a stream's T frames); anything else the round-by-round path.  Against the oracle
+    and against the same packets sent one per call."""
+    T, ns = 6, 24
+    if kind == "celt":
+        pk = synth.celt_fb_stereo_packets(range(ns), 3 * T, 160)
+        rows = [[pk[s, f].tobytes() for f in range(3 * T)] for s in range(ns)]
+    else:
+        vec = orc.load_vectors(ids=[10, 12], max_packets=900)
+        rows = [[bytes(p) for p in vec[10 if s % 2 else 12][1][100 + 11 * s: 100 + 11 * s + 3 * T]] for s in range(ns)]
+        rows[3][4] = b""                               # a lost packet among them
+    multi, single = BatchDecoder(ns, 2, 0), BatchDecoder(ns, 2, 0)
+    refs = [orc.Decoder(2) for _ in range(ns)]
+    for k in range(3):
+        errs = multi.send_multi([r[k * T:(k + 1) * T] for r in rows])
+        assert not any(any(e) for e in errs)
+        multi.decode()
+        outs = [[] for _ in range(ns)]
+        for t in range(T):
+            assert not any(single.send([r[k * T + t] for r in rows]))
+            single.decode()
+            for s in range(ns):
+                outs[s].append(single.read(s))
+        for s in range(ns):
+            want = np.concatenate([refs[s].decode(p) for p in rows[s][k * T:(k + 1) * T]])
+            got = multi.read(s)
+            assert got.shape == want.shape, (s, k)
+            check_pcm(want, got, f"{kind} stream {s} send {k}")
+            check_pcm(np.concatenate(outs[s]), got, f"{kind} stream {s} send {k}: multi against one packet per call")
