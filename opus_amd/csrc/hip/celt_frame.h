@@ -834,44 +834,83 @@ OG_DEV void og_celt_spectrum(const OgCeltHdr *hg, const OgBandPlan *plan, const 
     //      leaves included: opusgpu_sort_pvq_leaves lists them and K1 stores zeros) and the one-bin bands' signs (plan kernel).
     //      Everything else in the row is left over from earlier launches and is replaced by zero here, so nobody has to hand
     //      the rows back zero-filled.
-    const int lm0 = hg->lm & 3;
+    //      Two rounds of loads, each issued as a whole: (1) everything whose address is known from the kernel arguments -- header,
+    //      plan head, first fill ops, constants, the row -- and, per wavefront, the few header / plan words the rest depends on,
+    //      which then reach scalar registers by a lane read (a chain of dependent fetches here cost each workgroup several memory
+    //      round trips before its first useful instruction); (2) the band of every bin and its sqrt(width), which depend on LM.
     struct OgRow2 { OgF4 v[2], sq[2]; uint32_t bb[2]; };
+    struct OgStage { uint32_t hv, pv, ov, sel; float em; uint32_t eb, wd; };
     OG_LANE_VAR(OgRow2, rowv);
-    // which (buffer, band)s of the row K1 / the plan wrote: the plan's keep masks, cut to the coded bands (a silent frame's row
-    // is untouched); uniform
-    //      The calls with nothing to transform (most of a non-transient frame's) are finished here as well: their lowband_out
-    //      = sqrt(N0) x goes to the folding source rows, zero everywhere else (the plan's `plain` masks).
-    uint32_t keepm[2], plainm[2];
-    int norm_off0;
+    OG_LANE_VAR(OgStage, stv);
+    OG_LANE_VAR(uint32_t, selv);
+    static_assert(sizeof(OgCeltHdr) / 4 <= OG_WG && OG_PLAN_HEAD_BYTES / 4 <= OG_WG && OG_LDS_OPS * 4 <= OG_WG, "one dword per lane");
+    OG_LANES_BEGIN_NOSYNC(tid)
     {
-        const uint32_t flags0 = OG_U32(hg->flags), b_lo = OG_U32(hg->start), b_hi = (flags0 & OG_F_SILENCE) ? 0u : OG_U32(hg->end);
+        const uint32_t *src = (const uint32_t *)hg, *ps = (const uint32_t *)plan;       // plan: head, then the first fill ops
+        OgStage st = {0, 0, 0, 0, 0.f, 0, 0};
+        if (tid < (int)(sizeof(OgCeltHdr) / 4)) st.hv = src[tid];
+        if (tid < OG_PLAN_HEAD_BYTES / 4) st.pv = ps[tid];
+        if (tid < OG_LDS_OPS * 4) st.ov = ps[OG_PLAN_HEAD_BYTES / 4 + tid];
+        if (tid < 24) { st.em = T->k.emeans[tid]; st.eb = T->k.ebands[tid]; st.wd = T->k.width[tid]; }
+        const int l = tid & 63;                         // per wavefront: lanes 0..8 header head, 9..13 plain / joint / keep masks, 16..21 band edges
+        uint32_t sel = 0;
+        if (l < 9) sel = src[l];
+        else if (l < 14) sel = ps[offsetof(OgBandPlan, plain) / 4 + (l - 9)];
+        else if (l >= 16 && l < 22) sel = ((const uint32_t *)T->k.ebands)[l - 16];
+        OG_LV(stv) = st;
+        OG_LV(selv) = sel;
+#pragma unroll
+        for (int j = 0; j < 2; j++) {                   // 2 * 960 / 4 = 480 pieces of 16 bytes; piece p = bins 4p' .. 4p'+3 of buffer p / 240
+            const int p = tid + j * OG_WG;
+            OG_LV(rowv).v[j] = OgF4{0.f, 0.f, 0.f, 0.f};
+            OG_LV(rowv).bb[j] = 0xFFFFFFFFu;
+            if (p < 480) {
+                OG_LV(rowv).v[j] = ((const OgF4 *)coef_row)[p];
+                // round (2) issued early for LM = 3 (20 ms frames, the usual case): fetched again below if the frame's LM differs
+                OG_LV(rowv).bb[j] = ((const uint32_t *)T->bin2band[3])[p >= 240 ? p - 240 : p];
+                OG_LV(rowv).sq[j] = ((const OgF4 *)T->bin2sq[3])[p >= 240 ? p - 240 : p];
+            }
+        }
+    }
+    OG_LANES_END_NOSYNC
+    static_assert(offsetof(OgBandPlan, keep) == offsetof(OgBandPlan, plain) + 12 && offsetof(OgBandPlan, joint) == offsetof(OgBandPlan, plain) + 8,
+                  "plain[2], joint, keep[2] are consecutive words");
+    static_assert(offsetof(OgCeltHdr, lm) == 18 && offsetof(OgCeltHdr, flags) == 19 && offsetof(OgCeltHdr, start) == 20 && offsetof(OgCeltHdr, end) == 21,
+                  "header words 4 and 5");
+    // which (buffer, band)s of the row K1 / the plan wrote: the plan's keep masks, cut to the coded bands (a silent frame's row
+    // is untouched); uniform.  The calls with nothing to transform (most of a non-transient frame's) are finished here as well:
+    // their lowband_out = sqrt(N0) x goes to the folding source rows, zero everywhere else (the plan's `plain` masks).
+    uint32_t keepm[2], plainm[2];
+    int norm_off0, lm0;
+    {
+        const uint32_t w4 = OG_LANE_GET0(selv, 4), w5 = OG_LANE_GET0(selv, 5);
+        lm0 = (int)((w4 >> 16) & 3u);
+        const uint32_t flags0 = w4 >> 24, b_lo = w5 & 255u, b_hi = (flags0 & OG_F_SILENCE) ? 0u : (w5 >> 8) & 255u;
         const uint32_t coded = b_hi > b_lo ? ((b_hi >= 21u ? (1u << 21) : (1u << b_hi)) - 1u) & ~((1u << b_lo) - 1u) : 0u;
-        keepm[0] = OG_U32(plan->keep[0]) & coded;
-        keepm[1] = OG_U32(plan->keep[1]) & coded;
-        plainm[0] = OG_U32(plan->plain[0]) & coded;
-        plainm[1] = OG_U32(plan->plain[1]) & coded;
-        norm_off0 = (int)(OG_U32(T->k.ebands[b_lo < 21u ? b_lo : 20u]) << lm0);
+        plainm[0] = OG_LANE_GET0(selv, 9) & coded;
+        plainm[1] = OG_LANE_GET0(selv, 10) & coded;
+        // (lane 11: joint)
+        keepm[0] = OG_LANE_GET0(selv, 12) & coded;
+        keepm[1] = OG_LANE_GET0(selv, 13) & coded;
+        const uint32_t bl = b_lo < 21u ? b_lo : 20u;
+        norm_off0 = (int)(((OG_LANE_GET0(selv, 16 + (bl >> 2)) >> (8 * (bl & 3u))) & 255u) << lm0);
     }
     OG_LANES_BEGIN(tid)
     {
-        const uint32_t *src = (const uint32_t *)hg;
-        uint32_t *dst = (uint32_t *)&L.hdr;
-        for (int p = tid; p < (int)(sizeof(OgCeltHdr) / 4); p += OG_WG) dst[p] = src[p];
-        const uint32_t *ps = (const uint32_t *)plan;    // head, then the first fill ops
-        for (int p = tid; p < OG_PLAN_HEAD_BYTES / 4; p += OG_WG) L.w.b.plan_head[p] = ps[p];
-        uint32_t *od = (uint32_t *)L.w.b.ops;
-        for (int p = tid; p < OG_LDS_OPS * 4; p += OG_WG) od[p] = ps[OG_PLAN_HEAD_BYTES / 4 + p];
+        const OgStage st = OG_LV(stv);
+        if (tid < (int)(sizeof(OgCeltHdr) / 4)) ((uint32_t *)&L.hdr)[tid] = st.hv;
+        if (tid < OG_PLAN_HEAD_BYTES / 4) L.w.b.plan_head[tid] = st.pv;
+        if (tid < OG_LDS_OPS * 4) ((uint32_t *)L.w.b.ops)[tid] = st.ov;
+        if (tid < 24) { L.k.emeans[tid] = st.em; L.k.ebands[tid] = (uint8_t)st.eb; L.k.width[tid] = (uint8_t)st.wd; }
     }
-    if (tid < 24) { L.k.emeans[tid] = T->k.emeans[tid]; L.k.ebands[tid] = T->k.ebands[tid]; L.k.width[tid] = T->k.width[tid]; }
+    if (lm0 != 3) {                                     // (uniform)
 #pragma unroll
-    for (int j = 0; j < 2; j++) {                       // 2 * 960 / 4 = 480 pieces of 16 bytes; piece p = bins 4p' .. 4p'+3 of buffer p / 240
-        const int p = tid + j * OG_WG;
-        OG_LV(rowv).v[j] = OgF4{0.f, 0.f, 0.f, 0.f};
-        OG_LV(rowv).bb[j] = 0xFFFFFFFFu;
-        if (p < 480) {
-            OG_LV(rowv).v[j] = ((const OgF4 *)coef_row)[p];
-            OG_LV(rowv).bb[j] = ((const uint32_t *)T->bin2band[lm0])[p >= 240 ? p - 240 : p];     // the four bins' bands
-            OG_LV(rowv).sq[j] = ((const OgF4 *)T->bin2sq[lm0])[p >= 240 ? p - 240 : p];
+        for (int j = 0; j < 2; j++) {
+            const int p = tid + j * OG_WG;
+            if (p < 480) {
+                OG_LV(rowv).bb[j] = ((const uint32_t *)T->bin2band[lm0])[p >= 240 ? p - 240 : p];     // the four bins' bands
+                OG_LV(rowv).sq[j] = ((const OgF4 *)T->bin2sq[lm0])[p >= 240 ? p - 240 : p];
+            }
         }
     }
     for (int p = tid + (960 - norm_off0); p < 800; p += OG_WG) L.R[p] = L.R[800 + p] = 0.f;   // norm bins no piece below covers (none when the frame starts at band 0)

@@ -83,6 +83,9 @@ template <int MASK> OG_DEV float og_lane_xor(float v)
 }
 #define OG_WAVE_XCH(dst, src, MEMBER, MASK) dst = og_lane_xor<MASK>(src MEMBER);
 #define OG_WAVE_GET(src, L) __builtin_amdgcn_readlane((int)(src), (L))
+// OG_LANE_GET0(var, L): lane L's value of an OG_LANE_VAR that every wavefront of the workgroup filled alike (by lane index
+// inside the wave), as a uniform value; used between OG_LANES regions (no barrier needed: a wave reads its own copy)
+#define OG_LANE_GET0(var, L) ((uint32_t)__builtin_amdgcn_readlane((int)(var), (int)(L)))
 #define OG_WAVE_REF(T, name) T &name
 // One-instruction approximations (1 ulp) for the CELT kernels, whose results are compared with a tolerance (the library
 // forms expand to a dozen or more instructions each: range checks, Newton steps, denormal scaling).  Arguments are normal
@@ -125,6 +128,7 @@ OG_DEV float og_fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
 #define OG_WAVE_FENCE
 #define OG_WAVE_XCH(dst, src, MEMBER, MASK) { for (int l_ = 0; l_ < 64; l_++) dst[l_] = src[l_ ^ (MASK)] MEMBER; }
 #define OG_WAVE_GET(src, L) ((int)src[L])
+#define OG_LANE_GET0(var, L) ((uint32_t)var[L])
 #define OG_WAVE_REF(T, name) T (&name)[64]
 OG_DEV float og_frsq(float x) { return 1.f / sqrtf(x); }
 OG_DEV float og_frcp(float x) { return 1.f / x; }
