@@ -668,67 +668,102 @@ OG_DEV void og_anti_collapse(OgBandCtx &c)
                                                         //  header carries its own seed)
 
 // ------------------------------------------------------------------------------------------------
-// K3: IMDCT as an N/4-point complex FFT (N/4 = 60 * 2^lm = 15 * 2^(lm+2): radix 4/2/3/5 Stockham
-// stages ping-ponging between two LDS buffers), RFC 6716 4.3.7.
+// K3: IMDCT as an n-point complex FFT, n = 60 * 2^k = 15 * 2^(k+2) (RFC 6716 4.3.7), in two or three Stockham passes that
+// ping-pong between two LDS buffers: a 15-point pass first (no twiddles in front of a first pass; inside, 3 x 5 by the
+// prime-factor mapping, so none there either -- index permutations of registers only), then radix 4 and / or 8.  A pass
+// holds its R points in registers as packed complex pairs (wg.h); one to three of the four wavefronts are busy in it, and
+// which ones rotates with `rot` (the frame number) so that a CU's SIMDs share the load over its resident workgroups.
+// (Fewer, fatter passes are what cuts instructions: this kernel is VALU-bound, and a pass costs its address arithmetic and
+// twiddle fetches per work item whatever the radix.  Cross-lane butterflies (DPP) in place of an LDS pass cost MORE VALU
+// instructions than the pass they replace -- an exchange is a VALU move per value, an LDS access is not -- so the passes stay.)
 OG_DEV OgCf og_cmul(OgCf a, OgCf b) { OgCf r; r.r = a.r * b.r - a.i * b.i; r.i = a.r * b.i + a.i * b.r; return r; }
 
 // floor(q / d) for the small non-negative integers used as work-item indices (q < 4096, d <= 480): exact
 OG_DEV int og_div(int q, float inv_d) { return (int)(((float)q + 0.5f) * inv_d); }
 
-// One Stockham stage of radix R over TT = 2^tsh transforms of size n.  The transforms are interleaved: element i of
-// transform t sits at i * TT + t in both buffers, so a work item q splits into (transform, butterfly) with a mask and a
-// shift and its inputs are q, q + per * TT, ...  Ns = product of the radices already done: a power of two for R = 2, 3, 4
-// (stage order 4, 4, 2, 3, 5) and n/5 for the final R = 5 stage, so the position inside the sub-transform is a mask too.
-template <int R, int n, int Ns>      // compile-time sizes: every per-stage constant folds
-OG_DEV void og_wg_fft_stage(const OgCf *src, OgCf *dst, int tsh, const OgCf *W)
+OG_DEV void og_dft3(OgC2 &a, OgC2 &b, OgC2 &c)          // forward (e^{-2 pi i / 3}), in place
 {
+    const OgC2 s = b + c, d = og_c2_scale(b - c, 0.86602540378443864676f);
+    const OgC2 m = og_c2_fma(s, -0.5f, a);
+    a = a + s;
+    b = og_c2_sub_i(m, d);
+    c = og_c2_add_i(m, d);
+}
+OG_DEV void og_dft5(OgC2 &v0, OgC2 &v1, OgC2 &v2, OgC2 &v3, OgC2 &v4)
+{
+    const float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f;
+    const float s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;
+    const OgC2 s14 = v1 + v4, d14 = v1 - v4, s23 = v2 + v3, d23 = v2 - v3;
+    const OgC2 p1 = og_c2_fma(s23, c2, og_c2_fma(s14, c1, v0)), p2 = og_c2_fma(s23, c1, og_c2_fma(s14, c2, v0));
+    const OgC2 q1 = og_c2_fma(d23, s2, og_c2_scale(d14, s1)), q2 = og_c2_fma(d23, -s1, og_c2_scale(d14, s2));
+    v0 = v0 + s14 + s23;
+    v1 = og_c2_sub_i(p1, q1);
+    v4 = og_c2_add_i(p1, q1);
+    v2 = og_c2_sub_i(p2, q2);
+    v3 = og_c2_add_i(p2, q2);
+}
+
+// One Stockham pass of radix R over TT = 2^tsh transforms of size n.  The transforms are interleaved: element i of
+// transform t sits at i * TT + t in both buffers, so a work item q splits into (transform, butterfly j) with a mask and a
+// shift and its inputs are q, q + per * TT, ...  Ns = product of the radices already done; k = j mod Ns is the position
+// inside the sub-transform (0 in a first pass, j in a last one); outputs go Ns apart from (j - k) R + k.
+template <int R, int n, int Ns>      // compile-time sizes: every per-pass constant folds
+OG_DEV void og_wg_fft_stage(const OgCf *src_, OgCf *dst_, int tsh, const OgCf *W_, int rot)
+{
+    static_assert(R == 4 || R == 8 || R == 15, "radices of 15 * 2^k");
     constexpr int per = n / R, wstep = 480 / (Ns * R);
-    const int total = per << tsh, rstep = per << tsh, ostep = Ns << tsh;
+    constexpr bool last = Ns * R == n;
+    const OgC2 *src = (const OgC2 *)src_, *W = (const OgC2 *)W_;
+    OgC2 *dst = (OgC2 *)dst_;
+    const int total = per << tsh, rstep = per << tsh, ostep = Ns << tsh;          // total <= OG_WG: at most one item per lane
     OG_LANES_BEGIN(tid)
-    for (int q = tid; q < total; q += OG_WG) {
+    const int q = (tid + rot) & (OG_WG - 1);
+    if (q < total) {
         const int t = q & ((1 << tsh) - 1), j = q >> tsh;
-        const int k = R == 5 ? j : (j & (Ns - 1));
-        const int kw = OG_MUL24(k, wstep);
-        OgCf v[R];
+        const int k = Ns == 1 ? 0 : last ? j : j - Ns * og_div(j, 1.f / Ns);
+        OgC2 v[R];
 #pragma unroll
-        for (int r = 0; r < R; r++) {
-            v[r] = src[q + r * rstep];
-            if (r) v[r] = og_cmul(v[r], W[r * kw]);
+        for (int r = 0; r < R; r++) v[r] = src[q + r * rstep];
+        if (Ns > 1) {
+            const int kw = OG_MUL24(k, wstep);
+#pragma unroll
+            for (int r = 1; r < R; r++) v[r] = og_c2_mul(v[r], W[r * kw]);
         }
-        OgCf *o = dst + ((((j - k) * R + k) << tsh) + t);
-        const int Ns_ = ostep;                          // outputs Ns apart in their transform = Ns * TT apart here
-        if (R == 2) {
-            o[0].r = v[0].r + v[1].r; o[0].i = v[0].i + v[1].i;
-            o[Ns_].r = v[0].r - v[1].r; o[Ns_].i = v[0].i - v[1].i;
-        } else if (R == 4) {
-            OgCf t0 = {v[0].r + v[2].r, v[0].i + v[2].i}, t1 = {v[0].r - v[2].r, v[0].i - v[2].i};
-            OgCf t2 = {v[1].r + v[3 % R].r, v[1].i + v[3 % R].i}, t3 = {v[1].i - v[3 % R].i, v[3 % R].r - v[1].r};   // -i (v1 - v3)
-            o[0].r = t0.r + t2.r; o[0].i = t0.i + t2.i;
-            o[Ns_].r = t1.r + t3.r; o[Ns_].i = t1.i + t3.i;
-            o[2 * Ns_].r = t0.r - t2.r; o[2 * Ns_].i = t0.i - t2.i;
-            o[3 * Ns_].r = t1.r - t3.r; o[3 * Ns_].i = t1.i - t3.i;
-        } else if (R == 3) {
-            const float s3 = 0.86602540378443864676f;
-            OgCf s = {v[1].r + v[2 % R].r, v[1].i + v[2 % R].i}, d = {v[1].r - v[2 % R].r, v[1].i - v[2 % R].i};
-            OgCf m = {v[0].r - 0.5f * s.r, v[0].i - 0.5f * s.i};
-            OgCf e = {s3 * d.i, -s3 * d.r};                                                          // -i s3 d
-            o[0].r = v[0].r + s.r; o[0].i = v[0].i + s.i;
-            o[Ns_].r = m.r + e.r; o[Ns_].i = m.i + e.i;
-            o[2 * Ns_].r = m.r - e.r; o[2 * Ns_].i = m.i - e.i;
+        OgC2 *o = dst + ((((j - k) * R + k) << tsh) + t);
+        if (R == 4) {
+            const OgC2 t0 = v[0] + v[2], t1 = v[0] - v[2], t2 = v[1] + v[3 % R], t3 = v[1] - v[3 % R];
+            o[0] = t0 + t2;
+            o[ostep] = og_c2_sub_i(t1, t3);
+            o[2 * ostep] = t0 - t2;
+            o[3 * ostep] = og_c2_add_i(t1, t3);
+        } else if (R == 8) {
+            const float h = 0.70710678118654752440f;
+            const OgC2 a0 = v[0] + v[4 % R], a1 = v[0] - v[4 % R], a2 = v[2 % R] + v[6 % R], a3 = v[2 % R] - v[6 % R];
+            const OgC2 a4 = v[1] + v[5 % R], a5 = v[1] - v[5 % R], a6 = v[3 % R] + v[7 % R], a7 = v[3 % R] - v[7 % R];
+            const OgC2 b0 = a0 + a2, b2 = a0 - a2, b1 = og_c2_sub_i(a1, a3), b3 = og_c2_add_i(a1, a3);
+            const OgC2 b4 = a4 + a6, b6 = a4 - a6, b5 = og_c2_sub_i(a5, a7), b7 = og_c2_add_i(a5, a7);
+            const OgC2 u5 = og_c2_scale(og_c2_sub_i(b5, b5), h);          //  e^{-i pi/4}  b5
+            const OgC2 u7 = og_c2_scale(og_c2_add_i(b7, b7), h);          // -e^{-3i pi/4} b7
+            o[0] = b0 + b4;
+            o[ostep] = b1 + u5;
+            o[2 * ostep] = og_c2_sub_i(b2, b6);
+            o[3 * ostep] = b3 - u7;
+            o[4 * ostep] = b0 - b4;
+            o[5 * ostep] = b1 - u5;
+            o[6 * ostep] = og_c2_add_i(b2, b6);
+            o[7 * ostep] = b3 + u7;
         } else {
-            const float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f;
-            const float s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;
-            OgCf s14 = {v[1].r + v[4 % R].r, v[1].i + v[4 % R].i}, d14 = {v[1].r - v[4 % R].r, v[1].i - v[4 % R].i};
-            OgCf s23 = {v[2 % R].r + v[3 % R].r, v[2 % R].i + v[3 % R].i}, d23 = {v[2 % R].r - v[3 % R].r, v[2 % R].i - v[3 % R].i};
-            OgCf p1 = {v[0].r + c1 * s14.r + c2 * s23.r, v[0].i + c1 * s14.i + c2 * s23.i};
-            OgCf p2 = {v[0].r + c2 * s14.r + c1 * s23.r, v[0].i + c2 * s14.i + c1 * s23.i};
-            OgCf q1 = {s1 * d14.r + s2 * d23.r, s1 * d14.i + s2 * d23.i};
-            OgCf q2 = {s2 * d14.r - s1 * d23.r, s2 * d14.i - s1 * d23.i};
-            o[0].r = v[0].r + s14.r + s23.r; o[0].i = v[0].i + s14.i + s23.i;
-            o[Ns_].r = p1.r + q1.i; o[Ns_].i = p1.i - q1.r;                                           // p1 - i q1
-            o[4 * Ns_].r = p1.r - q1.i; o[4 * Ns_].i = p1.i + q1.r;
-            o[2 * Ns_].r = p2.r + q2.i; o[2 * Ns_].i = p2.i - q2.r;
-            o[3 * Ns_].r = p2.r - q2.i; o[3 * Ns_].i = p2.i + q2.r;
+            // 15 = 3 x 5, prime-factor mapping: input n = 5 n1 + 3 n2, output k = 10 k1 + 6 k2 (mod 15) -- five 3-point
+            // transforms over n1, then three 5-point ones over n2, in place
+#pragma unroll
+            for (int n2 = 0; n2 < 5; n2++) og_dft3(v[(3 * n2) % R], v[(5 + 3 * n2) % R], v[(10 + 3 * n2) % R]);
+#pragma unroll
+            for (int k1 = 0; k1 < 3; k1++)
+                og_dft5(v[(5 * k1) % R], v[(5 * k1 + 3) % R], v[(5 * k1 + 6) % R], v[(5 * k1 + 9) % R], v[(5 * k1 + 12) % R]);
+#pragma unroll
+            for (int k1 = 0; k1 < 3; k1++)
+#pragma unroll
+                for (int k2 = 0; k2 < 5; k2++) o[((10 * k1 + 6 * k2) % 15) * ostep] = v[(5 * k1 + 3 * k2) % R];
         }
     }
     OG_LANES_END
@@ -823,7 +858,8 @@ OG_DEV void og_wave_comb_filter(float *y, int T0, int T1, int n, float g0, float
 // mono output).  Uniform arguments; every lane of the workgroup calls it.  `dbg` pointers are already offset to this
 // frame (any may be null).
 OG_DEV void og_celt_spectrum(const OgCeltHdr *hg, const OgBandPlan *plan, const OgCeltTables *T, OgCeltLds &L, const OgCeltDebug &dbg,
-                             float *coef_row, int stop = 0 /* profiling aid: leave after stage `stop` (tools/stage_insts.sh) */)
+                             float *coef_row, int stop = 0 /* profiling aid: leave after stage `stop` (tools/stage_insts.sh) */,
+                             int rot = 0 /* which wavefronts take the narrow FFT passes: any number, e.g. the frame's */)
 {
     float *dbg_norm = dbg.norm, *dbg_freq = dbg.freq;
     uint8_t *dbg_collapse = dbg.collapse;
@@ -986,7 +1022,7 @@ OG_DEV void og_celt_spectrum(const OgCeltHdr *hg, const OgBandPlan *plan, const 
     // the CC * B transforms of the frame are interleaved in the FFT buffers: work item q = bin i of transform t = ch * B + b
     // at q = i * TT + t, TT = CC * B = 2^tsh; it reads MDCT bins 2i and NB-1-2i of block b, which sit at j1, j2 in X[ch]
     const int bsh = transient ? lm : 0, tsh = bsh + (CC == 2), tmask = (1 << tsh) - 1;
-    struct OgTw4 { OgCf w[4]; uint32_t bands[4]; };
+    struct OgTw4 { OgC2 w[4]; uint32_t bands[4]; };
     OG_LANE_VAR(OgTw4, twr);
     OG_LANES_BEGIN(tid)
     for (int t = tid; t < 48; t += OG_WG) {             // per-(channel, band) gains 2^(E + mean), zero outside [start, end)
@@ -1002,12 +1038,12 @@ OG_DEV void og_celt_spectrum(const OgCeltHdr *hg, const OgBandPlan *plan, const 
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int q = tid + j * OG_WG;
-        OG_LV(twr).w[j] = OgCf{0.f, 0.f};
+        OG_LV(twr).w[j] = OgC2{0.f, 0.f};
         OG_LV(twr).bands[j] = 0;
         if (q < CC * (N >> 1)) {
             const int i = q >> tsh, b = (q & tmask) & (B - 1);
             const int j1 = ((2 * i) << bsh) + b, j2 = N - B - ((2 * i) << bsh) + b;
-            OG_LV(twr).w[j] = T->tw[(n4 - 60) + i];
+            OG_LV(twr).w[j] = ((const OgC2 *)T->tw)[(n4 - 60) + i];
             const uint32_t b1 = T->bin2band[lm0][j1], b2 = T->bin2band[lm0][j2];
             OG_LV(twr).bands[j] = (b1 == 255u ? 23u : b1) | (b2 == 255u ? 23u : b2) << 8;       // gband[.][21..23] = 0
         }
@@ -1051,42 +1087,33 @@ OG_DEV void og_celt_spectrum(const OgCeltHdr *hg, const OgBandPlan *plan, const 
                 x1 = L.X[0][j1] * L.gband[0][b1];
                 x2 = L.X[0][j2] * L.gband[0][b2];
             }
-            const OgCf w = OG_LV(twr).w[j];
-            OgCf z;
-            z.r = x1 * w.r + x2 * w.i;
-            z.i = x2 * w.r - x1 * w.i;
-            bufA[q] = z;
+            ((OgC2 *)bufA)[q] = og_c2_mulc(OgC2{x1, x2}, OG_LV(twr).w[j]);     // (x1 w.r + x2 w.i, x2 w.r - x1 w.i)
         }
     }
     OG_LANES_END
     {
-        // 60 * 2^k points = radix 4 (, 4) (, 2), 3, 5 stages; `src` ends up holding the spectrum
+        // 60 * 2^k points = passes of radix 15, (4,) 4 or 8; `src` ends up holding the spectrum
         OgCf *src = bufA, *dst = bufB;
+        const int r1 = (rot & 3) << 6, r2 = ((rot + 1) & 3) << 6, r3 = ((rot + 2) & 3) << 6;
         switch (n4) {
         case 60:
-            og_wg_fft_stage<4, 60, 1>(bufA, bufB, tsh, ldsW);
-            og_wg_fft_stage<3, 60, 4>(bufB, bufA, tsh, ldsW);
-            og_wg_fft_stage<5, 60, 12>(bufA, bufB, tsh, ldsW);
-            src = bufB; dst = bufA;
+            og_wg_fft_stage<15, 60, 1>(bufA, bufB, tsh, ldsW, r1);
+            og_wg_fft_stage<4, 60, 15>(bufB, bufA, tsh, ldsW, r2);
             break;
         case 120:
-            og_wg_fft_stage<4, 120, 1>(bufA, bufB, tsh, ldsW);
-            og_wg_fft_stage<2, 120, 4>(bufB, bufA, tsh, ldsW);
-            og_wg_fft_stage<3, 120, 8>(bufA, bufB, tsh, ldsW);
-            og_wg_fft_stage<5, 120, 24>(bufB, bufA, tsh, ldsW);
+            og_wg_fft_stage<15, 120, 1>(bufA, bufB, tsh, ldsW, r1);
+            og_wg_fft_stage<8, 120, 15>(bufB, bufA, tsh, ldsW, r2);
             break;
         case 240:
-            og_wg_fft_stage<4, 240, 1>(bufA, bufB, tsh, ldsW);
-            og_wg_fft_stage<4, 240, 4>(bufB, bufA, tsh, ldsW);
-            og_wg_fft_stage<3, 240, 16>(bufA, bufB, tsh, ldsW);
-            og_wg_fft_stage<5, 240, 48>(bufB, bufA, tsh, ldsW);
+            og_wg_fft_stage<15, 240, 1>(bufA, bufB, tsh, ldsW, r1);
+            og_wg_fft_stage<4, 240, 15>(bufB, bufA, tsh, ldsW, r2);
+            og_wg_fft_stage<4, 240, 60>(bufA, bufB, tsh, ldsW, r3);
+            src = bufB; dst = bufA;
             break;
         default:
-            og_wg_fft_stage<4, 480, 1>(bufA, bufB, tsh, ldsW);
-            og_wg_fft_stage<4, 480, 4>(bufB, bufA, tsh, ldsW);
-            og_wg_fft_stage<2, 480, 16>(bufA, bufB, tsh, ldsW);
-            og_wg_fft_stage<3, 480, 32>(bufB, bufA, tsh, ldsW);
-            og_wg_fft_stage<5, 480, 96>(bufA, bufB, tsh, ldsW);
+            og_wg_fft_stage<15, 480, 1>(bufA, bufB, tsh, ldsW, r1);
+            og_wg_fft_stage<4, 480, 15>(bufB, bufA, tsh, ldsW, r2);
+            og_wg_fft_stage<8, 480, 60>(bufA, bufB, tsh, ldsW, r3);
             src = bufB; dst = bufA;
             break;
         }
@@ -1099,8 +1126,8 @@ OG_DEV void og_celt_spectrum(const OgCeltHdr *hg, const OgBandPlan *plan, const 
         for (int j = 0; j < 4; j++) {
             const int q = tid + j * OG_WG;
             if (q < CC * (N >> 1)) {
-                const OgCf Z = src[q], w = OG_LV(twr).w[j];
-                const float vr = Z.r * w.r + Z.i * w.i, vi = Z.i * w.r - Z.r * w.i;
+                const OgC2 v = og_c2_mulc(((const OgC2 *)src)[q], OG_LV(twr).w[j]);
+                const float vr = v.x, vi = v.y;
                 const int t = q & tmask, k = q >> tsh, ch = t >> bsh, b = t & (B - 1);
                 float *D = coef_row + ch * 960 + OG_MUL24(NB, b);
                 D[2 * k] = vi;

@@ -122,7 +122,7 @@ __global__ __launch_bounds__(OG_WG) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     d.freq = dbg.freq ? dbg.freq + (size_t)f * 1920 : nullptr;
     d.collapse = dbg.collapse ? dbg.collapse + (size_t)f * 42 : nullptr;
     d.cycles = dbg.cycles ? dbg.cycles + (size_t)f * 64 : nullptr;
-    og_celt_spectrum(hdr + f, og_work_plan(work, f), T, L, d, og_work_coef(work, f), stop);
+    og_celt_spectrum(hdr + f, og_work_plan(work, f), T, L, d, og_work_coef(work, f), stop, (int)f);
 }
 
 __global__ __launch_bounds__(OG_WGT) void og_celt_tail_kernel(const OgCeltHdr *__restrict__ hdr, uint32_t nframes, uint32_t frames_per_group,

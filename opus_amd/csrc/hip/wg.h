@@ -94,6 +94,39 @@ OG_DEV float og_frsq(float x) { return __builtin_amdgcn_rsqf(x); }
 OG_DEV float og_frcp(float x) { return __builtin_amdgcn_rcpf(x); }
 OG_DEV float og_fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 OG_DEV float og_fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
+// Complex numbers as packed pairs (re in .x, im in .y: one 64-bit register pair): sums, differences and scalings are single
+// v_pk_* instructions as the compiler emits them; the forms below need the operand selectors (which half of a source feeds
+// which half of the result) and per-half negation that it does not derive -- two instructions per complex product
+// instead of six, one for a sum with a factor of +-i instead of three.
+typedef float OgC2 __attribute__((ext_vector_type(2)));
+OG_DEV OgC2 og_c2_mul(OgC2 a, OgC2 w)                  // a w
+{
+    OgC2 t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(w));                          // (a.i w.i, a.i w.r)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[0,0,1]" : "=v"(r) : "v"(a), "v"(w), "v"(t));   // (a.r w.r - t.lo, a.r w.i + t.hi)
+    return r;
+}
+OG_DEV OgC2 og_c2_mulc(OgC2 a, OgC2 w)                 // a conj(w)
+{
+    OgC2 t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(w));                          // (a.i w.i, a.r w.i)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1] neg_hi:[0,0,1]" : "=v"(r) : "v"(a), "v"(w), "v"(t));   // (a.r w.r + t.lo, a.i w.r - t.hi)
+    return r;
+}
+OG_DEV OgC2 og_c2_sub_i(OgC2 a, OgC2 b)                // a - i b
+{
+    OgC2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+OG_DEV OgC2 og_c2_add_i(OgC2 a, OgC2 b)                // a + i b
+{
+    OgC2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+OG_DEV OgC2 og_c2_scale(OgC2 a, float s) { return a * s; }
+OG_DEV OgC2 og_c2_fma(OgC2 a, float s, OgC2 b) { return __builtin_elementwise_fma(a, OgC2{s, s}, b); }     // a s + b
 #else
 #include <math.h>
 #define OG_DEV static inline
@@ -134,6 +167,16 @@ OG_DEV float og_frsq(float x) { return 1.f / sqrtf(x); }
 OG_DEV float og_frcp(float x) { return 1.f / x; }
 OG_DEV float og_fsqrt(float x) { return sqrtf(x); }
 OG_DEV float og_fexp2(float x) { return exp2f(x); }
+struct OgC2 { float x, y; };
+OG_DEV OgC2 operator+(OgC2 a, OgC2 b) { return OgC2{a.x + b.x, a.y + b.y}; }
+OG_DEV OgC2 operator-(OgC2 a, OgC2 b) { return OgC2{a.x - b.x, a.y - b.y}; }
+OG_DEV OgC2 operator*(OgC2 a, OgC2 b) { return OgC2{a.x * b.x, a.y * b.y}; }      // per component, as on the packed pair
+OG_DEV OgC2 og_c2_mul(OgC2 a, OgC2 w) { return OgC2{a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x}; }
+OG_DEV OgC2 og_c2_mulc(OgC2 a, OgC2 w) { return OgC2{a.x * w.x + a.y * w.y, a.y * w.x - a.x * w.y}; }
+OG_DEV OgC2 og_c2_sub_i(OgC2 a, OgC2 b) { return OgC2{a.x + b.y, a.y - b.x}; }
+OG_DEV OgC2 og_c2_add_i(OgC2 a, OgC2 b) { return OgC2{a.x - b.y, a.y + b.x}; }
+OG_DEV OgC2 og_c2_scale(OgC2 a, float s) { return OgC2{a.x * s, a.y * s}; }
+OG_DEV OgC2 og_c2_fma(OgC2 a, float s, OgC2 b) { return OgC2{a.x * s + b.x, a.y * s + b.y}; }
 #endif
 // floor(a / d) for small non-negative integers (a < 4096, 0 < d <= 1024) through the float reciprocal: (a + 1/2) / d is at
 // least 1 / (2d) away from an integer, far more than the product's rounding error

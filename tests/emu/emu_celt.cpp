@@ -42,7 +42,7 @@ extern "C" int emu_launch_celt(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, u
             d.freq = dbg->freq ? dbg->freq + (size_t)f * 1920 : nullptr;
             d.collapse = dbg->collapse ? dbg->collapse + (size_t)f * 42 : nullptr;
         }
-        og_celt_spectrum(hdr + f, og_work_plan(work.data(), f), &T, L, d, og_work_coef(work.data(), f));
+        og_celt_spectrum(hdr + f, og_work_plan(work.data(), f), &T, L, d, og_work_coef(work.data(), f), 0, (int)f);
     }
     std::memset(&Lt, 0xFF, sizeof Lt);
     std::memcpy(Lt.window, T.window, sizeof Lt.window);
