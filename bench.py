@@ -42,6 +42,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames-per-step", type=int, default=8, help="consecutive frames of every stream decoded per step")
     ap.add_argument("--streams", type=int, default=STREAMS_PER_GPU, help="streams per GPU (BASELINE: 4096)")
+    ap.add_argument("--no-t1", action="store_true", help="skip the one-frame-per-launch leg (reported as `t1`)")
     ap.add_argument("--split", type=int, default=1,
                     help="issue each step as this many independent sub-batches of streams, each on a HIP stream of its own "
                          "(the sub-batches share nothing: their kernels may run side by side)")
@@ -420,6 +421,39 @@ def main():
         verified = {"ok": True, "streams": sample, "frames_each": T, "max_scaled_err": float(f"{worst:.3e}"),
                     "bar": "max abs err <= 1e-4 (scaled by the reference peak when that exceeds 1), SNR >= 90 dB vs the CPU oracle"}
 
+    # ---- the same streams one frame per launch (frames_per_group = 1: what a caller that sends every packet as it arrives
+    #      gets), outside the headline's timed region and reported beside it
+    t1 = None
+    if world == 1 and not a.no_t1 and P == 1:
+        w1 = min(4, nframes // 4)
+        n1 = min(24, nframes - w1)
+        parser = BatchDecoder(S, 2, local_rank)
+        hs1, _ = stepmod.build_celt_steps(parser, packets[:, :n1 + w1], 1, n1 + w1)
+        parser.close()
+        d1 = [dict(hdr=torch.from_numpy(st.hdr).to(dev), leaves=torch.from_numpy(st.leaves).to(dev), refs=torch.from_numpy(st.refs).to(dev),
+                   classes=st.classes) for st in hs1]
+        state1 = torch.zeros_like(state)
+        pt = parts[0]
+
+        def step1(f):
+            d = d1[f]
+            check(lib.opusgpu_launch_celt_pvq(d["hdr"].data_ptr(), d["leaves"].data_ptr(), S, d["refs"].data_ptr(), d["classes"],
+                                              pt["work"].data_ptr(), None, pt["ps"]))
+            check(lib.opusgpu_launch_celt_spectrum(d["hdr"].data_ptr(), S, pt["work"].data_ptr(), None, pt["ps"]))
+            check(lib.opusgpu_launch_celt_tail(d["hdr"].data_ptr(), S, 1, pt["work"].data_ptr(), state1.data_ptr(), pcm.data_ptr(), stride,
+                                               None, pt["ps"]))
+        for f in range(w1):
+            step1(f)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for f in range(n1):
+            step1(w1 + f)
+        torch.cuda.synchronize(dev)
+        e1 = time.perf_counter() - t0
+        t1 = {"value": round(S * n1 * FRAME_S / e1, 1), "unit": "audio-s/s", "frames_per_stream_per_step": 1, "steps": n1, "warmup": w1,
+              "ms_per_step": round(e1 / n1 * 1e3, 4), "note": "same streams, one 20 ms frame per stream per launch (frames_per_group = 1)"}
+        del d1, state1
+
     avg_kernel_s = elapsed / K                               # the calls run back to back on one stream: per call = step time
     avg_alg = sum(alg_bytes[W:]) / K
     achieved = avg_alg / avg_kernel_s / 1e9
@@ -465,6 +499,8 @@ def main():
                            "note": "packets -> side-info on the host threads (untimed in `value`)",
                            "mean_leaves_per_frame": round(sum(nleaves) / (S * nframes), 1)},
         }
+        if t1:
+            out["t1"] = t1
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(packets)
         print(json.dumps(out), flush=True)

@@ -1022,7 +1022,7 @@ OG_DEV void og_celt_spectrum(const OgCeltHdr *hg, const OgBandPlan *plan, const 
     // the CC * B transforms of the frame are interleaved in the FFT buffers: work item q = bin i of transform t = ch * B + b
     // at q = i * TT + t, TT = CC * B = 2^tsh; it reads MDCT bins 2i and NB-1-2i of block b, which sit at j1, j2 in X[ch]
     const int bsh = transient ? lm : 0, tsh = bsh + (CC == 2), tmask = (1 << tsh) - 1;
-    struct OgTw4 { OgC2 w[4]; uint32_t bands[4]; };
+    struct OgTw4 { OgC2 w[4]; uint32_t bands[4], xoff[4]; };     // twiddle; gain cells of the item's two bins (gband, flat) | << 8; the bins (X, flat) | << 16
     OG_LANE_VAR(OgTw4, twr);
     OG_LANES_BEGIN(tid)
     for (int t = tid; t < 48; t += OG_WG) {             // per-(channel, band) gains 2^(E + mean), zero outside [start, end)
@@ -1034,18 +1034,35 @@ OG_DEV void og_celt_spectrum(const OgCeltHdr *hg, const OgBandPlan *plan, const 
         }
         L.gband[ch][b] = g;
     }
-    for (int p = tid; p < 960; p += OG_WG) ((float *)ldsW)[p] = ((const float *)T->fft_w)[p];
+    {
+        // every fetch first (independent: one memory latency for all of them; indices of idle work items are clamped, not
+        // branched around), then the LDS stores
+        const float *wsrc = (const float *)T->fft_w;
+        const uint8_t *b2b = T->bin2band[lm0];
+        const OgC2 *twp = (const OgC2 *)T->tw + (n4 - 60);
+        const uint32_t items = (uint32_t)(CC * (N >> 1));
+        float wv[4];
+        uint32_t b1[4], b2[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int q = tid + j * OG_WG;
-        OG_LV(twr).w[j] = OgC2{0.f, 0.f};
-        OG_LV(twr).bands[j] = 0;
-        if (q < CC * (N >> 1)) {
-            const int i = q >> tsh, b = (q & tmask) & (B - 1);
-            const int j1 = ((2 * i) << bsh) + b, j2 = N - B - ((2 * i) << bsh) + b;
-            OG_LV(twr).w[j] = ((const OgC2 *)T->tw)[(n4 - 60) + i];
-            const uint32_t b1 = T->bin2band[lm0][j1], b2 = T->bin2band[lm0][j2];
-            OG_LV(twr).bands[j] = (b1 == 255u ? 23u : b1) | (b2 == 255u ? 23u : b2) << 8;       // gband[.][21..23] = 0
+        for (int j = 0; j < 4; j++) {
+            const uint32_t p = (uint32_t)tid + (uint32_t)j * OG_WG;
+            wv[j] = wsrc[p < 960u ? p : 959u];
+            const uint32_t q = p < items ? p : 0u;
+            const uint32_t i = q >> tsh, b = (q & (uint32_t)tmask) & (uint32_t)(B - 1);
+            const uint32_t j1 = ((2u * i) << bsh) + b, j2 = (uint32_t)(N - B) - ((2u * i) << bsh) + b;
+            OG_LV(twr).w[j] = twp[i];
+            b1[j] = b2b[j1];
+            b2[j] = b2b[j2];
+            const uint32_t cx = (C == 2 && CC == 2) ? (q & (uint32_t)tmask) >> bsh : 0u;       // coded channel the output channel reads
+            OG_LV(twr).xoff[j] = (cx * 960u + j1) | (cx * 960u + j2) << 16;
+            b1[j] |= cx << 8;                                                               // (kept beside the band until it arrives)
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t p = (uint32_t)tid + (uint32_t)j * OG_WG;
+            if (p < 960u) ((float *)ldsW)[p] = wv[j];
+            const uint32_t cg = (b1[j] >> 8) * 24u, a1 = b1[j] & 255u;
+            OG_LV(twr).bands[j] = (cg + (a1 == 255u ? 23u : a1)) | (cg + (b2[j] == 255u ? 23u : b2[j])) << 8;     // gband[.][21..23] = 0
         }
     }
     OG_LANES_END
@@ -1073,19 +1090,12 @@ OG_DEV void og_celt_spectrum(const OgCeltHdr *hg, const OgBandPlan *plan, const 
     for (int j = 0; j < 4; j++) {                                            // denormalise + pre-twiddle
         const int q = tid + j * OG_WG;
         if (q < CC * (N >> 1)) {
-            const int t = q & tmask, i = q >> tsh, ch = t >> bsh, b = t & (B - 1);
-            const int j1 = ((2 * i) << bsh) + b, j2 = N - B - ((2 * i) << bsh) + b;
-            const int b1 = (int)(OG_LV(twr).bands[j] & 255u), b2 = (int)(OG_LV(twr).bands[j] >> 8);
-            float x1, x2;
-            if (C == 2 && CC == 2) {
-                x1 = L.X[ch][j1] * L.gband[ch][b1];
-                x2 = L.X[ch][j2] * L.gband[ch][b2];
-            } else if (C == 2) {                                             // stereo coded, mono out
-                x1 = 0.5f * (L.X[0][j1] * L.gband[0][b1]) + 0.5f * (L.X[1][j1] * L.gband[1][b1]);
-                x2 = 0.5f * (L.X[0][j2] * L.gband[0][b2]) + 0.5f * (L.X[1][j2] * L.gband[1][b2]);
-            } else {                                                         // mono coded: both outputs from buffer 0
-                x1 = L.X[0][j1] * L.gband[0][b1];
-                x2 = L.X[0][j2] * L.gband[0][b2];
+            const uint32_t xo = OG_LV(twr).xoff[j], go = OG_LV(twr).bands[j];
+            const float *Xf = &L.X[0][0], *Gf = &L.gband[0][0];
+            float x1 = Xf[xo & 0xFFFFu] * Gf[go & 255u], x2 = Xf[xo >> 16] * Gf[go >> 8];
+            if (C == 2 && CC == 1) {                                         // stereo coded, mono out
+                x1 = 0.5f * x1 + 0.5f * (Xf[960u + (xo & 0xFFFFu)] * Gf[24u + (go & 255u)]);
+                x2 = 0.5f * x2 + 0.5f * (Xf[960u + (xo >> 16)] * Gf[24u + (go >> 8)]);
             }
             ((OgC2 *)bufA)[q] = og_c2_mulc(OgC2{x1, x2}, OG_LV(twr).w[j]);     // (x1 w.r + x2 w.i, x2 w.r - x1 w.i)
         }
