@@ -67,20 +67,83 @@ __global__ __launch_bounds__(256) void og_pvq_all_kernel(const OgLeafRef *__rest
     }
 }
 
-// Band plan: one lane per frame (celt_plan.h), OG_PLAN_FPW frames per wavefront.  The per-lane code is one long serial
-// chain, so what it reads and indexes sits in LDS: the workgroup's headers (copied in coalesced; a lane's header is 188
-// dwords from its neighbour's), the small constant tables, and
-// a row of scratch cells per lane for the arrays it indexes at run time.
+// Band plan (celt_plan.h) of OG_PLAN_FPW frames per 256-lane workgroup, in three steps: a work item per (frame, band) for what
+// the bands do not share, a lane per frame for the recurrences over the bands (the only serial part: the other wavefronts
+// wait at the barrier), a work item per (frame, task) for the records out and their order.  What the steps read and index
+// sits in LDS: the workgroup's headers (copied in coalesced), the small constant tables, and an OgPlanShared per frame.
+// (Round 2, one lane per frame for everything: 94 us per 32 768 frames, 76 us per 4 096 -- the length of one lane's
+// instruction chain; the split cuts that chain to the recurrences.)
 #define OG_PLAN_FPW 16
-__global__ __launch_bounds__(64) void og_plan_kernel(const OgCeltHdr *__restrict__ hdr, const OgCeltLeaf *__restrict__ leaves,
-                                                     uint32_t nframes, const OgCeltTables *__restrict__ T, void *work)
+#define OG_PLAN_WG 256
+#define OG_PLAN_STEPS_MAX 16384       // frames per launch up to which the three-step kernel is used
+__global__ __launch_bounds__(OG_PLAN_WG) void og_plan_kernel(const OgCeltHdr *__restrict__ hdr, const OgCeltLeaf *__restrict__ leaves,
+                                                             uint32_t nframes, const OgCeltTables *__restrict__ T, void *work)
 {
     static_assert(sizeof(OgCeltHdr) % 4 == 0, "headers are copied as dwords");
     __shared__ uint32_t hs[OG_PLAN_FPW * sizeof(OgCeltHdr) / 4];
     __shared__ OgCeltConst K;
     __shared__ uint32_t la[184], lc[184];
-    __shared__ uint16_t sc[OG_PLAN_SCRATCH * OG_PLAN_FPW];
+    __shared__ OgPlanShared S[OG_PLAN_FPW];
+    const uint32_t tid = threadIdx.x;
     const uint32_t f0 = blockIdx.x * OG_PLAN_FPW, nf = nframes - f0 < OG_PLAN_FPW ? nframes - f0 : OG_PLAN_FPW;
+    const uint32_t *src = (const uint32_t *)(hdr + f0);
+    for (uint32_t p = tid; p < nf * (sizeof(OgCeltHdr) / 4); p += OG_PLAN_WG) hs[p] = src[p];
+    for (uint32_t p = tid; p < sizeof(OgCeltConst) / 4; p += OG_PLAN_WG) ((uint32_t *)&K)[p] = ((const uint32_t *)&T->k)[p];
+    for (uint32_t p = tid; p < 184; p += OG_PLAN_WG) { la[p] = T->lcg_a[p]; lc[p] = T->lcg_c[p]; }
+    {
+        // what the steps OR into or read before writing: bits .. the end of OgPlanShared
+        constexpr uint32_t Z0 = offsetof(OgPlanShared, bits) / 4, ZN = sizeof(OgPlanShared) / 4 - Z0;
+        static_assert(offsetof(OgPlanShared, bits) % 4 == 0, "cleared as dwords");
+        for (uint32_t p = tid; p < nf * ZN; p += OG_PLAN_WG) {
+            const uint32_t fr = p / ZN;
+            ((uint32_t *)&S[fr])[Z0 + p - fr * ZN] = 0;
+        }
+    }
+    __syncthreads();
+    // K1's collapse masks (48 words per frame): fetched coalesced, handed back zeroed, and kept over the band energies (energy, prev_min) of
+    // the LDS header copies, which the plan does not read
+    static_assert(offsetof(OgCeltHdr, energy) % 4 == 0 && offsetof(OgCeltHdr, band) - offsetof(OgCeltHdr, energy) >= 48 * 4, "room for the masks (over energy + prev_min)");
+    constexpr uint32_t HW = sizeof(OgCeltHdr) / 4, EOFF = offsetof(OgCeltHdr, energy) / 4;
+    for (uint32_t p = tid; p < nf * 48; p += OG_PLAN_WG) {
+        const uint32_t fr = p / 48, j = p - fr * 48;
+        uint32_t *cm = og_work_cm(work, f0 + fr);
+        hs[fr * HW + EOFF + j] = cm[j];
+        cm[j] = 0;
+    }
+    __syncthreads();
+    for (uint32_t p = tid; p < nf * 21; p += OG_PLAN_WG) {
+        const uint32_t fr = p / 21, i = p - fr * 21;
+        const OgCeltHdr *h = (const OgCeltHdr *)hs + fr;
+        og_plan_band_a(h, leaves + h->leaf_begin, K, hs + fr * HW + EOFF, og_work_coef(work, f0 + fr), (int)i, S[fr]);
+    }
+    __syncthreads();
+    if (tid < nf) {
+        const OgCeltHdr *h = (const OgCeltHdr *)hs + tid;
+        og_plan_chain(h, leaves + h->leaf_begin, K, la, lc, hs + tid * HW + EOFF, og_work_plan(work, f0 + tid), S[tid]);
+    }
+    __syncthreads();
+    for (uint32_t p = tid; p < nf * 42; p += OG_PLAN_WG) {
+        const uint32_t fr = p / 42, t = p - fr * 42;
+        og_plan_emit((int)t, og_work_plan(work, f0 + fr), S[fr]);
+    }
+}
+
+#define OG_PLAN_LANE_FPW 16
+// The band plan of a LARGE launch: one lane per frame start to end (og_band_plan_lane), OG_PLAN_LANE_FPW frames per wavefront.
+// Fewer instructions in all than the three steps above (which pay for their work items' set-up), and with every SIMD holding
+// two such wavefronts the chain's length no longer matters: 94 us against 111 for 32 768 frames; 76 against 47 for 4 096.  The per-lane code is one long serial
+// chain, so what it reads and indexes sits in LDS: the workgroup's headers (copied in coalesced; a lane's header is 188
+// dwords from its neighbour's), the small constant tables, and
+// a row of scratch cells per lane for the arrays it indexes at run time.
+__global__ __launch_bounds__(64) void og_plan_lane_kernel(const OgCeltHdr *__restrict__ hdr, const OgCeltLeaf *__restrict__ leaves,
+                                                     uint32_t nframes, const OgCeltTables *__restrict__ T, void *work)
+{
+    static_assert(sizeof(OgCeltHdr) % 4 == 0, "headers are copied as dwords");
+    __shared__ uint32_t hs[OG_PLAN_LANE_FPW * sizeof(OgCeltHdr) / 4];
+    __shared__ OgCeltConst K;
+    __shared__ uint32_t la[184], lc[184];
+    __shared__ uint16_t sc[OG_PLAN_SCRATCH * OG_PLAN_LANE_FPW];
+    const uint32_t f0 = blockIdx.x * OG_PLAN_LANE_FPW, nf = nframes - f0 < OG_PLAN_LANE_FPW ? nframes - f0 : OG_PLAN_LANE_FPW;
     const uint32_t *src = (const uint32_t *)(hdr + f0);
     for (uint32_t p = threadIdx.x; p < nf * (sizeof(OgCeltHdr) / 4); p += 64) hs[p] = src[p];
     for (int p = threadIdx.x; p < (int)(sizeof(OgCeltConst) / 4); p += 64) ((uint32_t *)&K)[p] = ((const uint32_t *)&T->k)[p];
@@ -98,8 +161,8 @@ __global__ __launch_bounds__(64) void og_plan_kernel(const OgCeltHdr *__restrict
     }
     __syncthreads();
     const uint32_t f = f0 + threadIdx.x;
-    if (threadIdx.x < OG_PLAN_FPW && f < nframes)
-        og_plan_frame<true>((const OgCeltHdr *)hs + threadIdx.x, leaves, f, K, la, lc, work, OgLaneScratch{sc + threadIdx.x, OG_PLAN_FPW},
+    if (threadIdx.x < OG_PLAN_LANE_FPW && f < nframes)
+        og_plan_frame_lane<true>((const OgCeltHdr *)hs + threadIdx.x, leaves, f, K, la, lc, work, OgLaneScratch{sc + threadIdx.x, OG_PLAN_LANE_FPW},
                       hs + threadIdx.x * HW + EOFF);
 }
 
@@ -242,7 +305,12 @@ int opusgpu_launch_celt_pvq(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, uint
         }
         if (wg) hipLaunchKernelGGL(og_pvq_all_kernel, dim3(wg), dim3(256), 0, st, refs, cl, leaves, nframes, T, work, dbg.pulses, dbg.cycles);
     }
-    hipLaunchKernelGGL(og_plan_kernel, dim3((nframes + OG_PLAN_FPW - 1) / OG_PLAN_FPW), dim3(64), 0, st, hdr, leaves, nframes, T, work);
+    // launches that fill the chip take the one-lane form (see og_plan_lane_kernel); OPUSGPU_PLAN = lane | steps overrides (profiling)
+    static const int plan_form = [] { const char *e = getenv("OPUSGPU_PLAN"); return !e ? 0 : e[0] == 'l' ? 1 : e[0] == 's' ? 2 : 0; }();
+    if (plan_form == 1 || (plan_form == 0 && nframes > OG_PLAN_STEPS_MAX))
+        hipLaunchKernelGGL(og_plan_lane_kernel, dim3((nframes + OG_PLAN_LANE_FPW - 1) / OG_PLAN_LANE_FPW), dim3(64), 0, st, hdr, leaves, nframes, T, work);
+    else
+        hipLaunchKernelGGL(og_plan_kernel, dim3((nframes + OG_PLAN_FPW - 1) / OG_PLAN_FPW), dim3(OG_PLAN_WG), 0, st, hdr, leaves, nframes, T, work);
     OG_HIP(hipGetLastError());
     return OPUSGPU_OK;
 }

@@ -82,7 +82,264 @@ OG_DEV void og_make_xform(int n, int B, int tf_change, OgXform *t, int *recombin
     *recombine_out = recombine; *time_divide_out = time_divide; *B0_out = B;
 }
 
-// Everything here is per-lane serial code on global memory.  coef_row: the frame's K1 output (the signs of the
+// The plan of a frame is made in three steps, so that only what is a recurrence over the bands runs as one:
+//   A  per band (21 independent work items): task geometry, the masks `keep` / `joint` / `plain`, the one-bin bands' signs,
+//      the collapse masks of the calls without live fill leaves;
+//   B  per frame (serial over the bands that have fill leaves or the dual -> intensity switch): levels, which fill leaves
+//      are live and their seeds, the collapse masks that depend on lower bands;
+//   C  per task (42 independent work items): the task records out, their order by level (each task counts the tasks in
+//      front of it), the small header fields.
+// OgPlanShared holds a frame's plan between the steps (LDS in the kernel, one per frame of the workgroup).
+enum { OG_PB_CHAIN0 = 1, OG_PB_CHAIN1 = 2, OG_PB_SERIAL = 4 /* step B has work here */, OG_PB_CODED = 8 /* inside [start, end), not silent */ };
+struct OgPlanBand {                   // step A -> step B
+    uint8_t flags;                    // OG_PB_*
+    uint8_t cm[2];                    // collapse masks of the calls step B leaves alone
+    uint8_t rc[2], td[2], B0[2];      // per call: recombine, time_divide, blocks after recombination (og_make_xform)
+    uint8_t pad_[3];
+};
+struct OgPlanShared {
+    OgTask task[42];
+    OgPlanBand rec[21];
+    uint32_t bits[5];                 // keep[0], keep[1], joint, plain[0], plain[1]: OR-ed together by the bands' work items
+    uint32_t seed_out;
+    uint16_t nops, merge_cnt;
+    uint8_t maxlvl, merge_level;
+    uint8_t tl[42];                   // level of the active tasks that go into `order` (0xFF: not in it)
+    uint8_t col[2][21], blevel[21];   // step B's running arrays (col: the bands' collapse masks, as the fill of higher bands reads them)
+    uint8_t pad_[13];
+};
+static_assert(sizeof(OgPlanBand) == 12 && sizeof(OgPlanShared) % 16 == 0, "OgPlanShared: a whole number of 16-byte pieces");
+// (Step B fetches its fill leaves from the leaf array, one memory round trip each.  Staging them in LDS in step A was
+// measured, round 2: no faster for a small launch, 25 % slower for a large one -- the LDS it takes costs a workgroup per CU.)
+
+// the fill leaves step B walks for call `slot` of a band: at most nfill, and none past the frame's leaves
+OG_DEV int og_plan_nfill(const OgCeltBand &bd, int slot, int nleaves)
+{
+    const int g0 = bd.leaf0 + (slot ? bd.nx : 0), nfill = slot ? bd.fy : bd.fx, left = nleaves - g0;
+    return left <= 0 ? 0 : nfill < left ? nfill : left;
+}
+
+// cm_row: K1's collapse masks [buffer][24]; coef_row: the frame's K1 output (the signs of the one-bin bands are added to it)
+OG_DEV void og_plan_band_a(const OgCeltHdr *h, const OgCeltLeaf *lv, const OgCeltConst &K, const uint32_t *cm_row, float *coef_row,
+                           int i, OgPlanShared &S)
+{
+    const int lm = h->lm, M = 1 << lm, start = h->start, end = h->end;
+    const int C = (h->flags & OG_F_STEREO) ? 2 : 1;
+    const int B = (h->flags & OG_F_TRANSIENT) ? M : 1;
+    const int nleaves = h->nleaves < OG_MAXLEAF ? h->nleaves : OG_MAXLEAF;
+    const bool silence = (h->flags & OG_F_SILENCE) != 0;
+    OgTask tk[2];
+    OgPlanBand r;
+    r.flags = 0; r.cm[0] = r.cm[1] = 0; r.rc[0] = r.rc[1] = r.td[0] = r.td[1] = 0; r.B0[0] = r.B0[1] = 1;
+    r.pad_[0] = r.pad_[1] = r.pad_[2] = 0;
+    int tl[2] = {0xFF, 0xFF};
+    for (int slot = 0; slot < 2; slot++) {
+        OgTask &t = tk[slot];
+        t.boff = t.n = t.n0p = t.ops = 0; t.lowpos = 0;
+        t.flags = t.hm = t.slog = t.rctd = t.level = 0; t.norm_row = 0xFF;
+    }
+    if (!(silence || i < start || i >= end)) {
+        const OgCeltBand bd = h->band[i];
+        const int n = M * K.width[i], boff = M * K.ebands[i];
+        r.flags = OG_PB_CODED;
+        // leaves of this band that write a buffer with pulses (or a sign): all of them but the fill-path ones
+        if (C == 2 && (bd.flags & OG_B_JOINT)) OG_ATOMIC_OR(&S.bits[2], 1u << i);
+        if ((int)bd.nx - (int)bd.fx > 0) OG_ATOMIC_OR(&S.bits[0], 1u << i);
+        if ((int)bd.ny - (int)bd.fy > 0) OG_ATOMIC_OR(&S.bits[1], 1u << i);
+        const bool dual = (bd.flags & OG_B_DUAL) != 0;
+        for (int slot = 0; slot < 2; slot++) {
+            OgTask &t = tk[slot];
+            const int nfill = slot ? bd.fy : bd.fx;
+            bool active, chain = false;
+            int norm_row = -1;
+            if (C == 1) { active = slot == 0; norm_row = 0; chain = nfill > 0; }
+            else if (dual) { active = true; norm_row = slot; chain = nfill > 0; }
+            else if (n == 1) { active = true; norm_row = slot == 0 ? 0 : -1; }
+            else if (n == 2) { active = slot == ((bd.flags & OG_B_N2SWAP) ? 1 : 0); norm_row = 0; chain = nfill > 0; }
+            else { active = true; norm_row = slot == 0 ? 0 : -1; chain = slot == 0 && nfill > 0 && !(bd.flags & OG_B_MIDFILL0); }
+            if (bd.flags & OG_B_LAST) norm_row = -1;
+            if (!active) continue;
+            t.boff = (uint16_t)boff; t.n = (uint16_t)n;
+            t.flags = (uint8_t)(OG_T_ACTIVE | (chain ? OG_T_CHAIN : 0) | (B == 1 ? OG_T_LONG : 0));
+            t.norm_row = (uint8_t)norm_row;
+            tl[slot] = 0;
+            if (n == 1) {                               // decode_band_1 (celt/decoder.rs:1466-1495)
+                const int li = bd.leaf0 + (slot ? bd.nx : 0);
+                coef_row[slot * 960 + boff] = (li < nleaves && lv[li].index) ? -1.f : 1.f;
+                r.cm[slot] = 1;
+                continue;
+            }
+            OgXform xf;
+            int rc, td, B0;
+            og_make_xform(n, B, bd.tf_change, &xf, &rc, &td, &B0);
+            t.hm = (uint8_t)xf.hm; t.slog = (uint8_t)xf.slog; t.n0p = (uint16_t)xf.n0p;
+            t.rctd = (uint8_t)(rc | td << 4);
+            r.rc[slot] = (uint8_t)rc; r.td[slot] = (uint8_t)td; r.B0[slot] = (uint8_t)B0;
+            if (chain) {
+                r.flags |= (uint8_t)(OG_PB_CHAIN0 << slot);
+            } else {                                    // its fill leaves (if any) are dead: the PVQ masks are all
+                int m = (int)cm_row[slot * 24 + i];
+                for (int k = 0, Bk = B0; k < td; k++) { Bk >>= 1; m |= m >> Bk; }
+                for (int k = 0; k < rc; k++) m = K.bit_deinterleave[m & 255];
+                r.cm[slot] = (uint8_t)(m & ((1 << ((B0 >> td) << rc)) - 1));
+            }
+        }
+        if ((r.flags & (OG_PB_CHAIN0 | OG_PB_CHAIN1)) || (bd.flags & OG_B_MERGE_NORM)) r.flags |= OG_PB_SERIAL;
+        for (int slot = 0; slot < 2; slot++) {          // the calls that stay at level 0
+            const OgTask &t = tk[slot];
+            if (tl[slot] == 0 && !(t.flags & OG_T_CHAIN) && !(t.hm | t.slog) && (t.norm_row == 0xFF || t.norm_row == slot)) {
+                // nothing to transform: at most lowband_out = sqrt(N0) x, which the frame kernel writes while staging
+                if (t.norm_row == slot) OG_ATOMIC_OR(&S.bits[3 + slot], 1u << i);
+                tl[slot] = 0xFF;
+            }
+        }
+    }
+    S.task[2 * i] = tk[0];
+    S.task[2 * i + 1] = tk[1];
+    S.rec[i] = r;
+    S.tl[2 * i] = (uint8_t)tl[0];
+    S.tl[2 * i + 1] = (uint8_t)tl[1];
+}
+
+// K, la, lc: the small constant tables (LDS copies in the kernel).  Fill ops go straight to the plan P.  S.col and S.blevel
+// are zero on entry.
+OG_DEV void og_plan_chain(const OgCeltHdr *h, const OgCeltLeaf *lv, const OgCeltConst &K, const uint32_t *la, const uint32_t *lc,
+                          const uint32_t *cm_row, OgBandPlan *P, OgPlanShared &S)
+{
+    const int lm = h->lm, M = 1 << lm, start = h->start;
+    const int C = (h->flags & OG_F_STEREO) ? 2 : 1;
+    const int B = (h->flags & OG_F_TRANSIENT) ? M : 1;
+    const int nleaves = h->nleaves < OG_MAXLEAF ? h->nleaves : OG_MAXLEAF;
+    const int norm_offset = M * K.ebands[start < 21 ? start : 20];
+    uint32_t seed = h->seed;
+    int floor_lvl = 1, maxlvl = 0, merge_level = 0xFF, merge_cnt = 0, nops = 0;
+    for (int i = 0; i < 21; i++) {
+        const OgPlanBand r = S.rec[i];
+        int cm[2] = {r.cm[0], r.cm[1]};
+        bool dual = false;
+        if (r.flags & OG_PB_SERIAL) {
+            const OgCeltBand bd = h->band[i];
+            const int boff = M * K.ebands[i];
+            const bool any_chain = (r.flags & (OG_PB_CHAIN0 | OG_PB_CHAIN1)) != 0;
+            dual = (bd.flags & OG_B_DUAL) != 0;
+            int x_cm, y_cm, lvl = floor_lvl;
+            if (bd.lowband != 0xFF) {
+                x_cm = y_cm = 0;
+                for (int f = bd.fold_lo; f < bd.fold_hi && f < 21; f++) {
+                    x_cm |= S.col[0][f];
+                    y_cm |= S.col[1][f];
+                    if (S.blevel[f] >= lvl) lvl = S.blevel[f] + 1;
+                }
+            } else {
+                x_cm = y_cm = (1 << B) - 1;
+            }
+            if (bd.flags & OG_B_MERGE_NORM) {           // dual -> intensity switch (celt/decoder.rs:2133-2138): every lower
+                if (lvl <= maxlvl) lvl = maxlvl + 1;    // band is finished first, every later fill band comes after
+                floor_lvl = merge_level = lvl;
+                merge_cnt = boff - norm_offset;
+            }
+            if (lvl > OG_MAXLEVEL) lvl = OG_MAXLEVEL;   // cannot happen (one level per band at most, plus the switch)
+            for (int slot = 0; slot < 2; slot++) {
+                if (!(r.flags & (OG_PB_CHAIN0 << slot))) continue;
+                OgTask &t = S.task[2 * i + slot];
+                const int rc = r.rc[slot], td = r.td[slot], B0 = r.B0[slot];
+                // the integer half of a quant_band call with fill leaves: fill transforms (celt/decoder.rs:1700-1740),
+                // which leaves fold / make noise (:1633-1661), mask transforms (:1994-2019)
+                int fill = dual ? (slot ? y_cm : x_cm) : (x_cm | y_cm);
+                for (int k = 0; k < rc; k++) fill = K.bit_interleave[fill & 0xF] | K.bit_interleave[(fill >> 4) & 0xF] << 2;
+                for (int k = 0, Bk = B >> rc; k < td; k++, Bk <<= 1) fill |= fill << Bk;
+                t.level = (uint8_t)lvl;
+                S.tl[2 * i + slot] = (uint8_t)lvl;
+                if (bd.lowband != 0xFF && (bd.flags & (slot ? OG_B_FOLD_Y : OG_B_FOLD_X))) {
+                    t.flags |= OG_T_NEED_LB | ((dual && slot) ? OG_T_LB_ROW1 : 0);
+                    t.lowpos = (uint16_t)(bd.lowband * M);
+                }
+                const int g0 = bd.leaf0 + (slot ? bd.nx : 0), nfill = og_plan_nfill(bd, slot, nleaves);
+                int m = (int)cm_row[slot * 24 + i];     // PVQ leaves: expanded (and masks collected) by K1
+                int live = 0;
+                const int first_op = nops;
+                for (int l = 0; l < nfill; l++) {
+                    const OgCeltLeaf lf = lv[g0 + l];
+                    const int Bl = 1 << (lf.meta & OG_L_LOGB_MASK), sh = lf.cmshift;
+                    // the leaf's share of the fill: the recursion only shifts it (side halves) or clears it (theta)
+                    const int fl = (lf.meta & OG_L_FILL_DEAD) ? 0 : (fill >> sh) & ((1 << Bl) - 1);
+                    if (!fl) continue;                  // x stays zero (celt/decoder.rs:1640-1643)
+                    const bool fold = (lf.meta & OG_L_HAS_LOWBAND) != 0;
+                    const int nn = lf.n < 184 ? lf.n : 183;
+                    if (nops < OG_MAXLEAF) {
+                        OgFillOp op;
+                        op.seed = seed; op.gain = lf.gain;
+                        op.pos = (uint16_t)(slot * 960 + boff + lf.off);
+                        op.n = (uint8_t)nn; op.flags = fold ? OG_OP_FOLD : 0;
+                        op.level = (uint8_t)lvl; op.task = (uint8_t)(2 * i + slot); op.pad_[0] = op.pad_[1] = 0;
+                        P->op[nops++] = op;
+                        live++;
+                    }
+                    m |= (fold ? fl : (1 << Bl) - 1) << sh;
+                    seed = la[nn] * seed + lc[nn];
+                }
+                for (int k = 0, Bk = B0; k < td; k++) { Bk >>= 1; m |= m >> Bk; }
+                for (int k = 0; k < rc; k++) m = K.bit_deinterleave[m & 255];
+                cm[slot] = m & ((1 << ((B0 >> td) << rc)) - 1);
+                t.ops = (uint16_t)(live << 10 | (live ? first_op : 0));
+            }
+            if (any_chain) S.blevel[i] = (uint8_t)lvl;
+            if (lvl > maxlvl) maxlvl = lvl;
+        } else if (r.flags & OG_PB_CODED) {
+            dual = (h->band[i].flags & OG_B_DUAL) != 0;
+        }
+        const int both = cm[0] | cm[1];
+        S.col[0][i] = (uint8_t)(dual || C == 1 ? cm[0] : both);
+        S.col[1][i] = (uint8_t)(dual ? cm[1] : C == 1 ? cm[0] : both);      // (mono: the fill of a band reads col[0] for both)
+    }
+    S.seed_out = seed;
+    S.nops = (uint16_t)nops; S.merge_cnt = (uint16_t)merge_cnt;
+    S.maxlvl = (uint8_t)maxlvl; S.merge_level = (uint8_t)merge_level;
+}
+
+// work item t = 0 .. 41 of a frame: task t out, its place in `order`; the low work items also write the header fields
+OG_DEV void og_plan_emit(int t, OgBandPlan *P, const OgPlanShared &S)
+{
+    P->task[t] = S.task[t];
+    const int lv = S.tl[t];
+    int before = 0, below = 0;                          // tasks in front of t in the order; tasks of a level below t's number
+    for (int u = 0; u < 42; u++) {
+        const int lu = S.tl[u];
+        before += (lu < lv || (lu == lv && u < t)) ? 1 : 0;
+        below += lu < t ? 1 : 0;                        // (0xFF is below no level)
+    }
+    if (lv != 0xFF) P->order[before] = (uint8_t)t;
+    if (t < OG_MAXLEVEL + 3) P->task_start[t] = (uint8_t)below;      // tasks of level l: order[task_start[l]] .. order[task_start[l + 1]]
+    if (t < 12) {                                       // collapse[2][24], four bytes per work item (bands 21 .. 23: zero)
+        const int b = t >= 6, i0 = 4 * (t - 6 * b);
+        uint32_t w = 0;
+        for (int k = 0; k < 4; k++)
+            if (i0 + k < 21) w |= (uint32_t)S.col[b][i0 + k] << (8 * k);
+        ((uint32_t *)&P->collapse[0][0])[t] = w;
+    }
+    if (t == 0) {
+        P->seed_out = S.seed_out;
+        P->nops = S.nops; P->merge_cnt = S.merge_cnt;
+        P->nlevels = S.maxlvl; P->merge_level = S.merge_level;
+        P->pad_[0] = P->pad_[1] = 0;
+        P->keep[0] = S.bits[0]; P->keep[1] = S.bits[1]; P->joint = S.bits[2]; P->plain[0] = S.bits[3]; P->plain[1] = S.bits[4];
+        P->pad2_[0] = P->pad2_[1] = P->pad2_[2] = 0;
+    }
+}
+
+// the three steps for one frame, one after the other (CPU builds; the kernel spreads A and C over lanes)
+OG_DEV void og_band_plan(const OgCeltHdr *h, const OgCeltLeaf *lv, const OgCeltConst &K, const uint32_t *la, const uint32_t *lc,
+                         const uint32_t *cm_row, float *coef_row, OgBandPlan *P, OgPlanShared &S)
+{
+    for (int k = 0; k < 5; k++) S.bits[k] = 0;          // (the kernel clears these, S.col and S.blevel with all its lanes)
+    for (int i = 0; i < 21; i++) S.col[0][i] = S.col[1][i] = S.blevel[i] = 0;
+    for (int i = 0; i < 21; i++) og_plan_band_a(h, lv, K, cm_row, coef_row, i, S);
+    og_plan_chain(h, lv, K, la, lc, cm_row, P, S);
+    for (int t = 0; t < 42; t++) og_plan_emit(t, P, S);
+}
+
+// The same plan made start to end by ONE lane (the form large launches use: og_plan_lane_kernel, celt_launch.hip): the three
+// steps above fused, tasks written straight to the plan, the order by a counting sort.  Per-lane serial code on global memory.  coef_row: the frame's K1 output (the signs of the
 // one-bin bands are added to it); cm_row: K1's collapse masks [buffer][24].
 // K, la, lc: the small constant tables (LDS copies in the kernel).  sc: OG_PLAN_SCRATCH cells private to the lane: the
 // small per-band / per-level arrays are indexed with run-time indices, which in registers costs a chain of selects per
@@ -94,7 +351,7 @@ struct OgLaneScratch {                // u16 cells, cell i at p[i * stride] (lan
     OG_MEMBER OgLaneScratch at(int o) const { OgLaneScratch r = {p + o * stride, stride}; return r; }
 };
 #define OG_PLAN_SCRATCH 184
-OG_DEV void og_band_plan(const OgCeltHdr *h, const OgCeltLeaf *lv, const OgCeltConst &K, const uint32_t *la, const uint32_t *lc,
+OG_DEV void og_band_plan_lane(const OgCeltHdr *h, const OgCeltLeaf *lv, const OgCeltConst &K, const uint32_t *la, const uint32_t *lc,
                          const uint32_t *cm_row, float *coef_row, OgBandPlan *P, OgLaneScratch sc)
 {
     const OgLaneScratch tl = sc.at(0), blevel = sc.at(44), col0 = sc.at(65), col1 = sc.at(86), tcur = sc.at(157);
@@ -276,17 +533,27 @@ OG_DEV OgBandPlan *og_work_plan(void *work, uint32_t frame)
     return (OgBandPlan *)((char *)work + (size_t)frame * OG_WORK_STRIDE + 1920 * 4 + 48 * 4);
 }
 
-// The plan of frame f: consumes (and re-zeroes) K1's collapse masks.  h = the frame's header (the kernel passes an LDS copy).
-// STAGED: cm_staged holds the frame's 48 collapse-mask words, already fetched (and re-zeroed in `work`) by the caller.
-template <bool STAGED = false>
+// The plan of frame f, start to end by one caller (CPU builds): consumes (and re-zeroes) K1's collapse masks.
 OG_DEV void og_plan_frame(const OgCeltHdr *h, const OgCeltLeaf *leaves, uint32_t f, const OgCeltConst &K, const uint32_t *la,
-                          const uint32_t *lc, void *work, OgLaneScratch sc, const uint32_t *cm_staged = nullptr)
+                          const uint32_t *lc, void *work)
+{
+    OgPlanShared S;
+    uint32_t *cm = og_work_cm(work, f);
+    og_band_plan(h, leaves + h->leaf_begin, K, la, lc, cm, og_work_coef(work, f), og_work_plan(work, f), S);
+    for (int i = 0; i < 48; i++) cm[i] = 0;
+}
+
+// The same by the one-lane form (og_band_plan_lane); sc: OG_PLAN_SCRATCH cells.  STAGED: cm_staged holds the frame's 48
+// collapse-mask words, already fetched (and re-zeroed in `work`) by the caller.
+template <bool STAGED = false>
+OG_DEV void og_plan_frame_lane(const OgCeltHdr *h, const OgCeltLeaf *leaves, uint32_t f, const OgCeltConst &K, const uint32_t *la,
+                               const uint32_t *lc, void *work, OgLaneScratch sc, const uint32_t *cm_staged = nullptr)
 {
     if (STAGED) {
-        og_band_plan(h, leaves + h->leaf_begin, K, la, lc, cm_staged, og_work_coef(work, f), og_work_plan(work, f), sc);
+        og_band_plan_lane(h, leaves + h->leaf_begin, K, la, lc, cm_staged, og_work_coef(work, f), og_work_plan(work, f), sc);
     } else {
         uint32_t *cm = og_work_cm(work, f);
-        og_band_plan(h, leaves + h->leaf_begin, K, la, lc, cm, og_work_coef(work, f), og_work_plan(work, f), sc);
+        og_band_plan_lane(h, leaves + h->leaf_begin, K, la, lc, cm, og_work_coef(work, f), og_work_plan(work, f), sc);
         for (int i = 0; i < 48; i++) cm[i] = 0;
     }
 }

@@ -19,6 +19,7 @@
 #define OG_LANES_BEGIN(tid) { const int tid = (int)threadIdx.x; {
 #define OG_LANES_END } } __syncthreads();
 #define OG_ATOMIC_OR(p, v) atomicOr((p), (v))
+#define OG_ATOMIC_ADD(p, v) atomicAdd((p), (v))         /* returns the value before */
 // the same for the kernels that run OG_WGT-lane workgroups (the CELT tail kernel)
 #define OG_TLANES_BEGIN(tid) { const int tid = (int)threadIdx.x; {
 #define OG_TLANES_END } } __syncthreads();
@@ -134,6 +135,7 @@ OG_DEV OgC2 og_c2_fma(OgC2 a, float s, OgC2 b) { return __builtin_elementwise_fm
 #define OG_LANES_BEGIN(tid) for (int tid = 0; tid < OG_WG; tid++) { {
 #define OG_LANES_END } }
 #define OG_ATOMIC_OR(p, v) (*(p) |= (v))
+#define OG_ATOMIC_ADD(p, v) ((*(p) += (v)) - (v))
 #define OG_TLANES_BEGIN(tid) for (int tid = 0; tid < OG_WGT; tid++) { {
 #define OG_TLANES_END } }
 #define OG_TWAVES_BEGIN(w) for (int w = 0; w < OG_WGT / 64; w++) { {

@@ -30,9 +30,31 @@ extern "C" int emu_launch_celt(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, u
             og_pvq_lane(refs[r], leaves[refs[r].leaf], work.data(), T.pvq_u2, x, 1, dbg ? dbg->pulses : nullptr, nullptr);
         }
     }
+    // the band plan in both its forms (three steps / one lane start to end, celt_plan.h): they must agree on everything the
+    // frame kernel reads; the frames then go on with one or the other, alternately
+    int plan_mismatches = 0;
     for (uint32_t f = 0; f < nframes; f++) {
+        uint32_t cm[48];
+        std::memcpy(cm, og_work_cm(work.data(), f), sizeof cm);
+        og_plan_frame(hdr + f, leaves, f, T.k, T.lcg_a, T.lcg_c, work.data());
+        static OgBandPlan A;
+        OgBandPlan *P = og_work_plan(work.data(), f);
+        std::memcpy(&A, P, sizeof A);
+        std::memset(P, 0xFF, sizeof *P);
+        std::memcpy(og_work_cm(work.data(), f), cm, sizeof cm);
         uint16_t sc[OG_PLAN_SCRATCH];
-        og_plan_frame(hdr + f, leaves, f, T.k, T.lcg_a, T.lcg_c, work.data(), OgLaneScratch{sc, 1});
+        og_plan_frame_lane(hdr + f, leaves, f, T.k, T.lcg_a, T.lcg_c, work.data(), OgLaneScratch{sc, 1});
+        int ntasks = 0;
+        for (int t = 0; t < 42; t++) ntasks += (A.task[t].flags & OG_T_ACTIVE) != 0;
+        bool same = std::memcmp(A.task, P->task, sizeof A.task) == 0 && std::memcmp(A.collapse, P->collapse, sizeof A.collapse) == 0 &&
+                    A.seed_out == P->seed_out && A.nops == P->nops && A.merge_cnt == P->merge_cnt && A.nlevels == P->nlevels &&
+                    A.merge_level == P->merge_level && A.plain[0] == P->plain[0] && A.plain[1] == P->plain[1] && A.joint == P->joint &&
+                    A.keep[0] == P->keep[0] && A.keep[1] == P->keep[1] &&
+                    std::memcmp(A.task_start, P->task_start, A.nlevels + 3) == 0 &&
+                    std::memcmp(A.order, P->order, A.task_start[A.nlevels + 2]) == 0 && A.task_start[A.nlevels + 2] <= ntasks &&
+                    std::memcmp(A.op, P->op, sizeof(OgFillOp) * A.nops) == 0;
+        if (!same) plan_mismatches++;
+        if (f & 1) std::memcpy(P, &A, sizeof A);
     }
     for (uint32_t f = 0; f < nframes; f++) {
         std::memset(&L, 0xFF, sizeof L);               // LDS starts undefined on the device
@@ -50,7 +72,7 @@ extern "C" int emu_launch_celt(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, u
     const uint32_t fpg = frames_per_group ? frames_per_group : 1;
     for (uint32_t f = 0; f < nframes; f += fpg)         // the tail kernel: one workgroup per group, frames in order
         og_celt_tail_group(hdr + f, nframes - f < fpg ? nframes - f : fpg, state, pcm, pcm_stride, Lt, nullptr, work.data(), f);
-    return 0;
+    return plan_mismatches;
 }
 extern "C" size_t emu_lds_bytes(void) { return sizeof(OgCeltLds); }
 extern "C" size_t emu_tail_lds_bytes(void) { return sizeof(OgTailLds); }
@@ -62,8 +84,7 @@ extern "C" void emu_plan_stats(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, u
     static bool init = false;
     if (!init) { og_fill_celt_tables(&T); init = true; }
     std::vector<float> work(OG_WORK_BYTES(f + 1) / 4 + 4, 0.f);
-    uint16_t sc[OG_PLAN_SCRATCH];
-    og_plan_frame(hdr + f, leaves, f, T.k, T.lcg_a, T.lcg_c, work.data(), OgLaneScratch{sc, 1});
+    og_plan_frame(hdr + f, leaves, f, T.k, T.lcg_a, T.lcg_c, work.data());
     const OgBandPlan *P = og_work_plan(work.data(), f);
     out[0] = P->nlevels; out[1] = P->nops; out[2] = P->merge_level;
     int xf0 = 0, xfn = 0, act = 0;

@@ -35,7 +35,8 @@ def _run(emu, packets, channels):
             off += hp.fi[f].frame_size
         pulses = np.zeros((n, 2, 960), np.int16)
         dbg = A.CeltDebug(pulses.ctypes.data, None, None, None)
-        emu.emu_launch_celt(hp.celt, hp.leaves, n, 1, C.byref(st), pcm.ctypes.data, 5760 * channels, C.byref(dbg))
+        rc = emu.emu_launch_celt(hp.celt, hp.leaves, n, 1, C.byref(st), pcm.ctypes.data, 5760 * channels, C.byref(dbg))
+        assert rc == 0, f"packet {i}: the two forms of the band plan differ on {rc} frame(s)"
         check_pcm(r, pcm[: off * channels].reshape(off, channels), f"packet {i}")
         t = ref.trace
         assert np.array_equal(pulses[n - 1][: t.C], np.ctypeslib.as_array(t.pulses)[: t.C]), f"packet {i}: PVQ pulses"
@@ -74,7 +75,8 @@ def _run_grouped(emu, packets, channels, per_group, reset_at=()):
             leaves.append(bytes(C.string_at(C.addressof(hp.leaves), nl * 16)))
         hb, lb = b"".join(hdrs), b"".join(leaves) or bytes(16)
         pcm = np.zeros(off * channels + 16, np.float32)
-        emu.emu_launch_celt(hb, lb, len(hdrs), len(hdrs), C.byref(st), pcm.ctypes.data, off * channels + 16, None)
+        rc = emu.emu_launch_celt(hb, lb, len(hdrs), len(hdrs), C.byref(st), pcm.ctypes.data, off * channels + 16, None)
+        assert rc == 0, f"group at packet {g0}: the two forms of the band plan differ on {rc} frame(s)"
         r = np.concatenate(want)
         check_pcm(r, pcm[: off * channels].reshape(off, channels), f"group at packet {g0}")
 
