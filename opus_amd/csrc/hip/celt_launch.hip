@@ -17,11 +17,16 @@
 // against 201: fewer, longer workgroups balance worse over the CUs than the table staging costs.)
 struct OgPvqClasses { uint32_t cnt[4], wg0[4]; };      // leaves per class (largest first); first workgroup of each class
 #define OG_K1_BATCHES(c) 1u
-__global__ __launch_bounds__(256) void og_pvq_all_kernel(const OgLeafRef *__restrict__ refs, OgPvqClasses cl,
+// Register budget: five wavefronts per SIMD (96 VGPRs, which the plain instantiation meets without spilling; measured, round 2:
+// 203 us at the compiler's own choice of 110 VGPRs = four per SIMD, 189 us at five, 202 us at six = 80 VGPRs with 29 spills).
+template <bool DBG>                   // DBG: stage dumps / profiling stamps wanted (the plain instantiation carries none of that code)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void og_pvq_all_kernel(const OgLeafRef *__restrict__ refs, OgPvqClasses cl,
                                                          const OgCeltLeaf *__restrict__ leaves,
                                                          uint32_t nframes, const OgCeltTables *__restrict__ T, void *work,
-                                                         int16_t *dbg_pulses, uint64_t *dbg_cycles)
+                                                         int16_t *dbg_pulses_, uint64_t *dbg_cycles_)
 {
+    int16_t *const dbg_pulses = DBG ? dbg_pulses_ : nullptr;
+    uint64_t *const dbg_cycles = DBG ? dbg_cycles_ : nullptr;
     __shared__ uint32_t U2[15 * OG_U2_STRIDE];
     __shared__ float x[3072];                           // 176 * 16 = 2816, 64 * 32 = 2048, 24 * 128 = 3072, 8 * 256 = 2048
     // Workgroup order: the two large classes keep one 16 / 32-lane wavefront busy for ~100 us each while holding a full
@@ -303,7 +308,8 @@ int opusgpu_launch_celt_pvq(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, uint
             const uint32_t per_wg = lanes[c] * OG_K1_BATCHES(c);
             if ((only >> c) & 1) wg += (class_counts[c] + per_wg - 1) / per_wg;
         }
-        if (wg) hipLaunchKernelGGL(og_pvq_all_kernel, dim3(wg), dim3(256), 0, st, refs, cl, leaves, nframes, T, work, dbg.pulses, dbg.cycles);
+        if (wg && (dbg.pulses || dbg.cycles)) hipLaunchKernelGGL(og_pvq_all_kernel<true>, dim3(wg), dim3(256), 0, st, refs, cl, leaves, nframes, T, work, dbg.pulses, dbg.cycles);
+        else if (wg) hipLaunchKernelGGL(og_pvq_all_kernel<false>, dim3(wg), dim3(256), 0, st, refs, cl, leaves, nframes, T, work, nullptr, nullptr);
     }
     // launches that fill the chip take the one-lane form (see og_plan_lane_kernel); OPUSGPU_PLAN = lane | steps overrides (profiling)
     static const int plan_form = [] { const char *e = getenv("OPUSGPU_PLAN"); return !e ? 0 : e[0] == 'l' ? 1 : e[0] == 's' ? 2 : 0; }();
