@@ -1136,12 +1136,12 @@ OG_DEV void og_celt_spectrum(const OgCeltHdr *hg, const OgBandPlan *plan, const 
         for (int j = 0; j < 4; j++) {
             const int q = tid + j * OG_WG;
             if (q < CC * (N >> 1)) {
-                const OgC2 v = og_c2_mulc(((const OgC2 *)src)[q], OG_LV(twr).w[j]);
-                const float vr = v.x, vi = v.y;
-                const int t = q & tmask, k = q >> tsh, ch = t >> bsh, b = t & (B - 1);
-                float *D = coef_row + ch * 960 + OG_MUL24(NB, b);
-                D[2 * k] = vi;
-                D[NB - 1 - 2 * k] = -vr;
+                const OgC2 v = og_c2_mulc(((const OgC2 *)src)[q], OG_LV(twr).w[j]);          // (Z.r w.r + Z.i w.i, Z.i w.r - Z.r w.i)
+                const uint32_t t = (uint32_t)q & (uint32_t)tmask, k = (uint32_t)q >> tsh, ch = t >> bsh, b = t & (uint32_t)(B - 1);
+                const uint32_t base = ch * 960u + (uint32_t)OG_MUL24(NB, (int)b);         // 32-bit byte offsets from the row's (uniform) address
+                char *row = (char *)coef_row;
+                *(float *)(row + ((base + 2u * k) << 2)) = v.y;
+                *(float *)(row + ((base + (uint32_t)NB - 1u - 2u * k) << 2)) = -v.x;
             }
         }
         OG_LANES_END
