@@ -1170,16 +1170,7 @@ struct alignas(16) OgTailLds {
     float pad_[2];
 };
 
-// the head of OgCeltHdr (everything up to the band arrays): what the tail needs, fetched in one go
-struct OgHdrHead {
-    uint32_t stream, pcm_off, leaf_begin, seed;
-    uint16_t nleaves;
-    uint8_t lm, flags, start, end, spread, intensity;     // spread: also the cross-fade kind and launch round (opusgpu_sideinfo.h)
-    uint16_t pf_period[3];
-    uint8_t pf_gain_q[3], pf_tapset[3];
-};
-static_assert(sizeof(OgHdrHead) == 36 && offsetof(OgCeltHdr, pf_tapset) == offsetof(OgHdrHead, pf_tapset) &&
-              offsetof(OgCeltHdr, flags) == offsetof(OgHdrHead, flags), "OgHdrHead mirrors the start of OgCeltHdr");
+// (OgHdrHead, celt_plan.h: the head of OgCeltHdr, everything up to the band arrays, is what the tail needs of a header)
 
 // comb post-filter state of a frame (RFC 6716 4.3.7.1): sets [0] old, [1] current, [2] new; how far back it reads
 OG_DEV bool og_pf_on(const OgHdrHead &h) { return h.pf_gain_q[0] != 0 || h.pf_gain_q[1] != 0 || ((h.lm & 3) != 0 && h.pf_gain_q[2] != 0); }

@@ -72,74 +72,91 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
     }
 }
 
-// Band plan (celt_plan.h) of OG_PLAN_FPW frames per 256-lane workgroup, in three steps: a work item per (frame, band) for what
+// Band plan (celt_plan.h) of OG_PLAN_FPW frames per 128-lane workgroup, in three steps: a work item per (frame, band) for what
 // the bands do not share, a lane per frame for the recurrences over the bands (the only serial part: the other wavefronts
-// wait at the barrier), a work item per (frame, task) for the records out and their order.  What the steps read and index
-// sits in LDS: the workgroup's headers (copied in coalesced), the small constant tables, and an OgPlanShared per frame.
-// (Round 2, one lane per frame for everything: 94 us per 32 768 frames, 76 us per 4 096 -- the length of one lane's
-// instruction chain; the split cuts that chain to the recurrences.)
+// wait at the barrier), the (frame, band) work items again for the records out.  A work item keeps its band's two task
+// records in registers from the first step to the last.  What the steps read and index sits in LDS: the head and the band
+// records of the workgroup's headers (93 of a header's 188 dwords), the small constant tables, an OgPlanShared per frame:
+// 18.2 KB, eight workgroups per CU.
+// (Round 2, one lane per frame for everything -- og_plan_lane_kernel below: 94 us per 32 768 frames, 76 us per 4 096, the
+// length of one lane's instruction chain.  The split cuts that chain to the recurrences: 74 and 47 us.  What it took to win at
+// the large size as well: all 2 048 workgroups resident at once, i.e. the 18 KB of LDS and two wavefronts per workgroup;
+// with the task records in LDS -- 31 KB, five workgroups per CU -- it took 111 us; a 64-lane workgroup 5 us more than 128.)
 #define OG_PLAN_FPW 16
-#define OG_PLAN_WG 256
-#define OG_PLAN_STEPS_MAX 16384       // frames per launch up to which the three-step kernel is used
-__global__ __launch_bounds__(OG_PLAN_WG) void og_plan_kernel(const OgCeltHdr *__restrict__ hdr, const OgCeltLeaf *__restrict__ leaves,
-                                                             uint32_t nframes, const OgCeltTables *__restrict__ T, void *work)
+#define OG_PLAN_WG 128                /* two wavefronts: eight workgroups per CU are then four wavefronts per SIMD (109 VGPRs) */
+#define OG_PLAN_ITEMS ((OG_PLAN_FPW * 21 + OG_PLAN_WG - 1) / OG_PLAN_WG)      /* (frame, band) work items per lane */
+#define OG_PLAN_HW 93                 // dwords kept of a header: head (9) + band records (21 x 4)
+__global__ __launch_bounds__(OG_PLAN_WG) __attribute__((amdgpu_waves_per_eu(4, 8))) void og_plan_kernel(const OgCeltHdr *__restrict__ hdr, const OgCeltLeaf *__restrict__ leaves,
+                                                             uint32_t nframes, const OgCeltTables *__restrict__ T, void *work,
+                                                             int stop /* profiling aid: leave after step `stop` (1 = A, 2 = B) */)
 {
-    static_assert(sizeof(OgCeltHdr) % 4 == 0, "headers are copied as dwords");
-    __shared__ uint32_t hs[OG_PLAN_FPW * sizeof(OgCeltHdr) / 4];
+    static_assert(sizeof(OgHdrHead) == 36 && sizeof(OgCeltBand) == 16 && offsetof(OgCeltHdr, band) % 4 == 0 && OG_MAX_BANDS == 21, "header pieces as dwords");
+    __shared__ uint32_t hs[OG_PLAN_FPW * OG_PLAN_HW];
     __shared__ OgCeltConst K;
     __shared__ uint32_t la[184], lc[184];
     __shared__ OgPlanShared S[OG_PLAN_FPW];
     const uint32_t tid = threadIdx.x;
     const uint32_t f0 = blockIdx.x * OG_PLAN_FPW, nf = nframes - f0 < OG_PLAN_FPW ? nframes - f0 : OG_PLAN_FPW;
-    const uint32_t *src = (const uint32_t *)(hdr + f0);
-    for (uint32_t p = tid; p < nf * (sizeof(OgCeltHdr) / 4); p += OG_PLAN_WG) hs[p] = src[p];
-    for (uint32_t p = tid; p < sizeof(OgCeltConst) / 4; p += OG_PLAN_WG) ((uint32_t *)&K)[p] = ((const uint32_t *)&T->k)[p];
-    for (uint32_t p = tid; p < 184; p += OG_PLAN_WG) { la[p] = T->lcg_a[p]; lc[p] = T->lcg_c[p]; }
+    constexpr uint32_t BOFF = offsetof(OgCeltHdr, band) / 4;
     {
-        // what the steps OR into or read before writing: bits .. the end of OgPlanShared
-        constexpr uint32_t Z0 = offsetof(OgPlanShared, bits) / 4, ZN = sizeof(OgPlanShared) / 4 - Z0;
-        static_assert(offsetof(OgPlanShared, bits) % 4 == 0, "cleared as dwords");
-        for (uint32_t p = tid; p < nf * ZN; p += OG_PLAN_WG) {
-            const uint32_t fr = p / ZN;
-            ((uint32_t *)&S[fr])[Z0 + p - fr * ZN] = 0;
+        // every fetch first (one memory round trip for all of them), then the LDS stores
+        constexpr int NH = (OG_PLAN_FPW * OG_PLAN_HW + OG_PLAN_WG - 1) / OG_PLAN_WG, NK = (sizeof(OgCeltConst) / 4 + OG_PLAN_WG - 1) / OG_PLAN_WG;
+        static_assert(2 * OG_PLAN_WG >= 184, "the LCG maps in two pieces per lane");
+        uint32_t hv[NH], kv[NK], av[2], cv[2];
+#pragma unroll
+        for (int r = 0; r < NH; r++) {
+            const uint32_t p = tid + r * OG_PLAN_WG, q = p < nf * OG_PLAN_HW ? p : 0u;
+            const uint32_t fr = q / OG_PLAN_HW, j = q - fr * OG_PLAN_HW;
+            hv[r] = ((const uint32_t *)(hdr + f0 + fr))[j < 9 ? j : BOFF + (j - 9)];
+        }
+#pragma unroll
+        for (int r = 0; r < NK; r++) { const uint32_t p = tid + r * OG_PLAN_WG; kv[r] = ((const uint32_t *)&T->k)[p < sizeof(OgCeltConst) / 4 ? p : 0u]; }
+#pragma unroll
+        for (int r = 0; r < 2; r++) { const uint32_t p = tid + r * OG_PLAN_WG; av[r] = T->lcg_a[p < 184u ? p : 0u]; cv[r] = T->lcg_c[p < 184u ? p : 0u]; }
+#pragma unroll
+        for (int r = 0; r < NH; r++) { const uint32_t p = tid + r * OG_PLAN_WG; if (p < nf * OG_PLAN_HW) hs[p] = hv[r]; }
+#pragma unroll
+        for (int r = 0; r < NK; r++) { const uint32_t p = tid + r * OG_PLAN_WG; if (p < sizeof(OgCeltConst) / 4) ((uint32_t *)&K)[p] = kv[r]; }
+#pragma unroll
+        for (int r = 0; r < 2; r++) { const uint32_t p = tid + r * OG_PLAN_WG; if (p < 184u) { la[p] = av[r]; lc[p] = cv[r]; } }
+        for (uint32_t p = tid; p < nf * (sizeof(OgPlanShared) / 4); p += OG_PLAN_WG) ((uint32_t *)&S[0])[p] = 0;
+    }
+    __syncthreads();
+    OgTask tk[OG_PLAN_ITEMS][2];      // the work items' task records
+#pragma unroll
+    for (int r = 0; r < OG_PLAN_ITEMS; r++) {
+        const uint32_t p = tid + r * OG_PLAN_WG;
+        if (p < nf * 21) {
+            const uint32_t fr = p / 21, i = p - fr * 21;
+            const OgHdrHead &h = *(const OgHdrHead *)(hs + fr * OG_PLAN_HW);
+            og_plan_band_a(h, (const OgCeltBand *)(hs + fr * OG_PLAN_HW + 9), leaves + h.leaf_begin, K, og_work_cm(work, f0 + fr),
+                           og_work_coef(work, f0 + fr), (int)i, S[fr], tk[r]);
         }
     }
-    __syncthreads();
-    // K1's collapse masks (48 words per frame): fetched coalesced, handed back zeroed, and kept over the band energies (energy, prev_min) of
-    // the LDS header copies, which the plan does not read
-    static_assert(offsetof(OgCeltHdr, energy) % 4 == 0 && offsetof(OgCeltHdr, band) - offsetof(OgCeltHdr, energy) >= 48 * 4, "room for the masks (over energy + prev_min)");
-    constexpr uint32_t HW = sizeof(OgCeltHdr) / 4, EOFF = offsetof(OgCeltHdr, energy) / 4;
-    for (uint32_t p = tid; p < nf * 48; p += OG_PLAN_WG) {
-        const uint32_t fr = p / 48, j = p - fr * 48;
-        uint32_t *cm = og_work_cm(work, f0 + fr);
-        hs[fr * HW + EOFF + j] = cm[j];
-        cm[j] = 0;
-    }
-    __syncthreads();
-    for (uint32_t p = tid; p < nf * 21; p += OG_PLAN_WG) {
-        const uint32_t fr = p / 21, i = p - fr * 21;
-        const OgCeltHdr *h = (const OgCeltHdr *)hs + fr;
-        og_plan_band_a(h, leaves + h->leaf_begin, K, hs + fr * HW + EOFF, og_work_coef(work, f0 + fr), (int)i, S[fr]);
-    }
+    if (stop == 1) return;
     __syncthreads();
     if (tid < nf) {
-        const OgCeltHdr *h = (const OgCeltHdr *)hs + tid;
-        og_plan_chain(h, leaves + h->leaf_begin, K, la, lc, hs + tid * HW + EOFF, og_work_plan(work, f0 + tid), S[tid]);
+        const OgHdrHead &h = *(const OgHdrHead *)(hs + tid * OG_PLAN_HW);
+        og_plan_chain(h, (const OgCeltBand *)(hs + tid * OG_PLAN_HW + 9), leaves + h.leaf_begin, K, la, lc, og_work_plan(work, f0 + tid), S[tid]);
     }
+    if (stop == 2) return;
     __syncthreads();
-    for (uint32_t p = tid; p < nf * 42; p += OG_PLAN_WG) {
-        const uint32_t fr = p / 42, t = p - fr * 42;
-        og_plan_emit((int)t, og_work_plan(work, f0 + fr), S[fr]);
+#pragma unroll
+    for (int r = 0; r < OG_PLAN_ITEMS; r++) {
+        const uint32_t p = tid + r * OG_PLAN_WG;
+        if (p < nf * 21) {
+            const uint32_t fr = p / 21, i = p - fr * 21;
+            const OgHdrHead &h = *(const OgHdrHead *)(hs + fr * OG_PLAN_HW);
+            og_plan_emit(h, (const OgCeltBand *)(hs + fr * OG_PLAN_HW + 9), (int)i, tk[r], og_work_plan(work, f0 + fr), S[fr]);
+        }
     }
 }
 
 #define OG_PLAN_LANE_FPW 16
-// The band plan of a LARGE launch: one lane per frame start to end (og_band_plan_lane), OG_PLAN_LANE_FPW frames per wavefront.
-// Fewer instructions in all than the three steps above (which pay for their work items' set-up), and with every SIMD holding
-// two such wavefronts the chain's length no longer matters: 94 us against 111 for 32 768 frames; 76 against 47 for 4 096.  The per-lane code is one long serial
-// chain, so what it reads and indexes sits in LDS: the workgroup's headers (copied in coalesced; a lane's header is 188
-// dwords from its neighbour's), the small constant tables, and
-// a row of scratch cells per lane for the arrays it indexes at run time.
+// The same plan by one lane per frame start to end (og_band_plan_lane), OG_PLAN_LANE_FPW frames per wavefront: the form the
+// three steps replaced, kept as their cross-check (the CPU emulation runs both on every frame) and behind OPUSGPU_PLAN=lane.
+// The per-lane code is one long serial chain, so what it reads and indexes sits in LDS: the workgroup's headers (copied in
+// coalesced), the small constant tables, and a row of scratch cells per lane for the arrays it indexes at run time.
 __global__ __launch_bounds__(64) void og_plan_lane_kernel(const OgCeltHdr *__restrict__ hdr, const OgCeltLeaf *__restrict__ leaves,
                                                      uint32_t nframes, const OgCeltTables *__restrict__ T, void *work)
 {
@@ -311,12 +328,15 @@ int opusgpu_launch_celt_pvq(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, uint
         if (wg && (dbg.pulses || dbg.cycles)) hipLaunchKernelGGL(og_pvq_all_kernel<true>, dim3(wg), dim3(256), 0, st, refs, cl, leaves, nframes, T, work, dbg.pulses, dbg.cycles);
         else if (wg) hipLaunchKernelGGL(og_pvq_all_kernel<false>, dim3(wg), dim3(256), 0, st, refs, cl, leaves, nframes, T, work, nullptr, nullptr);
     }
-    // launches that fill the chip take the one-lane form (see og_plan_lane_kernel); OPUSGPU_PLAN = lane | steps overrides (profiling)
-    static const int plan_form = [] { const char *e = getenv("OPUSGPU_PLAN"); return !e ? 0 : e[0] == 'l' ? 1 : e[0] == 's' ? 2 : 0; }();
-    if (plan_form == 1 || (plan_form == 0 && nframes > OG_PLAN_STEPS_MAX))
+    // OPUSGPU_PLAN=lane: the one-lane form instead (profiling: see og_plan_lane_kernel)
+    static const bool plan_lane = [] { const char *e = getenv("OPUSGPU_PLAN"); return e && e[0] == 'l'; }();
+    if (plan_lane)
         hipLaunchKernelGGL(og_plan_lane_kernel, dim3((nframes + OG_PLAN_LANE_FPW - 1) / OG_PLAN_LANE_FPW), dim3(64), 0, st, hdr, leaves, nframes, T, work);
     else
-        hipLaunchKernelGGL(og_plan_kernel, dim3((nframes + OG_PLAN_FPW - 1) / OG_PLAN_FPW), dim3(OG_PLAN_WG), 0, st, hdr, leaves, nframes, T, work);
+    {
+        static const int plan_stop = getenv("OPUSGPU_PLAN_STOP") ? atoi(getenv("OPUSGPU_PLAN_STOP")) : 0;       // profiling aid
+        hipLaunchKernelGGL(og_plan_kernel, dim3((nframes + OG_PLAN_FPW - 1) / OG_PLAN_FPW), dim3(OG_PLAN_WG), 0, st, hdr, leaves, nframes, T, work, plan_stop);
+    }
     OG_HIP(hipGetLastError());
     return OPUSGPU_OK;
 }

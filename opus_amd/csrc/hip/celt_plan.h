@@ -83,32 +83,53 @@ OG_DEV void og_make_xform(int n, int B, int tf_change, OgXform *t, int *recombin
 }
 
 // The plan of a frame is made in three steps, so that only what is a recurrence over the bands runs as one:
-//   A  per band (21 independent work items): task geometry, the masks `keep` / `joint` / `plain`, the one-bin bands' signs,
-//      the collapse masks of the calls without live fill leaves;
+//   A  per band (21 independent work items): the band's two task records (kept by the work item), the masks `keep` / `joint` /
+//      `plain`, the one-bin bands' signs, the collapse masks of the calls without live fill leaves; K1's masks are consumed
+//      (and re-zeroed) here;
 //   B  per frame (serial over the bands that have fill leaves or the dual -> intensity switch): levels, which fill leaves
-//      are live and their seeds, the collapse masks that depend on lower bands;
-//   C  per task (42 independent work items): the task records out, their order by level (each task counts the tasks in
-//      front of it), the small header fields.
-// OgPlanShared holds a frame's plan between the steps (LDS in the kernel, one per frame of the workgroup).
+//      are live and their seeds, the collapse masks that depend on lower bands, the tasks' order by level;
+//   C  per band again: step B's amendments applied to the two task records, records out; the low work items also write
+//      the order and the header fields.
+// OgPlanShared holds what passes between the steps (LDS in the kernel, one per frame of the workgroup: 628 bytes, so that
+// eight workgroups of 16 frames fit a CU).  The steps read the frame's header through its head (OgHdrHead) and its band
+// records, which is what the kernel keeps of it in LDS.
+struct OgHdrHead {                    // the head of OgCeltHdr (everything up to the band arrays), fetched in one go
+    uint32_t stream, pcm_off, leaf_begin, seed;
+    uint16_t nleaves;
+    uint8_t lm, flags, start, end, spread, intensity;     // spread: also the cross-fade kind and launch round (opusgpu_sideinfo.h)
+    uint16_t pf_period[3];
+    uint8_t pf_gain_q[3], pf_tapset[3];
+};
+static_assert(sizeof(OgHdrHead) == 36 && offsetof(OgCeltHdr, pf_tapset) == offsetof(OgHdrHead, pf_tapset) &&
+              offsetof(OgCeltHdr, flags) == offsetof(OgHdrHead, flags), "OgHdrHead mirrors the start of OgCeltHdr");
+
 enum { OG_PB_CHAIN0 = 1, OG_PB_CHAIN1 = 2, OG_PB_SERIAL = 4 /* step B has work here */, OG_PB_CODED = 8 /* inside [start, end), not silent */ };
 struct OgPlanBand {                   // step A -> step B
     uint8_t flags;                    // OG_PB_*
     uint8_t cm[2];                    // collapse masks of the calls step B leaves alone
-    uint8_t rc[2], td[2], B0[2];      // per call: recombine, time_divide, blocks after recombination (og_make_xform)
-    uint8_t pad_[3];
+    uint8_t rctd[2], B0[2];           // per call: recombine | time_divide << 4; blocks after recombination (og_make_xform)
+    uint8_t pad_;
+    uint16_t raw[2];                  // K1's collapse mask of the call's PVQ leaves
 };
+// step B's amendment of a task with live fill leaves: level | OG_PA_NEED_LB | OG_PA_LB_ROW1 | ops << 16 (0: none)
+enum { OG_PA_LEVEL = 31, OG_PA_NEED_LB = 32, OG_PA_LB_ROW1 = 64 };
 struct OgPlanShared {
-    OgTask task[42];
     OgPlanBand rec[21];
+    uint32_t amend[42];
     uint32_t bits[5];                 // keep[0], keep[1], joint, plain[0], plain[1]: OR-ed together by the bands' work items
     uint32_t seed_out;
     uint16_t nops, merge_cnt;
     uint8_t maxlvl, merge_level;
     uint8_t tl[42];                   // level of the active tasks that go into `order` (0xFF: not in it)
     uint8_t col[2][21], blevel[21];   // step B's running arrays (col: the bands' collapse masks, as the fill of higher bands reads them)
-    uint8_t pad_[13];
+    uint8_t pad_[1];
+    uint8_t order[44];                // as in OgBandPlan (dword-aligned here as there: step C copies them as dwords)
+    uint8_t task_start[OG_MAXLEVEL + 3], zero_[2];      // + the plan's two pad bytes behind it
 };
-static_assert(sizeof(OgPlanBand) == 12 && sizeof(OgPlanShared) % 16 == 0, "OgPlanShared: a whole number of 16-byte pieces");
+static_assert(offsetof(OgPlanShared, order) % 4 == 0 && offsetof(OgPlanShared, task_start) % 4 == 0 && offsetof(OgBandPlan, order) % 4 == 0 &&
+              offsetof(OgBandPlan, task_start) % 4 == 0 && offsetof(OgBandPlan, task_start) + OG_MAXLEVEL + 3 + 3 <= offsetof(OgBandPlan, op),
+              "order and task_start are copied as dwords");
+static_assert(sizeof(OgPlanBand) == 12 && sizeof(OgPlanShared) == 628, "OgPlanShared: an odd number of dwords (the frames' lanes of step B hit distinct banks)");
 // (Step B fetches its fill leaves from the leaf array, one memory round trip each.  Staging them in LDS in step A was
 // measured, round 2: no faster for a small launch, 25 % slower for a large one -- the LDS it takes costs a workgroup per CU.)
 
@@ -119,19 +140,20 @@ OG_DEV int og_plan_nfill(const OgCeltBand &bd, int slot, int nleaves)
     return left <= 0 ? 0 : nfill < left ? nfill : left;
 }
 
-// cm_row: K1's collapse masks [buffer][24]; coef_row: the frame's K1 output (the signs of the one-bin bands are added to it)
-OG_DEV void og_plan_band_a(const OgCeltHdr *h, const OgCeltLeaf *lv, const OgCeltConst &K, const uint32_t *cm_row, float *coef_row,
-                           int i, OgPlanShared &S)
+// cm_row: K1's collapse masks [buffer][24] (global: read and re-zeroed here); coef_row: the frame's K1 output (the signs of the
+// one-bin bands are added to it); tk[2]: the band's task records
+OG_DEV void og_plan_band_a(const OgHdrHead &h, const OgCeltBand *bands, const OgCeltLeaf *lv, const OgCeltConst &K, uint32_t *cm_row,
+                           float *coef_row, int i, OgPlanShared &S, OgTask tk[2])
 {
-    const int lm = h->lm, M = 1 << lm, start = h->start, end = h->end;
-    const int C = (h->flags & OG_F_STEREO) ? 2 : 1;
-    const int B = (h->flags & OG_F_TRANSIENT) ? M : 1;
-    const int nleaves = h->nleaves < OG_MAXLEAF ? h->nleaves : OG_MAXLEAF;
-    const bool silence = (h->flags & OG_F_SILENCE) != 0;
-    OgTask tk[2];
+    const int lm = h.lm, M = 1 << lm, start = h.start, end = h.end;
+    const int C = (h.flags & OG_F_STEREO) ? 2 : 1;
+    const int B = (h.flags & OG_F_TRANSIENT) ? M : 1;
+    const int nleaves = h.nleaves < OG_MAXLEAF ? h.nleaves : OG_MAXLEAF;
+    const bool silence = (h.flags & OG_F_SILENCE) != 0;
     OgPlanBand r;
-    r.flags = 0; r.cm[0] = r.cm[1] = 0; r.rc[0] = r.rc[1] = r.td[0] = r.td[1] = 0; r.B0[0] = r.B0[1] = 1;
-    r.pad_[0] = r.pad_[1] = r.pad_[2] = 0;
+    r.flags = 0; r.cm[0] = r.cm[1] = 0; r.rctd[0] = r.rctd[1] = 0; r.B0[0] = r.B0[1] = 1; r.pad_ = 0;
+    r.raw[0] = (uint16_t)cm_row[i]; r.raw[1] = (uint16_t)cm_row[24 + i];
+    cm_row[i] = 0; cm_row[24 + i] = 0;
     int tl[2] = {0xFF, 0xFF};
     for (int slot = 0; slot < 2; slot++) {
         OgTask &t = tk[slot];
@@ -139,7 +161,7 @@ OG_DEV void og_plan_band_a(const OgCeltHdr *h, const OgCeltLeaf *lv, const OgCel
         t.flags = t.hm = t.slog = t.rctd = t.level = 0; t.norm_row = 0xFF;
     }
     if (!(silence || i < start || i >= end)) {
-        const OgCeltBand bd = h->band[i];
+        const OgCeltBand bd = bands[i];
         const int n = M * K.width[i], boff = M * K.ebands[i];
         r.flags = OG_PB_CODED;
         // leaves of this band that write a buffer with pulses (or a sign): all of them but the fill-path ones
@@ -174,11 +196,11 @@ OG_DEV void og_plan_band_a(const OgCeltHdr *h, const OgCeltLeaf *lv, const OgCel
             og_make_xform(n, B, bd.tf_change, &xf, &rc, &td, &B0);
             t.hm = (uint8_t)xf.hm; t.slog = (uint8_t)xf.slog; t.n0p = (uint16_t)xf.n0p;
             t.rctd = (uint8_t)(rc | td << 4);
-            r.rc[slot] = (uint8_t)rc; r.td[slot] = (uint8_t)td; r.B0[slot] = (uint8_t)B0;
+            r.rctd[slot] = t.rctd; r.B0[slot] = (uint8_t)B0;
             if (chain) {
                 r.flags |= (uint8_t)(OG_PB_CHAIN0 << slot);
             } else {                                    // its fill leaves (if any) are dead: the PVQ masks are all
-                int m = (int)cm_row[slot * 24 + i];
+                int m = r.raw[slot];
                 for (int k = 0, Bk = B0; k < td; k++) { Bk >>= 1; m |= m >> Bk; }
                 for (int k = 0; k < rc; k++) m = K.bit_deinterleave[m & 255];
                 r.cm[slot] = (uint8_t)(m & ((1 << ((B0 >> td) << rc)) - 1));
@@ -194,31 +216,29 @@ OG_DEV void og_plan_band_a(const OgCeltHdr *h, const OgCeltLeaf *lv, const OgCel
             }
         }
     }
-    S.task[2 * i] = tk[0];
-    S.task[2 * i + 1] = tk[1];
     S.rec[i] = r;
     S.tl[2 * i] = (uint8_t)tl[0];
     S.tl[2 * i + 1] = (uint8_t)tl[1];
 }
 
-// K, la, lc: the small constant tables (LDS copies in the kernel).  Fill ops go straight to the plan P.  S.col and S.blevel
-// are zero on entry.
-OG_DEV void og_plan_chain(const OgCeltHdr *h, const OgCeltLeaf *lv, const OgCeltConst &K, const uint32_t *la, const uint32_t *lc,
-                          const uint32_t *cm_row, OgBandPlan *P, OgPlanShared &S)
+// K, la, lc: the small constant tables (LDS copies in the kernel).  Fill ops go straight to the plan P.  S.amend, S.col,
+// S.blevel, S.order, S.task_start and S.zero_ are zero on entry.
+OG_DEV void og_plan_chain(const OgHdrHead &h, const OgCeltBand *bands, const OgCeltLeaf *lv, const OgCeltConst &K, const uint32_t *la,
+                          const uint32_t *lc, OgBandPlan *P, OgPlanShared &S)
 {
-    const int lm = h->lm, M = 1 << lm, start = h->start;
-    const int C = (h->flags & OG_F_STEREO) ? 2 : 1;
-    const int B = (h->flags & OG_F_TRANSIENT) ? M : 1;
-    const int nleaves = h->nleaves < OG_MAXLEAF ? h->nleaves : OG_MAXLEAF;
+    const int lm = h.lm, M = 1 << lm, start = h.start;
+    const int C = (h.flags & OG_F_STEREO) ? 2 : 1;
+    const int B = (h.flags & OG_F_TRANSIENT) ? M : 1;
+    const int nleaves = h.nleaves < OG_MAXLEAF ? h.nleaves : OG_MAXLEAF;
     const int norm_offset = M * K.ebands[start < 21 ? start : 20];
-    uint32_t seed = h->seed;
+    uint32_t seed = h.seed;
     int floor_lvl = 1, maxlvl = 0, merge_level = 0xFF, merge_cnt = 0, nops = 0;
     for (int i = 0; i < 21; i++) {
         const OgPlanBand r = S.rec[i];
         int cm[2] = {r.cm[0], r.cm[1]};
         bool dual = false;
         if (r.flags & OG_PB_SERIAL) {
-            const OgCeltBand bd = h->band[i];
+            const OgCeltBand bd = bands[i];
             const int boff = M * K.ebands[i];
             const bool any_chain = (r.flags & (OG_PB_CHAIN0 | OG_PB_CHAIN1)) != 0;
             dual = (bd.flags & OG_B_DUAL) != 0;
@@ -241,21 +261,18 @@ OG_DEV void og_plan_chain(const OgCeltHdr *h, const OgCeltLeaf *lv, const OgCelt
             if (lvl > OG_MAXLEVEL) lvl = OG_MAXLEVEL;   // cannot happen (one level per band at most, plus the switch)
             for (int slot = 0; slot < 2; slot++) {
                 if (!(r.flags & (OG_PB_CHAIN0 << slot))) continue;
-                OgTask &t = S.task[2 * i + slot];
-                const int rc = r.rc[slot], td = r.td[slot], B0 = r.B0[slot];
+                const int rc = r.rctd[slot] & 15, td = r.rctd[slot] >> 4, B0 = r.B0[slot];
                 // the integer half of a quant_band call with fill leaves: fill transforms (celt/decoder.rs:1700-1740),
                 // which leaves fold / make noise (:1633-1661), mask transforms (:1994-2019)
                 int fill = dual ? (slot ? y_cm : x_cm) : (x_cm | y_cm);
                 for (int k = 0; k < rc; k++) fill = K.bit_interleave[fill & 0xF] | K.bit_interleave[(fill >> 4) & 0xF] << 2;
                 for (int k = 0, Bk = B >> rc; k < td; k++, Bk <<= 1) fill |= fill << Bk;
-                t.level = (uint8_t)lvl;
+                uint32_t amend = (uint32_t)lvl;
                 S.tl[2 * i + slot] = (uint8_t)lvl;
-                if (bd.lowband != 0xFF && (bd.flags & (slot ? OG_B_FOLD_Y : OG_B_FOLD_X))) {
-                    t.flags |= OG_T_NEED_LB | ((dual && slot) ? OG_T_LB_ROW1 : 0);
-                    t.lowpos = (uint16_t)(bd.lowband * M);
-                }
+                if (bd.lowband != 0xFF && (bd.flags & (slot ? OG_B_FOLD_Y : OG_B_FOLD_X)))
+                    amend |= OG_PA_NEED_LB | ((dual && slot) ? OG_PA_LB_ROW1 : 0);
                 const int g0 = bd.leaf0 + (slot ? bd.nx : 0), nfill = og_plan_nfill(bd, slot, nleaves);
-                int m = (int)cm_row[slot * 24 + i];     // PVQ leaves: expanded (and masks collected) by K1
+                int m = r.raw[slot];                    // PVQ leaves: expanded (and masks collected) by K1
                 int live = 0;
                 const int first_op = nops;
                 for (int l = 0; l < nfill; l++) {
@@ -281,12 +298,12 @@ OG_DEV void og_plan_chain(const OgCeltHdr *h, const OgCeltLeaf *lv, const OgCelt
                 for (int k = 0, Bk = B0; k < td; k++) { Bk >>= 1; m |= m >> Bk; }
                 for (int k = 0; k < rc; k++) m = K.bit_deinterleave[m & 255];
                 cm[slot] = m & ((1 << ((B0 >> td) << rc)) - 1);
-                t.ops = (uint16_t)(live << 10 | (live ? first_op : 0));
+                S.amend[2 * i + slot] = amend | (uint32_t)(live << 10 | (live ? first_op : 0)) << 16;
             }
             if (any_chain) S.blevel[i] = (uint8_t)lvl;
             if (lvl > maxlvl) maxlvl = lvl;
         } else if (r.flags & OG_PB_CODED) {
-            dual = (h->band[i].flags & OG_B_DUAL) != 0;
+            dual = (bands[i].flags & OG_B_DUAL) != 0;
         }
         const int both = cm[0] | cm[1];
         S.col[0][i] = (uint8_t)(dual || C == 1 ? cm[0] : both);
@@ -295,21 +312,46 @@ OG_DEV void og_plan_chain(const OgCeltHdr *h, const OgCeltLeaf *lv, const OgCelt
     S.seed_out = seed;
     S.nops = (uint16_t)nops; S.merge_cnt = (uint16_t)merge_cnt;
     S.maxlvl = (uint8_t)maxlvl; S.merge_level = (uint8_t)merge_level;
+    // the active tasks ordered by level (band order inside a level), by the frame's lane: one pass over the 42 levels per
+    // level in use, the levels held in registers (fetched as dwords) and the write position in a register, so that no step
+    // waits for LDS (a counting sort does, twice per task: its counters are indexed by the level)
+    // (levels above maxlvl hold nothing: the frame kernel reads task_start[0 .. nlevels + 1])
+    {
+        static_assert(offsetof(OgPlanShared, tl) % 2 == 0, "tl is fetched in 16-bit pieces");
+        uint32_t lw[21];
+#pragma unroll
+        for (int k = 0; k < 21; k++) lw[k] = ((const uint16_t *)&S.tl[0])[k];
+        int n = 0;
+        for (int l = 0; l <= maxlvl; l++) {
+            S.task_start[l] = (uint8_t)n;
+#pragma unroll
+            for (int t = 0; t < 42; t++)
+                if ((int)((lw[t >> 1] >> (8 * (t & 1))) & 255u) == l) S.order[n++] = (uint8_t)t;
+        }
+        S.task_start[maxlvl + 1] = S.task_start[maxlvl + 2] = (uint8_t)n;
+    }
 }
 
-// work item t = 0 .. 41 of a frame: task t out, its place in `order`; the low work items also write the header fields
-OG_DEV void og_plan_emit(int t, OgBandPlan *P, const OgPlanShared &S)
+// the work item of band i again: step B's amendments applied to its two task records, records out; the low work items also
+// write the order and the header fields
+OG_DEV void og_plan_emit(const OgHdrHead &h, const OgCeltBand *bands, int i, OgTask tk[2], OgBandPlan *P, const OgPlanShared &S)
 {
-    P->task[t] = S.task[t];
-    const int lv = S.tl[t];
-    int before = 0, below = 0;                          // tasks in front of t in the order; tasks of a level below t's number
-    for (int u = 0; u < 42; u++) {
-        const int lu = S.tl[u];
-        before += (lu < lv || (lu == lv && u < t)) ? 1 : 0;
-        below += lu < t ? 1 : 0;                        // (0xFF is below no level)
+    for (int slot = 0; slot < 2; slot++) {
+        const uint32_t am = S.amend[2 * i + slot];
+        if (am) {
+            OgTask &t = tk[slot];
+            t.level = (uint8_t)(am & OG_PA_LEVEL);
+            if (am & OG_PA_NEED_LB) {
+                t.flags |= OG_T_NEED_LB | ((am & OG_PA_LB_ROW1) ? OG_T_LB_ROW1 : 0);
+                t.lowpos = (uint16_t)(bands[i].lowband << h.lm);
+            }
+            t.ops = (uint16_t)(am >> 16);
+        }
+        P->task[2 * i + slot] = tk[slot];
     }
-    if (lv != 0xFF) P->order[before] = (uint8_t)t;
-    if (t < OG_MAXLEVEL + 3) P->task_start[t] = (uint8_t)below;      // tasks of level l: order[task_start[l]] .. order[task_start[l + 1]]
+    const int t = i;
+    if (t < 11) ((uint32_t *)&P->order[0])[t] = ((const uint32_t *)&S.order[0])[t];                 // order[44]
+    if (t < (OG_MAXLEVEL + 3 + 3) / 4) ((uint32_t *)&P->task_start[0])[t] = ((const uint32_t *)&S.task_start[0])[t];   // task_start[26] + pad2_
     if (t < 12) {                                       // collapse[2][24], four bytes per work item (bands 21 .. 23: zero)
         const int b = t >= 6, i0 = 4 * (t - 6 * b);
         uint32_t w = 0;
@@ -323,19 +365,20 @@ OG_DEV void og_plan_emit(int t, OgBandPlan *P, const OgPlanShared &S)
         P->nlevels = S.maxlvl; P->merge_level = S.merge_level;
         P->pad_[0] = P->pad_[1] = 0;
         P->keep[0] = S.bits[0]; P->keep[1] = S.bits[1]; P->joint = S.bits[2]; P->plain[0] = S.bits[3]; P->plain[1] = S.bits[4];
-        P->pad2_[0] = P->pad2_[1] = P->pad2_[2] = 0;
+        P->pad2_[2] = 0;
     }
 }
 
-// the three steps for one frame, one after the other (CPU builds; the kernel spreads A and C over lanes)
-OG_DEV void og_band_plan(const OgCeltHdr *h, const OgCeltLeaf *lv, const OgCeltConst &K, const uint32_t *la, const uint32_t *lc,
-                         const uint32_t *cm_row, float *coef_row, OgBandPlan *P, OgPlanShared &S)
+// the three steps for one frame, one after the other (CPU builds; the kernel spreads A and C over lanes).  cm_row is consumed.
+OG_DEV void og_band_plan(const OgCeltHdr *hdr, const OgCeltLeaf *lv, const OgCeltConst &K, const uint32_t *la, const uint32_t *lc,
+                         uint32_t *cm_row, float *coef_row, OgBandPlan *P, OgPlanShared &S)
 {
-    for (int k = 0; k < 5; k++) S.bits[k] = 0;          // (the kernel clears these, S.col and S.blevel with all its lanes)
-    for (int i = 0; i < 21; i++) S.col[0][i] = S.col[1][i] = S.blevel[i] = 0;
-    for (int i = 0; i < 21; i++) og_plan_band_a(h, lv, K, cm_row, coef_row, i, S);
-    og_plan_chain(h, lv, K, la, lc, cm_row, P, S);
-    for (int t = 0; t < 42; t++) og_plan_emit(t, P, S);
+    const OgHdrHead h = *(const OgHdrHead *)hdr;
+    OgTask tk[21][2];
+    for (size_t k = 0; k < sizeof(OgPlanShared) / 4; k++) ((uint32_t *)&S)[k] = 0;      // (the kernel clears it with all its lanes)
+    for (int i = 0; i < 21; i++) og_plan_band_a(h, hdr->band, lv, K, cm_row, coef_row, i, S, tk[i]);
+    og_plan_chain(h, hdr->band, lv, K, la, lc, P, S);
+    for (int i = 0; i < 21; i++) og_plan_emit(h, hdr->band, i, tk[i], P, S);
 }
 
 // The same plan made start to end by ONE lane (the form large launches use: og_plan_lane_kernel, celt_launch.hip): the three
