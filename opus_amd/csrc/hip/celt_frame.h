@@ -65,10 +65,30 @@ OG_DEV float *og_part(OgCeltLds &L, int w) { return L.R + 1600 + 64 * w; }      
 // (<= 176-element) vector on its own (lane-strided partials + xor butterfly), so no LDS scratch and no barrier.
 #if defined(__HIP__)
 #define OG_BARRIER __syncthreads();
+// Sum over the wavefront, the same in every lane.  Six DPP additions (each one instruction: the lane exchange is an operand
+// modifier) and a lane read, where a __shfl_xor butterfly is six LDS-pipe round trips with their address arithmetic.  Inside a
+// row of 16 lanes: partners 1 and 2 away (quad_perm), then the mirrored half and the mirrored row -- which hold the same
+// values as the partners 4 and 8 away, since the lanes of a quad / half already agree -- then the row sums across the rows
+// (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3) and lane 63's total to everyone: the pairing of a
+// butterfly over partners 1, 2, 4, ... 32.
+template <int CTRL, int ROWS> OG_DEV float og_dpp_get(float v)       // the lane's DPP partner's v (0 in rows outside ROWS)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWS, 0xF, false));
+}
+OG_DEV float og_row16_sum(float v)                      // sum over the lane's row of 16, in every lane of the row
+{
+    v += og_dpp_get<0xB1, 0xF>(v);                      // quad_perm [1,0,3,2]
+    v += og_dpp_get<0x4E, 0xF>(v);                      // quad_perm [2,3,0,1]
+    v += og_dpp_get<0x141, 0xF>(v);                     // row_half_mirror
+    v += og_dpp_get<0x140, 0xF>(v);                     // row_mirror
+    return v;
+}
 OG_DEV float og_wave_sum(float v)
 {
-    for (int m = 32; m; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
+    v = og_row16_sum(v);
+    v += og_dpp_get<0x142, 0xA>(v);                     // row_bcast:15 -> rows 1, 3
+    v += og_dpp_get<0x143, 0xC>(v);                     // row_bcast:31 -> rows 2, 3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 OG_DEV float og_uniform_sumsq(const float *x, int n)
 {
@@ -88,9 +108,7 @@ OG_DEV float og_wave_tree_sum(const float *part) { return og_wave_sum(part[threa
 // sum over the 16-lane group of `lane` (every lane of the wave must call it)
 OG_DEV float og_group16_sum(const float *part, int lane)
 {
-    float v = part[lane];
-    for (int m = 8; m; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
+    return og_row16_sum(part[lane]);
 }
 #else
 #define OG_BARRIER
