@@ -32,18 +32,17 @@ struct alignas(16) OgF4 { float x, y, z, w; };
 #endif
 
 // 20.4 KB: eight workgroups per CU (LDS is allotted in 1280-byte granules: 16 of them).  Buffers with disjoint
-// lifetimes share storage: `R` holds the folding source `norm` + the waves' partial sums during the band walk and the
-// FFT pong buffer afterwards; the band-walk tables give way to the FFT twiddles.
+// lifetimes share storage: `R` holds the folding source `norm` during the band walk and the FFT pong buffer afterwards
+// (sums over a wavefront stay in registers: OG_WAVE_SUM); the band-walk tables give way to the FFT twiddles.
 struct alignas(16) OgCeltLds {
     float X[2][960];                  // coefficients (bands) -> MDCT bins -> FFT ping buffer -> samples before the window
-    float R[1920];                    // norm[2][800] | part[4][64]   ->   bin -> band map (denormalisation)   ->   FFT pong buffer [2][480] complex
+    float R[1920];                    // norm[2][800]   ->   bin -> band map (denormalisation)   ->   FFT pong buffer [2][480] complex
     union {
         struct {                      // band-walk lifetime
             alignas(16) uint32_t plan_head[OG_PLAN_HEAD_BYTES / 4];   // OgBandPlan up to (not including) .op
             OgFillOp ops[OG_LDS_OPS];
-            union {
+            struct {
                 float lb[OG_WG / 64][176];                        // per wave: transformed copy of its task's folding source
-                float mrg[OG_WG / 64][2][64];                     // per wave: stereo merge partial sums
             } s;
         } b;
         struct {                      // from denormalisation on
@@ -56,7 +55,6 @@ struct alignas(16) OgCeltLds {
 };
 // views into R (band-walk lifetime)
 OG_DEV float *og_norm(OgCeltLds &L, int row) { return L.R + 800 * row; }                // folding source row (celt/decoder.rs `norm_mid` / `norm_side`)
-OG_DEV float *og_part(OgCeltLds &L, int w) { return L.R + 1600 + 64 * w; }              // wave w's 64 partial sums
 
 #include "celt_pvq.h"
 
@@ -103,35 +101,8 @@ OG_DEV void og_uniform_dot2(const float *x, const float *y, int n, float *xy, fl
     *xy = og_wave_sum(a);
     *yy = og_wave_sum(b);
 }
-// sum of part[0..63] inside a single-wave section, same association order on the GPU and in the emulation
-OG_DEV float og_wave_tree_sum(const float *part) { return og_wave_sum(part[threadIdx.x & 63]); }
-// sum over the 16-lane group of `lane` (every lane of the wave must call it)
-OG_DEV float og_group16_sum(const float *part, int lane)
-{
-    return og_row16_sum(part[lane]);
-}
 #else
 #define OG_BARRIER
-OG_DEV float og_wave_tree_sum(const float *part)
-{
-    float v[64], w[64];
-    for (int i = 0; i < 64; i++) v[i] = part[i];
-    for (int m = 32; m; m >>= 1) {
-        for (int i = 0; i < 64; i++) w[i] = v[i] + v[i ^ m];
-        for (int i = 0; i < 64; i++) v[i] = w[i];
-    }
-    return v[0];
-}
-OG_DEV float og_group16_sum(const float *part, int lane)
-{
-    float v[16], w[16];
-    for (int i = 0; i < 16; i++) v[i] = part[(lane & ~15) + i];
-    for (int m = 8; m; m >>= 1) {
-        for (int i = 0; i < 16; i++) w[i] = v[i] + v[i ^ m];
-        for (int i = 0; i < 16; i++) v[i] = w[i];
-    }
-    return v[lane & 15];
-}
 OG_DEV float og_uniform_sumsq(const float *x, int n)
 {
     float e = 0.f;
@@ -349,7 +320,8 @@ OG_DEV void og_fill_op(OgBandCtx &c, int k, int w, int task_pos)     // task_pos
 {
     OgCeltLds &L = *c.L;
     const OgFillOp op = k < OG_LDS_OPS ? og_uniform(L.w.b.ops[k]) : og_uniform(c.plan->op[k]);
-    float *xl = &L.X[0][0] + op.pos, *part = og_part(L, w);
+    float *xl = &L.X[0][0] + op.pos;
+    OG_WAVE_VAR(float, ev);                             // the lane's share of the energy
     const float *lbl = L.w.b.s.lb[w] + ((int)op.pos - task_pos);
     const int nn = op.n;
     const uint32_t s0 = op.seed;
@@ -363,7 +335,7 @@ OG_DEV void og_fill_op(OgBandCtx &c, int k, int w, int task_pos)     // task_pos
             e += v * v;
             s = og_lcg_jump(64u, s);
         }
-        part[lane] = e;
+        OG_WV(ev) = e;
         OG_WAVE_END
     } else {                                            // fold the lower band in (celt/decoder.rs:1652-1659)
         OG_WAVE_BEGIN(lane)
@@ -375,10 +347,12 @@ OG_DEV void og_fill_op(OgBandCtx &c, int k, int w, int task_pos)     // task_pos
             e += v * v;
             s = og_lcg_jump(64u, s);
         }
-        part[lane] = e;
+        OG_WV(ev) = e;
         OG_WAVE_END
     }
-    const float g = op.gain * og_frsq(1e-15f + og_wave_tree_sum(part));
+    float esum;
+    OG_WAVE_SUM(esum, ev)
+    const float g = op.gain * og_frsq(1e-15f + esum);
     OG_WAVE_BEGIN(lane)
     for (int p = lane; p < nn; p += 64) xl[p] *= g;
     OG_WAVE_END
@@ -496,7 +470,7 @@ OG_DEV void og_celt_bands(OgBandCtx &c)
         jm &= end > start ? (((end >= 21 ? (1u << 21) : (1u << end)) - 1u) & ~((1u << start) - 1u)) : 0u;
         const uint32_t widem = lm == 3 ? 0x1E0000u : lm == 2 ? 0x180000u : 0u;      // M * width >= 64 (celt/decoder.rs:281-283)
         OG_WAVES_BEGIN(w)
-        float *pa = L.w.b.s.mrg[w][0], *pb = L.w.b.s.mrg[w][1];
+        OG_WAVE_VAR(float, av); OG_WAVE_VAR(float, bv);          // a lane's shares of <x, y> and <y, y>
         int turn = 0;                                   // whose turn the next piece of work is
         for (uint32_t m = jm & widem; m; m &= m - 1u, turn++) {
             if ((turn & (OG_WG / 64 - 1)) != w) continue;
@@ -515,9 +489,11 @@ OG_DEV void og_celt_bands(OgBandCtx &c)
                     a += xe * ye; b += ye * ye;
                 }
             }
-            pa[lane] = a; pb[lane] = b;
+            OG_WV(av) = a; OG_WV(bv) = b;
             OG_WAVE_END
-            const float xy = og_wave_tree_sum(pa), yy = og_wave_tree_sum(pb);
+            float xy, yy;
+            OG_WAVE_SUM(xy, av)
+            OG_WAVE_SUM(yy, bv)
             const float mid = (1.f / 32768) * bd.imid, inv = (bd.flags & OG_B_INV) ? -1.f : 1.f;
             const float xp = mid * xy, e = mid * mid + yy, e0 = e - 2.f * xp, e1 = e + 2.f * xp;
             float ax = 1.f, bx = 0.f, ay = inv, by = 0.f;              // degenerate: y = x
@@ -566,11 +542,14 @@ OG_DEV void og_celt_bands(OgBandCtx &c)
                 }
             }
             OG_WV(bdv) = bd; OG_WV(nv) = n; OG_WV(offv) = off;
-            pa[lane] = a; pb[lane] = b;
+            OG_WV(av) = a; OG_WV(bv) = b;
             OG_WAVE_END
+            OG_WAVE_VAR(float, xyv); OG_WAVE_VAR(float, yyv);
+            OG_ROW16_SUM(xyv, av)
+            OG_ROW16_SUM(yyv, bv)
             OG_WAVE_BEGIN(lane)
             const int l = lane & 15, n = OG_WV(nv);
-            const float xy = og_group16_sum(pa, lane), yy = og_group16_sum(pb, lane);
+            const float xy = OG_WV(xyv), yy = OG_WV(yyv);
             if (n) {
                 const OgCeltBand bd = OG_WV(bdv);
                 float *x = L.X[0] + OG_WV(offv), *y = L.X[1] + OG_WV(offv);
@@ -660,7 +639,8 @@ OG_DEV void og_anti_collapse(OgBandCtx &c)
         const int n0 = L.k.width[i], n = n0 << lm;
         const float r = A.r[t];
         const uint32_t sb = A.seed[t], dead = ~(uint32_t)collapse[ch][i] & ((1u << M) - 1u);
-        float *x = L.X[ch] + (L.k.ebands[i] << lm), *part = og_part(L, w);
+        float *x = L.X[ch] + (L.k.ebands[i] << lm);
+        OG_WAVE_VAR(float, ev);
         OG_WAVE_BEGIN(lane)
         float e = 0.f;
         for (int p = lane; p < n; p += 64) {                // element p = coefficient j of block k
@@ -674,9 +654,11 @@ OG_DEV void og_anti_collapse(OgBandCtx &c)
             }
             e += v * v;
         }
-        part[lane] = e;
+        OG_WV(ev) = e;
         OG_WAVE_END
-        const float g = og_frsq(1e-15f + og_wave_tree_sum(part));
+        float esum;
+        OG_WAVE_SUM(esum, ev)
+        const float g = og_frsq(1e-15f + esum);
         OG_WAVE_BEGIN(lane)
         for (int p = lane; p < n; p += 64) x[p] *= g;
         OG_WAVE_END

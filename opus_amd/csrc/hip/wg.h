@@ -88,6 +88,11 @@ template <int MASK> OG_DEV float og_lane_xor(float v)
 // inside the wave), as a uniform value; used between OG_LANES regions (no barrier needed: a wave reads its own copy)
 #define OG_LANE_GET0(var, L) ((uint32_t)__builtin_amdgcn_readlane((int)(var), (int)(L)))
 #define OG_WAVE_REF(T, name) T &name
+// Reductions of a float OG_WAVE_VAR, used between OG_WAVE regions: OG_WAVE_SUM(dst, var): dst (a plain float) = the sum over the
+// wavefront; OG_ROW16_SUM(dstvar, var): dstvar (an OG_WAVE_VAR) of a lane = the sum over the lane's row of 16.  Registers only
+// (og_wave_sum / og_row16_sum, celt_frame.h); partners 1, 2, 4, ... apart in both builds.
+#define OG_WAVE_SUM(dst, var) dst = og_wave_sum(var);
+#define OG_ROW16_SUM(dstvar, var) dstvar = og_row16_sum(var);
 // One-instruction approximations (1 ulp) for the CELT kernels, whose results are compared with a tolerance (the library
 // forms expand to a dozen or more instructions each: range checks, Newton steps, denormal scaling).  Arguments are normal
 // numbers wherever these are used.  The SILK kernels, which are held to bit-exactness, do not use them.
@@ -165,6 +170,10 @@ OG_DEV OgC2 og_c2_fma(OgC2 a, float s, OgC2 b) { return __builtin_elementwise_fm
 #define OG_WAVE_GET(src, L) ((int)src[L])
 #define OG_LANE_GET0(var, L) ((uint32_t)var[L])
 #define OG_WAVE_REF(T, name) T (&name)[64]
+#define OG_LANE_TREE_(var, TOP) float v_[64], w_[64]; for (int i_ = 0; i_ < 64; i_++) v_[i_] = var[i_]; \
+    for (int m_ = 1; m_ < (TOP); m_ <<= 1) { for (int i_ = 0; i_ < 64; i_++) w_[i_] = v_[i_] + v_[i_ ^ m_]; for (int i_ = 0; i_ < 64; i_++) v_[i_] = w_[i_]; }
+#define OG_WAVE_SUM(dst, var) { OG_LANE_TREE_(var, 64) dst = v_[0]; }
+#define OG_ROW16_SUM(dstvar, var) { OG_LANE_TREE_(var, 16) for (int i_ = 0; i_ < 64; i_++) dstvar[i_] = v_[i_]; }
 OG_DEV float og_frsq(float x) { return 1.f / sqrtf(x); }
 OG_DEV float og_frcp(float x) { return 1.f / x; }
 OG_DEV float og_fsqrt(float x) { return sqrtf(x); }
