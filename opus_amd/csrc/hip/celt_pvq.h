@@ -7,6 +7,7 @@
 #include "../../../include/opusgpu.h"
 
 struct alignas(16) OgF4s { float x, y, z, w; };
+struct alignas(8) OgF2s { float x, y; };
 OG_DEV uint32_t og_lcg(uint32_t s) { return 1664525u * s + 1013904223u; }   // celt/decoder.rs:1595-1599
 
 // ------------------------------------------------------------------------------------------------
@@ -216,19 +217,28 @@ OG_DEV void og_pvq_lane(const OgLeafRef ref, const OgCeltLeaf lf, void *work,
 {
     const uint32_t frame = ref.frame & OG_REF_FRAME_MASK;
     const int ch = (lf.meta & OG_L_CH_Y) ? 1 : 0;
-    if (lf.k == 0) {                                    // a zero-pulse leaf next to PVQ leaves in its (band, buffer): K1 owns the
-        float *z = og_work_coef(work, frame) + ch * 960 + lf.pos;          // zeros there (live fill leaves are rewritten by the
-        for (int i = 0; i < lf.n; i++) z[i] = 0.f;                         // frame kernel); no collapse mask
-        return;
+    const bool zeros = lf.k == 0;                       // a zero-pulse leaf next to PVQ leaves in its (band, buffer): K1 owns the
+                                                        // zeros there (live fill leaves are rewritten by the frame kernel); no collapse mask
+    uint32_t cm = 0;
+    if (!zeros) {
+        const int spread = (int)(ref.frame >> OG_REF_SPREAD_SHIFT);
+        int16_t *dbg = dbg_pulses ? dbg_pulses + (size_t)frame * 1920 + ch * 960 + lf.pos : nullptr;
+        cm = og_pvq_leaf(U2, lf, spread, xl, xs, dbg, stamps);
     }
-    const int spread = (int)(ref.frame >> OG_REF_SPREAD_SHIFT);
-    int16_t *dbg = dbg_pulses ? dbg_pulses + (size_t)frame * 1920 + ch * 960 + lf.pos : nullptr;
-    const uint32_t cm = og_pvq_leaf(U2, lf, spread, xl, xs, dbg, stamps);
+    // the leaf's n values out, in the widest pieces its place in the row allows: one value to an even place, two to a
+    // multiple of four, then fours, then the rest (a wavefront's leaves lie in 64 different rows: a store instruction costs
+    // the memory pipeline the same whether a lane writes 4 or 16 bytes)
     float *dst = og_work_coef(work, frame) + ch * 960 + lf.pos;
+    const int n = lf.n;
     int i = 0;
-    if ((lf.pos & 3) == 0)                              // 16-byte stores where the leaf's place in the row allows them
-        for (; i + 4 <= lf.n; i += 4) *(OgF4s *)(dst + i) = OgF4s{xl[i * xs], xl[(i + 1) * xs], xl[(i + 2) * xs], xl[(i + 3) * xs]};
-    for (; i < lf.n; i++) dst[i] = xl[i * xs];
+#define OG_XV(j) (zeros ? 0.f : xl[(j) * xs])
+    if ((lf.pos & 1) && i < n) { dst[i] = OG_XV(i); i++; }
+    if (((lf.pos + i) & 2) && i + 2 <= n) { *(OgF2s *)(dst + i) = OgF2s{OG_XV(i), OG_XV(i + 1)}; i += 2; }
+    for (; i + 4 <= n; i += 4) *(OgF4s *)(dst + i) = OgF4s{OG_XV(i), OG_XV(i + 1), OG_XV(i + 2), OG_XV(i + 3)};
+    if (i + 2 <= n) { *(OgF2s *)(dst + i) = OgF2s{OG_XV(i), OG_XV(i + 1)}; i += 2; }
+    if (i < n) dst[i] = OG_XV(i);
+#undef OG_XV
+    if (zeros) return;
     OG_ATOMIC_OR(og_work_cm(work, frame) + ch * 24 + lf.band, cm);
     OG_PVQ_STAMP(3)
 }
