@@ -244,7 +244,7 @@ def main_c3(a, rank, local_rank, world):
         dist.barrier()
     elapsed = sharding.max_over_ranks(time.perf_counter() - t0)
     launch_s = ev0.elapsed_time(ev1) / K / 1e3          # both kernels of a launch, on the stream they run on
-    assert bool(torch.isfinite(pcm).all())
+    assert a.no_verify or bool(torch.isfinite(pcm).all())      # (profiling runs that stop kernels early or skip leaf classes: --no-verify)
     verify = None
     if not a.no_verify:                                 # the last step's PCM of a few streams against the CPU oracle (bit-exact)
         sys.path.insert(0, os.path.join(ROOT, "tests"))

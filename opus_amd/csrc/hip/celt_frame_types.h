@@ -28,7 +28,7 @@ struct OgCeltTables {                 // constant tables, built once per device 
     uint32_t lcg_a[184], lcg_c[184];  // seed after j LCG steps = lcg_a[j] * seed + lcg_c[j]
     uint32_t pvq_u[1272];             // U(N,K) rows (celt/decoder.rs:293-409)
     uint16_t pvq_row[16];             // row offsets (celt/decoder.rs:410-413)
-    uint32_t pvq_u2[15 * 177];        // the same table unpacked: U(lo, hi) at [lo * 177 + hi] (no dependent row look-up)
+    alignas(16) uint32_t pvq_u2[15 * 177 + 1];   // the same table unpacked: U(lo, hi) at [lo * 177 + hi] (no dependent row look-up); 16-byte pieces
     uint8_t bin2band[4][960];         // per LM: band of MDCT bin j (255 above band 20)
     float bin2sq[4][960];             // per LM: sqrt(width of bin j's band) -- lowband_out = sqrt(N0) x, celt/decoder.rs:2021-2028 (0 above band 20)
     OgCeltConst k;

@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
 {
     int16_t *const dbg_pulses = DBG ? dbg_pulses_ : nullptr;
     uint64_t *const dbg_cycles = DBG ? dbg_cycles_ : nullptr;
-    __shared__ uint32_t U2[15 * OG_U2_STRIDE];
+    __shared__ __attribute__((aligned(16))) uint32_t U2[15 * OG_U2_STRIDE + 1];      // staged in 16-byte pieces
     __shared__ float x[3072];                           // 176 * 16 = 2816, 64 * 32 = 2048, 24 * 128 = 3072, 8 * 256 = 2048
     // Workgroup order: the two large classes keep one 16 / 32-lane wavefront busy for ~100 us each while holding a full
     // workgroup's LDS, so they are dealt one in three among the small-class workgroups from the start of the grid (every CU
@@ -53,7 +53,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
     OgCeltLeaf lf = {};
     if (live && g < cnt) { ref = refs[base + g]; lf = leaves[ref.leaf]; }
     const uint32_t nw = (lanes + 63u) >> 6;             // wavefronts that stay: they share the table
-    for (uint32_t p = tid; p < 15 * OG_U2_STRIDE; p += 64 * nw) U2[p] = T->pvq_u2[p];
+    {
+        static_assert((15 * OG_U2_STRIDE + 1) % 4 == 0 && offsetof(OgCeltTables, pvq_u2) % 16 == 0, "the table as 16-byte pieces");
+        const uint4 *src = (const uint4 *)T->pvq_u2;
+        for (uint32_t p = tid; p < (15 * OG_U2_STRIDE + 1) / 4; p += 64 * nw) ((uint4 *)U2)[p] = src[p];
+    }
     __syncthreads();                                    // wavefronts that have ended no longer take part in the barrier
     if (!live) return;
     const int nmax = c == 0 ? 176 : c == 1 ? 64 : c == 2 ? 24 : 8;

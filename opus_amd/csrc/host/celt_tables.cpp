@@ -43,6 +43,7 @@ void og_fill_celt_tables(OgCeltTables *t)
             const int idx = CELT_PVQ_U_ROW[lo] + hi, end = lo < 14 ? CELT_PVQ_U_ROW[lo + 1] + lo + 1 : 1272;
             t->pvq_u2[lo * 177 + hi] = (hi >= lo && idx < end) ? CELT_PVQ_U[idx] : 0xFFFFFFFFu;
         }
+    t->pvq_u2[15 * 177] = 0;                             // (padding: the kernel stages the table in 16-byte pieces)
     for (int lm = 0; lm < 4; lm++)
         for (int j = 0; j < 960; j++) {
             int b = 255;
