@@ -533,7 +533,7 @@ def main():
             # moves by design (side-info + energies 1724, K1 row in 7680, sample row out 7680)
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "kernel": "one opusgpu_launch_celt call: og_pvq_all_kernel + og_plan_lane_kernel (og_plan_kernel up to 16 384 frames) + og_celt_kernel + og_celt_tail_kernel",
+                         "kernel": "one opusgpu_launch_celt call: og_pvq_all_kernel + og_plan_kernel + og_celt_kernel + og_celt_tail_kernel",
                          "avg_launch_us": round(avg_kernel_s * 1e6, 2),
                          "algorithmic_bytes_per_launch": int(avg_alg),
                          "dominant": {"kernel": "og_celt_kernel", "avg_launch_us": round(k2_s * 1e6, 2), "bytes_per_launch": int(k2_bytes),
