@@ -38,34 +38,34 @@ OG_DEV uint32_t og_cwrsi(const uint32_t *U2, int n, int k, uint32_t i, float *x,
     {                                                                                                               \
         x[pos * xs] = (float)(v);                                                                                   \
         if (dbg) dbg[pos] = (int16_t)(v);                                                                           \
-        yy += (uint32_t)((v) * (v));                                                                                \
+        yy += (uint32_t)OG_MUL24((v), (v));                                 /* |v| <= 176 */                        \
         if (v) cm |= 1 << bi;                                                                                       \
         pos++;                                                                                                      \
         if (--bl == 0) { bl = nb; bi++; }                                                                           \
     }
     while (n > 2 && k > 0) {
+        // straight-line: both phases' outcomes are computed and selected, so that the wavefront's lanes -- each in its own
+        // phase -- run one instruction stream instead of three masked ones (the branches cost more than the arithmetic)
         const int kb = phase ? (kk > 0 ? kk - 1 : 0) : kk + 1;
         const uint32_t pA = og_u2(U2, n, kk), pB = og_u2(U2, n, kb);
-        bool emit = false;
-        int val = 0;
-        if (!phase) {
-            s = -(int)(i >= pB);
-            i -= pB & (uint32_t)s;
-            k0 = k;
-            if (!s && pA <= i) { i -= pA; emit = true; }                     // this coefficient is zero
-            else { kk = k - 1; phase = 1; }                                     // pA > i here: at least one pulse
-        } else {
-            const bool atA = pA <= i, atB = pB <= i;
-            if (atA || atB) {
-                const int found = atA ? kk : kk - 1;
-                i -= atA ? pA : pB;
-                val = (k0 - found + s) ^ s;
-                k = found; kk = found; phase = 0;
-                emit = true;
-            } else {
-                kk -= 2;
-            }
-        }
+        // phase 0 (new coefficient)
+        const int s0 = -(int)(i >= pB);
+        const uint32_t i0 = i - (pB & (uint32_t)s0);
+        const bool zero0 = !s0 && pA <= i0;                                     // this coefficient is zero
+        // phase 1 (search)
+        const bool atA = pA <= i, atB = pB <= i, hit1 = atA || atB;
+        const int found1 = atA ? kk : kk - 1;
+        const uint32_t i1 = i - (atA ? pA : pB);
+        // the step taken
+        const bool p1 = phase != 0;
+        const bool emit = p1 ? hit1 : zero0;
+        s = p1 ? s : s0;
+        k0 = p1 ? k0 : k;
+        const int val = (p1 && hit1) ? ((k0 - found1 + s) ^ s) : 0;
+        i = p1 ? (hit1 ? i1 : i) : (zero0 ? i0 - pA : i0);
+        k = (p1 && hit1) ? found1 : k;
+        kk = p1 ? (hit1 ? found1 : kk - 2) : (zero0 ? kk : k - 1);             // (phase 0 with pA > i: at least one pulse)
+        phase = p1 ? (hit1 ? 0 : 1) : (zero0 ? 0 : 1);
         if (emit) { OG_PUT(val) n--; }
     }
     for (; n > 2; n--) OG_PUT(0)                                               // every pulse placed: the rest is zeros
