@@ -14,7 +14,8 @@
 // conflict-free).  refs are sorted by decreasing size, so a class is a contiguous range, cut into batches of `lanes` leaves.
 // OG_K1_BATCHES(c) consecutive batches per workgroup of class c: 1 everywhere.  (Measured, r2n: four batches per workgroup
 // for N <= 8 and two for N <= 24 -- table staged once, next batch's records prefetched -- made the kernel 25 % slower, 250 us
-// against 201: fewer, longer workgroups balance worse over the CUs than the table staging costs.)
+// against 201: fewer, longer workgroups balance worse over the CUs than the table staging costs.  Measured again at the
+// end of round 2, two batches for the two small classes: 177 us against 160.)
 struct OgPvqClasses { uint32_t cnt[4], wg0[4]; };      // leaves per class (largest first); first workgroup of each class
 #define OG_K1_BATCHES(c) 1u
 // Register budget: five wavefronts per SIMD (96 VGPRs, which the plain instantiation meets without spilling; measured, round 2:
