@@ -222,14 +222,21 @@ OG_DEV OgXfAddr og_xf_addr(const OgTask tk, int first, int STEP)
 // the butterflies of the lanes' tasks on registers: hmv = the lane's task's hm (0 for lanes without one), hm_any = the OR of
 // hmv over the wave (uniform), nmax = a uniform bound on the tasks' n.  Lanes past their task's n hold zeros: their partners
 // are past it too (n is a multiple of every butterfly's span).
+// A butterfly as one multiply and one fused multiply-add per element: v' = ca v + cb v_partner with, per lane and index bit,
+// (ca, cb) = (1, 1) in the lower lane of a pair, (-1, 1) in the upper one, (1, 0) where the lane's task has no butterfly on
+// that bit -- products with 0 and +-1 are exact, so this is the sum / difference itself, without a select per element.
 #define OG_XF_BFLY_BIT(B)                                                                                           \
     if (hm_any & (1 << (B))) {                                                                                      \
+        OG_WAVE_REGS_BEGIN(lane)                                                                                    \
+        const bool on_ = ((OG_WV(hmv) >> (B)) & 1) != 0;                                                            \
+        OG_WV(ca) = (on_ && ((lane >> (B)) & 1)) ? -1.f : 1.f;                                                      \
+        OG_WV(cb) = on_ ? 1.f : 0.f;                                                                                \
+        OG_WAVE_REGS_END                                                                                            \
         _Pragma("unroll") for (int k = 0; k < K; k++) {                                                             \
             if (k * STEP < nmax) {                                                                                  \
                 OG_WAVE_XCH(ex, rv, .v[k], 1 << (B))                                                                \
                 OG_WAVE_REGS_BEGIN(lane)                                                                            \
-                if ((OG_WV(hmv) >> (B)) & 1)              /* lane bit clear: a + c; set: a - c, a = the lower lane's */ \
-                    OG_WV(rv).v[k] = ((lane >> (B)) & 1) ? OG_WV(ex) - OG_WV(rv).v[k] : OG_WV(rv).v[k] + OG_WV(ex);  \
+                OG_WV(rv).v[k] = fmaf(OG_WV(rv).v[k], OG_WV(ca), OG_WV(cb) * OG_WV(ex));                            \
                 OG_WAVE_REGS_END                                                                                    \
             }                                                                                                       \
         }                                                                                                           \
@@ -238,6 +245,8 @@ template <int K, int STEP>
 OG_DEV void og_wave_bflies(OG_WAVE_REF(OgXr<K>, rv), OG_WAVE_REF(int, hmv), int hm_any, int nmax)
 {
     OG_WAVE_VAR(float, ex);
+    OG_WAVE_VAR(float, ca);
+    OG_WAVE_VAR(float, cb);
     OG_XF_BFLY_BIT(0)
     OG_XF_BFLY_BIT(1)
     OG_XF_BFLY_BIT(2)
