@@ -331,39 +331,34 @@ OG_DEV void og_fill_op(OgBandCtx &c, int k, int w, int task_pos)     // task_pos
     const OgFillOp op = k < OG_LDS_OPS ? og_uniform(L.w.b.ops[k]) : og_uniform(c.plan->op[k]);
     float *xl = &L.X[0][0] + op.pos;
     OG_WAVE_VAR(float, ev);                             // the lane's share of the energy
+    OG_WAVE_VAR(OgXr<3>, vv);                           // its coefficients (n <= 176: at most three), kept until they are scaled
     const float *lbl = L.w.b.s.lb[w] + ((int)op.pos - task_pos);
     const int nn = op.n;
     const uint32_t s0 = op.seed;
-    if (!(op.flags & OG_OP_FOLD)) {                     // noise (celt/decoder.rs:1644-1651)
-        OG_WAVE_BEGIN(lane)
-        float e = 0.f;
-        uint32_t s = og_lcg_jump<7>((uint32_t)lane + 1u, s0);   // lane + 1 <= 64
-        for (int p = lane; p < nn; p += 64) {
-            const float v = (float)((int32_t)s >> 20);
-            xl[p] = v;
-            e += v * v;
-            s = og_lcg_jump(64u, s);
-        }
-        OG_WV(ev) = e;
-        OG_WAVE_END
-    } else {                                            // fold the lower band in (celt/decoder.rs:1652-1659)
-        OG_WAVE_BEGIN(lane)
-        float e = 0.f;
-        uint32_t s = og_lcg_jump<7>((uint32_t)lane + 1u, s0);   // lane + 1 <= 64
-        for (int p = lane; p < nn; p += 64) {
-            const float v = lbl[p] + ((s & 0x8000) ? 1.f / 256 : -1.f / 256);
-            xl[p] = v;
-            e += v * v;
-            s = og_lcg_jump(64u, s);
-        }
-        OG_WV(ev) = e;
-        OG_WAVE_END
+    const bool fold = (op.flags & OG_OP_FOLD) != 0;     // fold the lower band in (celt/decoder.rs:1652-1659), else noise (:1644-1651)
+    OG_WAVE_BEGIN(lane)
+    float e = 0.f;
+    uint32_t s = og_lcg_jump<7>((uint32_t)lane + 1u, s0);       // lane + 1 <= 64
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const int p = lane + 64 * j;
+        float v = 0.f;
+        if (64 * j < nn && p < nn) v = fold ? lbl[p] + ((s & 0x8000) ? 1.f / 256 : -1.f / 256) : (float)((int32_t)s >> 20);
+        OG_WV(vv).v[j] = v;
+        e += v * v;
+        s = og_lcg_jump(64u, s);
     }
+    OG_WV(ev) = e;
+    OG_WAVE_END
     float esum;
     OG_WAVE_SUM(esum, ev)
     const float g = op.gain * og_frsq(1e-15f + esum);
     OG_WAVE_BEGIN(lane)
-    for (int p = lane; p < nn; p += 64) xl[p] *= g;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const int p = lane + 64 * j;
+        if (64 * j < nn && p < nn) xl[p] = OG_WV(vv).v[j] * g;
+    }
     OG_WAVE_END
 }
 
