@@ -1375,9 +1375,14 @@ OG_DEV void og_celt_tail_run(const OgCeltHdr *hg, uint32_t nfr, OgCeltState *sta
             OG_WAVE_BEGIN(lane)
             const int l = lane;
             if (l < nl) {
-                const int q0 = l > back ? l - back : 0;
-                float m = q0 > 0 ? 0.f : L.dm[ch];      // the stream's de-emphasis memory (0 after a reset)
-                for (int q = q0; q < l; q++) m = m * aL + L.carry[ch][q];
+                const int cnt = l > back ? back : l;    // earlier chunks that count: l - cnt .. l - 1
+                float m = l > back ? 0.f : L.dm[ch];    // the stream's de-emphasis memory (0 after a reset)
+                float cq[back];                         // their carries, fetched together (the Horner steps below then wait for none)
+#pragma unroll
+                for (int j = 0; j < back; j++) cq[j] = L.carry[ch][l - 1 - j >= 0 ? l - 1 - j : 0];
+#pragma unroll
+                for (int j = back - 1; j >= 0; j--)
+                    if (j < cnt) m = m * aL + cq[j];    // oldest first
                 float *z = z0 + l * Lc;
 #pragma unroll
                 for (int j = 0; j < 15; j++) { const float v = OG_WV(yv).v[j] + m; m = coef * v; z[j] = v; }
