@@ -314,14 +314,18 @@ static int batch_send_impl(opusgpu_batch *b, const uint8_t *const *pkts, const u
     uint32_t rounds = 0;
     const size_t np = size_t(n) * T;
     for (size_t i = 0; i < np; i++) if (parsed[i].rc > 0) rounds = std::max(rounds, RPF * (parsed[i].frame0 + uint32_t(parsed[i].rc)));
-    // Fast path of a multi-packet send: every stream brought T packets of one CELT-only frame each (no SILK, no redundant
-    // frames).  The records are then laid out [stream][t] and the whole send is ONE launch in which a tail workgroup walks a
-    // stream's T frames in time order (frames_per_group = T), instead of T rounds of launches.
-    bool grouped = T > 1 && n > 0;
+    // Fast path: every packet of the send holds the same number F of frames, all CELT-only (no SILK, no redundant frames), and
+    // T F > 1 -- several packets per stream and / or code 1-3 packets.  The records are then laid out [stream][t][f] and the
+    // whole send is ONE launch in which a tail workgroup walks a stream's T F frames in time order (frames_per_group = T F),
+    // instead of a round of launches per frame.
+    const uint32_t F = np && parsed[0].rc > 0 ? uint32_t(parsed[0].rc) : 0;
+    bool grouped = n > 0 && F > 0 && size_t(T) * F > 1;
     for (size_t i = 0; i < np && grouped; i++) {
         const ParsedPacket &pp = parsed[i];
-        grouped = pp.rc == 1 && pp.fi[0].nsilk == 0 && pp.fi[0].has_celt == 1 &&
-                  (workers[pp.worker].celt[pp.fi[0].celt_index].spread >> OG_X_SHIFT) == (OG_ROUND_MAIN << (OG_ROUND_SHIFT - OG_X_SHIFT));
+        grouped = pp.rc == int(F);
+        for (int f = 0; f < pp.rc && grouped; f++)
+            grouped = pp.fi[f].nsilk == 0 && pp.fi[f].has_celt == 1 &&
+                      (workers[pp.worker].celt[pp.fi[f].celt_index].spread >> OG_X_SHIFT) == (OG_ROUND_MAIN << (OG_ROUND_SHIFT - OG_X_SHIFT));
     }
     if (grouped) rounds = 1;
     std::vector<uint32_t> ccount(rounds + 1, 0), scount(rounds + 1, 0);
@@ -387,7 +391,7 @@ static int batch_send_impl(opusgpu_batch *b, const uint8_t *const *pkts, const u
         b->ref_round_off[r + 1] = nref;
     }
     b->h_refs.n = nref;
-    b->grouped_T = grouped ? T : 0;
+    b->grouped_T = grouped ? T * F : 0;
     b->pending = true;
     return OPUSGPU_OK;
 }
