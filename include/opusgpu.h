@@ -125,9 +125,10 @@ int opusgpu_batch_send(opusgpu_batch *, const uint8_t *const *pkts, const uint32
 /* The same for `packets_per_stream` consecutive packets of each of `nstreams` streams in one call (packet t of the i-th stream
  * of the call is pkts[i * packets_per_stream + t], errors likewise): the stream's PCM row then holds their output back to
  * back (the rows grow to packets_per_stream x OPUSGPU_MAX_FRAME samples on first use; batch_pcm's pointer and stride change
- * with that).  When every packet is one CELT-only frame -- no SILK part, no redundant frame -- batch_decode issues the whole
+ * with that).  When every packet of a send (this call or opusgpu_batch_send) holds the same number of frames, all of them
+ * CELT-only -- no SILK part, no redundant frame -- and there is more than one frame per stream, batch_decode issues the whole
  * send as ONE launch in which each stream's frames are walked in time order by one workgroup (the layer-3b
- * frames_per_group), instead of one round of launches per packet.  No counterpart in the reference (one packet per call). */
+ * frames_per_group), instead of one round of launches per frame.  No counterpart in the reference (one packet per call). */
 int opusgpu_batch_send_multi(opusgpu_batch *, const uint8_t *const *pkts, const uint32_t *lens, const uint32_t *stream_ids,
                              uint32_t nstreams, uint32_t packets_per_stream, int32_t *errors);
 /* Device half: H2D of the side-info, then the kernels, on the batch's HIP stream.  Asynchronous: the next batch_send
