@@ -323,3 +323,46 @@ def test_multi_packet_send(kind):
             assert got.shape == want.shape, (s, k)
             check_pcm(want, got, f"{kind} stream {s} send {k}")
             check_pcm(np.concatenate(outs[s]), got, f"{kind} stream {s} send {k}: multi against one packet per call")
+
+
+def test_multi_frame_packets_in_one_launch():
+    """code 1-3 CELT packets (vectors 01 and 11 hold up to six frames per packet): streams in lockstep bring packets of the same
+    frame count, which the batch engine issues as ONE launch with frames_per_group = frames per packet (x packets per stream
+    with send_multi); streams out of step fall back to a round of launches per frame.  Both against the oracle."""
+    ns = 6
+    for vid in (1, 11):
+        _, pk = orc.load_vectors(ids=[vid], max_packets=260)[vid]
+        pk = [bytes(p) for p in pk]
+        step = BatchDecoder(ns, 2, 0)                   # every stream at the same packet: grouped
+        skew = BatchDecoder(ns, 2, 0)                   # stream s runs s packets ahead: mixed frame counts
+        refs = [orc.Decoder(2) for _ in range(ns)]
+        refk = [orc.Decoder(2) for _ in range(ns)]
+        for i in range(200):
+            assert not any(step.send([pk[i]] * ns))
+            step.decode()
+            want = refs[0].decode(pk[i])
+            for s in range(ns):
+                if s:
+                    refs[s].decode(pk[i])
+                got = step.read(s)
+                assert got.shape == want.shape, (vid, i, s)
+                check_pcm(want, got, f"vector {vid} packet {i} stream {s} (lockstep)")
+            assert not any(skew.send([pk[i + s] for s in range(ns)]))
+            skew.decode()
+            for s in range(ns):
+                w = refk[s].decode(pk[i + s])
+                g = skew.read(s)
+                assert g.shape == w.shape, (vid, i, s)
+                check_pcm(w, g, f"vector {vid} packet {i + s} stream {s} (out of step)")
+        # two packets per stream per call on top of several frames per packet
+        multi = BatchDecoder(2, 2, 0)
+        refm = [orc.Decoder(2), orc.Decoder(2)]
+        for i in range(0, 120, 2):
+            errs = multi.send_multi([[pk[i], pk[i + 1]], [pk[i], pk[i + 1]]])
+            assert not any(any(e) for e in errs)
+            multi.decode()
+            for s in range(2):
+                w = np.concatenate([refm[s].decode(pk[i]), refm[s].decode(pk[i + 1])])
+                g = multi.read(s)
+                assert g.shape == w.shape, (vid, i, s)
+                check_pcm(w, g, f"vector {vid} packets {i}, {i + 1} stream {s} (send_multi)")
