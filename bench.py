@@ -500,7 +500,7 @@ def main():
         del halves
 
     # ---- and with consecutive steps pipelined over two HIP streams (the three-part launch API exists for this): K1 + plan of
-    #      step n + 1 run beside the frame and tail kernels of step n, on scratch of their own (two scratch blocks, alternating)
+    #      step n + 1 run beside the tail kernel of step n, on scratch of their own (two scratch blocks, alternating)
     pl = None
     if world == 1 and a.pipeline_leg and P == 1:
         pt = parts[0]
@@ -547,8 +547,8 @@ def main():
             okp = float(f"{worstp:.3e}")
         pl = {"value": round(S * K * T * FRAME_S / ep, 1), "unit": "audio-s/s", "steps": K, "warmup": W, "ms_per_step": round(ep / K * 1e3, 4),
               "verified_max_scaled_err": okp,
-              "note": "same workload, consecutive steps pipelined over two HIP streams: K1 + plan of step n + 1 beside the frame and "
-                      "tail kernels of step n (two scratch blocks); the first K1 + plan of the timed steps ran before the clock started"}
+              "note": "same workload, consecutive steps pipelined over two HIP streams: K1 + plan of step n + 1 beside the tail kernel of "
+                      "step n (two scratch blocks); the first K1 + plan of the timed steps ran before the clock started"}
 
     avg_kernel_s = elapsed / K                               # the calls run back to back on one stream: per call = step time
     avg_alg = sum(alg_bytes[W:]) / K
