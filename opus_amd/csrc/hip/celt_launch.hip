@@ -18,10 +18,11 @@
 // end of round 2, two batches for the two small classes: 177 us against 160.)
 struct OgPvqClasses { uint32_t cnt[4], wg0[4]; };      // leaves per class (largest first); first workgroup of each class
 #define OG_K1_BATCHES(c) 1u
-// Register budget: five wavefronts per SIMD (96 VGPRs, which the plain instantiation meets without spilling; measured, round 2:
-// 203 us at the compiler's own choice of 110 VGPRs = four per SIMD, 189 us at five, 202 us at six = 80 VGPRs with 29 spills).
+// Register budget: six wavefronts per SIMD (80 VGPRs, which the kernel meets without spilling now that the rotation works in
+// blocks of four coefficients; measured, round 2: 203 us at the compiler's own choice of 110 VGPRs = four per SIMD, 189 us at
+// five, 202 us at six while that took 29 spills; with blocks of four: 157 us at six, 160 us at seven = 72 VGPRs with 4 spills).
 template <bool DBG>                   // DBG: stage dumps / profiling stamps wanted (the plain instantiation carries none of that code)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void og_pvq_all_kernel(const OgLeafRef *__restrict__ refs, OgPvqClasses cl,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void og_pvq_all_kernel(const OgLeafRef *__restrict__ refs, OgPvqClasses cl,
                                                          const OgCeltLeaf *__restrict__ leaves,
                                                          uint32_t nframes, const OgCeltTables *__restrict__ T, void *work,
                                                          int16_t *dbg_pulses_, uint64_t *dbg_cycles_)

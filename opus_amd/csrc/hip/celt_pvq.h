@@ -90,21 +90,21 @@ OG_DEV uint32_t og_cwrsi(const uint32_t *U2, int n, int k, uint32_t i, float *x,
 // RFC 6716 vq.c exp_rotation1 (celt/decoder.rs:676-692).  The reference loops walk x[i], x[i+stride] in place; the
 // `stride` residue classes are independent first-order recurrences, so each runs with its carry in a register
 // (same order within a class; each step's two outputs are one multiply and one fused multiply-add, so the carried value
-// sees one operation per step).  Eight steps are loaded, rotated and stored at a time so that the LDS latency is paid per
-// block, not per coefficient.
+// sees one operation per step).  Four steps are loaded, rotated and stored at a time so that the LDS latency is paid per
+// block, not per coefficient (eight at a time cost the kernel a wavefront per SIMD in registers: celt_launch.hip).
 OG_DEV void og_rot_fwd(float *x, int xs, int i, int stride, int cnt, float c, float s)      // steps at i, i+stride, ...
 {
     float t = x[i * xs];
-    while (cnt >= 8) {
-        float v[8];
+    while (cnt >= 4) {
+        float v[4];
 #pragma unroll
-        for (int j = 0; j < 8; j++) v[j] = x[(i + (j + 1) * stride) * xs];
+        for (int j = 0; j < 4; j++) v[j] = x[(i + (j + 1) * stride) * xs];
 #pragma unroll
-        for (int j = 0; j < 8; j++) { const float x2 = v[j]; v[j] = fmaf(c, t, -(s * x2)); t = fmaf(s, t, c * x2); }
+        for (int j = 0; j < 4; j++) { const float x2 = v[j]; v[j] = fmaf(c, t, -(s * x2)); t = fmaf(s, t, c * x2); }
 #pragma unroll
-        for (int j = 0; j < 8; j++) x[(i + j * stride) * xs] = v[j];
-        i += 8 * stride;
-        cnt -= 8;
+        for (int j = 0; j < 4; j++) x[(i + j * stride) * xs] = v[j];
+        i += 4 * stride;
+        cnt -= 4;
     }
     for (; cnt > 0; cnt--, i += stride) {
         const float x2 = x[(i + stride) * xs];
@@ -117,16 +117,16 @@ OG_DEV void og_rot_fwd(float *x, int xs, int i, int stride, int cnt, float c, fl
 OG_DEV void og_rot_bwd(float *x, int xs, int i, int stride, int cnt, float c, float s)      // steps at i, i-stride, ...
 {
     float u = x[(i + stride) * xs];
-    while (cnt >= 8) {
-        float v[8];
+    while (cnt >= 4) {
+        float v[4];
 #pragma unroll
-        for (int j = 0; j < 8; j++) v[j] = x[(i - j * stride) * xs];
+        for (int j = 0; j < 4; j++) v[j] = x[(i - j * stride) * xs];
 #pragma unroll
-        for (int j = 0; j < 8; j++) { const float x1 = v[j]; v[j] = fmaf(c, u, s * x1); u = fmaf(-s, u, c * x1); }
+        for (int j = 0; j < 4; j++) { const float x1 = v[j]; v[j] = fmaf(c, u, s * x1); u = fmaf(-s, u, c * x1); }
 #pragma unroll
-        for (int j = 0; j < 8; j++) x[(i - j * stride + stride) * xs] = v[j];
-        i -= 8 * stride;
-        cnt -= 8;
+        for (int j = 0; j < 4; j++) x[(i - j * stride + stride) * xs] = v[j];
+        i -= 4 * stride;
+        cnt -= 4;
     }
     for (; cnt > 0; cnt--, i -= stride) {
         const float x1 = x[i * xs];
