@@ -42,15 +42,40 @@ int bx_log2tan(int isin, int icos)                                              
     isin <<= 15 - ls;
     return (ls - lc) * 2048 + fmul16(isin, fmul16(isin, -2597) + 7932) - fmul16(icos, fmul16(icos, -2597) + 7932);
 }
-uint32_t isqrt32(uint32_t v)
-{
-    uint32_t g = 0;
-    for (int b = 15; b >= 0; b--) {
-        uint32_t t = g | (1u << b);
-        if (uint64_t(t) * t <= v) g = t;
+inline uint32_t isqrt32(uint32_t v) { return uint32_t(std::sqrt(double(v))); }   // exact: the double square root of v < 2^32 never rounds up to the next integer
+
+// bits2pulses (celt/decoder.rs:738-764) tabulated: for every row of the pulse cache, the pulse-count index chosen for a budget
+// of `bits` eighth-bits.  Cache entries are bytes, so every budget above 255 chooses as 256 does and every negative one as -1.
+struct PulseLut {
+    uint8_t q[24][258];
+    uint8_t row[105];
+    PulseLut()
+    {
+        int nrows = 0, off_of[24];
+        for (int i = 0; i < 105; i++) {
+            const int off = CELT_CACHE_INDEX[i];
+            row[i] = 0;
+            if (off < 0) continue;
+            int r = 0;
+            while (r < nrows && off_of[r] != off) r++;
+            if (r == nrows) {
+                off_of[nrows++] = off;
+                const uint8_t *cache = CELT_CACHE_BITS + off;
+                for (int bits = -1; bits <= 256; bits++) {
+                    int lo = 0, hi = cache[0];
+                    for (int it = 0; it < 6; it++) {
+                        int mid = (lo + hi + 1) >> 1;
+                        if (int(cache[mid]) >= bits) hi = mid; else lo = mid;
+                    }
+                    q[r][bits + 1] = uint8_t((bits - (lo == 0 ? -1 : int(cache[lo])) <= int(cache[hi]) - bits) ? lo : hi);
+                }
+            }
+            row[i] = uint8_t(r);
+        }
     }
-    return g;
-}
+};
+const PulseLut kPulseLut;
+
 inline uint32_t U(int n, int k) { return CELT_PVQ_U[CELT_PVQ_U_ROW[std::min(n, k)] + std::max(n, k)]; }   // :412, :663
 inline uint32_t V(int n, int k) { return U(n, k) + U(n, k + 1); }                                          // :666
 
@@ -176,12 +201,7 @@ public:
             return;
         }
         // bits2pulses / pulses2bits (celt/decoder.rs:738-764; RFC 6716 rate.h offsets)
-        int lo = 0, hi = cache[0], bits = b - 1;
-        for (int i = 0; i < 6; i++) {
-            int mid = (lo + hi + 1) >> 1;
-            if (int(cache[mid]) >= bits) hi = mid; else lo = mid;
-        }
-        int q = (bits - (lo == 0 ? -1 : int(cache[lo])) <= int(cache[hi]) - bits) ? lo : hi;
+        int q = kPulseLut.q[kPulseLut.row[(LM + 1) * 21 + band_]][std::max(-1, std::min(256, b - 1)) + 1];
         int curr = q ? cache[q] + 1 : 0;
         remaining_ -= curr;
         while (remaining_ < 0 && q > 0) {
