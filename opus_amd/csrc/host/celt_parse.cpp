@@ -90,16 +90,34 @@ public:
     OgCeltHdr *hdr_;
     int band_ = 0, intensity_ = 0, tf_change_ = 0, remaining_ = 0;
 
+    // A band's leaves are grouped for the device walk as they are emitted: X then Y, fill leaves in front of coded ones, decode
+    // order inside each group.  A band holds at most 16 leaves per channel (four levels of splits).
+    OgCeltLeaf group_[4][32];
+    int cnt_[4] = {0, 0, 0, 0};
+    bool fold_[4] = {false, false, false, false}, overflow_ = false;
+
     void emit(int off, int n, int k, int B, uint32_t index, bool dead, float gain, int cmshift, int chy, bool lowband, bool n1)
     {
-        OgCeltLeaf l;
+        const int g = (chy ? 2 : 0) + (k == 0 && !n1 ? 0 : 1);
+        if (cnt_[g] == 32) { overflow_ = true; return; }
+        OgCeltLeaf &l = group_[g][cnt_[g]++];
+        fold_[g] |= lowband;
         l.index = index; l.gain = gain;
         l.off = uint8_t(off); l.n = uint8_t(n); l.k = uint8_t(k);
         l.cmshift = uint8_t(cmshift); l.band = uint8_t(band_);
         l.pos = uint16_t((int(CELT_EBANDS[band_]) << hdr_->lm) + off);
         const int logb = 31 - __builtin_clz(unsigned(B));
         l.meta = uint8_t(logb | (dead ? OG_L_FILL_DEAD : 0) | (chy ? OG_L_CH_Y : 0) | (n1 ? OG_L_N1 : 0) | (lowband ? OG_L_HAS_LOWBAND : 0));
-        leaves_.push_back(l);
+    }
+
+    void close_band(OgCeltBand &bd)
+    {
+        for (int g = 0; g < 4; g++) leaves_.insert(leaves_.end(), group_[g], group_[g] + cnt_[g]);
+        if (fold_[0]) bd.flags |= OG_B_FOLD_X;
+        if (fold_[2]) bd.flags |= OG_B_FOLD_Y;
+        bd.fx = uint8_t(cnt_[0]); bd.nx = uint8_t(cnt_[0] + cnt_[1]);
+        bd.fy = uint8_t(cnt_[2]); bd.ny = uint8_t(cnt_[2] + cnt_[3]);
+        for (int g = 0; g < 4; g++) { cnt_[g] = 0; fold_[g] = false; }
     }
 
     void band_n1(bool stereo)                                  // celt/decoder.rs:1466-1495
@@ -330,6 +348,7 @@ int celt_parse_frame(CeltHostState &st, RangeDec &rd, int N, int start, int end,
             }
     }
     int tf_res[21] = {0};
+    bool overflow = false;
     {   // tf_decode, :994-1033
         int budget = total_bits, logp = transient ? 2 : 4, curr = 0, changed = 0;
         tell = rd.tell();
@@ -397,9 +416,9 @@ int celt_parse_frame(CeltHostState &st, RangeDec &rd, int N, int start, int end,
             int mid = (lo + hi) >> 1, psum = 0;
             bool done = false;
             for (int j = end; j-- > start;) {
-                int bj = vec_bits(mid, j) + offsets[j];
-                if (bj >= thresh[j] || done) { done = true; psum += std::min(bj, cap[j]); }
-                else if (bj >= C << BITRES) psum += C << BITRES;
+                const int bj = vec_bits(mid, j) + offsets[j];                 // selects, not branches: the outcome is data
+                done |= bj >= thresh[j];
+                psum += done ? std::min(bj, cap[j]) : bj >= C << BITRES ? C << BITRES : 0;
             }
             if (psum > total) hi = mid - 1; else lo = mid + 1;
         } while (lo <= hi);
@@ -422,9 +441,9 @@ int celt_parse_frame(CeltHostState &st, RangeDec &rd, int N, int start, int end,
             int mid = (lo + hi) >> 1, psum = 0;
             bool done = false;
             for (int j = end; j-- > start;) {
-                int t = interp(mid, j);
-                if (t >= thresh[j] || done) { done = true; psum += std::min(t, cap[j]); }
-                else if (t >= alloc_floor) psum += alloc_floor;
+                const int t = interp(mid, j);
+                done |= t >= thresh[j];
+                psum += done ? std::min(t, cap[j]) : t >= alloc_floor ? alloc_floor : 0;
             }
             if (psum > total) hi = mid; else lo = mid;
         }
@@ -433,8 +452,8 @@ int celt_parse_frame(CeltHostState &st, RangeDec &rd, int N, int start, int end,
             bool done = false;
             for (int j = end; j-- > start;) {
                 int t = interp(lo, j);
-                if (t < thresh[j] && !done) t = t >= alloc_floor ? alloc_floor : 0;
-                else done = true;
+                done |= t >= thresh[j];
+                t = done ? t : t >= alloc_floor ? alloc_floor : 0;
                 t = std::min(t, cap[j]);
                 pulses[j] = t;
                 psum += t;
@@ -572,35 +591,11 @@ int celt_parse_frame(CeltHostState &st, RangeDec &rd, int N, int start, int end,
             } else {
                 fp.quant_band(n, b, B, LM, 1.f, 0, lowband);
             }
-            {   // group the band's leaves for the device walk: X then Y, fill leaves first, decode order inside runs
-                OgCeltLeaf *first = leaves.data() + hdr->leaf_begin + bd.leaf0, *last = leaves.data() + leaves.size();
-                auto key = [](const OgCeltLeaf &l) {
-                    const bool fillleaf = l.k == 0 && !(l.meta & OG_L_N1);
-                    return ((l.meta & OG_L_CH_Y) ? 2 : 0) + (fillleaf ? 0 : 1);
-                };
-                const size_t nl = size_t(last - first);
-                OgCeltLeaf tmp[64];
-                if (nl <= 64) {                         // stable four-bucket placement (a band has at most 2 x 16 leaves)
-                    int at[4] = {0, 0, 0, 0}, pos[4];
-                    for (size_t q = 0; q < nl; q++) at[key(first[q])]++;
-                    pos[0] = 0; pos[1] = at[0]; pos[2] = pos[1] + at[1]; pos[3] = pos[2] + at[2];
-                    for (size_t q = 0; q < nl; q++) tmp[pos[key(first[q])]++] = first[q];
-                    for (size_t q = 0; q < nl; q++) first[q] = tmp[q];
-                } else {
-                    std::stable_sort(first, last, [&](const OgCeltLeaf &a, const OgCeltLeaf &c) { return key(a) < key(c); });
-                }
-                int cnt[4] = {0, 0, 0, 0};
-                for (OgCeltLeaf *l = first; l != last; ++l) {
-                    cnt[key(*l)]++;
-                    if (key(*l) == 0 && (l->meta & OG_L_HAS_LOWBAND)) bd.flags |= OG_B_FOLD_X;
-                    if (key(*l) == 2 && (l->meta & OG_L_HAS_LOWBAND)) bd.flags |= OG_B_FOLD_Y;
-                }
-                bd.fx = uint8_t(cnt[0]); bd.nx = uint8_t(cnt[0] + cnt[1]);
-                bd.fy = uint8_t(cnt[2]); bd.ny = uint8_t(cnt[2] + cnt[3]);
-            }
+            fp.close_band(bd);
             balance += pulses[i] + tellf;
             update_lowband = b > (n << BITRES);
         }
+        overflow = fp.overflow_;
         bool anti_on = false;
         if (anti_rsv > 0) anti_on = rd.bits(1);
         if (anti_on) hdr->flags |= OG_F_ANTICOLLAPSE;
@@ -649,7 +644,7 @@ int celt_parse_frame(CeltHostState &st, RangeDec &rd, int N, int start, int end,
         for (int i = 0; i < 21; i++)
             if (i < start || i >= end) { st.oldE[c][i] = 0.f; st.logE1[c][i] = st.logE2[c][i] = -28.f; }
     st.rng = rd.rng();                                             // :2322
-    return rd.tell() > total_bits ? -1 : 0;
+    return rd.tell() > total_bits || overflow ? -1 : 0;
 }
 
 }  // namespace og

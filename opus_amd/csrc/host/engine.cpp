@@ -6,6 +6,8 @@
 // Dec::send_packet (decoder.rs:48-127), batch_decode the device half.
 #include <hip/hip_runtime_api.h>
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -17,6 +19,7 @@
 #include <new>
 #include <thread>
 #include <vector>
+#include "leaf_sort.hpp"
 #include "stream_parser.hpp"
 #include "../hip/device_util.hpp"
 
@@ -149,6 +152,7 @@ struct opusgpu_batch {
     std::unique_ptr<ParsePool> pool;                        // parse threads and their arenas, kept between batch_send calls
     std::vector<Worker> workers;
     std::vector<ParsedPacket> parsed;
+    std::vector<uint32_t> key_count;                        // [worker][og::K1_NKEYS + 256]: the threaded K1 sort's histograms
 
     // side-info of the last batch_send, frames ordered by round (frame index inside the packet)
     PinnedBuf<OgCeltHdr> h_celt;
@@ -185,6 +189,81 @@ struct opusgpu_batch {
         if (d_pcm) (void)hipFree(d_pcm);
     }
 };
+
+// The second half of a uniform send (batch_send_impl), on the parse threads: every worker copies its leaves and headers to
+// their places in the pinned arrays -- the records of the send form one round, [stream][t][f], which is the order the workers
+// hold them in -- and the K1 work list (opusgpu_sort_pvq_leaves' order exactly: key descending, then frame, then leaf) comes
+// from per-worker histograms, one prefix pass over them, and a scatter by every worker of its own leaves.
+// Returns the number of refs; class counts of the round go to (*classes)[4 * round ..].
+static uint32_t merge_uniform(opusgpu_batch *b, uint32_t n, uint32_t T, int nw, const uint32_t *stream_ids, int32_t *errors,
+                              const std::vector<size_t> &leaf_base, std::vector<uint32_t> *classes, uint32_t rounds, uint32_t round)
+{
+    using namespace og;
+    constexpr size_t ROW = K1_NKEYS + 256;                   // a worker's histogram: keys, then leaves per dimension n
+    std::vector<Worker> &workers = b->workers;
+    std::vector<size_t> celt_base(size_t(nw) + 1, 0);
+    for (int w = 0; w < nw; w++) celt_base[w + 1] = celt_base[w] + workers[w].celt.size();
+    if (b->key_count.size() < ROW * size_t(nw)) b->key_count.resize(ROW * size_t(nw));
+    const std::function<void(int)> place = [&](int w) {
+        Worker &W = workers[w];
+        uint32_t *cnt = b->key_count.data() + ROW * size_t(w);
+        std::memset(cnt, 0, ROW * sizeof(uint32_t));
+        if (!W.leaves.empty()) std::memcpy(b->h_leaves.p + leaf_base[w], W.leaves.data(), W.leaves.size() * sizeof(OgCeltLeaf));
+        const uint32_t lo = uint32_t(uint64_t(n) * w / nw), hi = uint32_t(uint64_t(n) * (w + 1) / nw);
+        OgCeltHdr *out = b->h_celt.p + celt_base[w];
+        size_t j = 0;
+        for (uint32_t i = lo; i < hi; i++) {
+            uint32_t pcm_off = 0;
+            const uint32_t stream = stream_ids ? stream_ids[i] : i;
+            for (uint32_t t = 0; t < T; t++) {
+                const ParsedPacket &pp = b->parsed[size_t(i) * T + t];
+                if (errors) errors[size_t(i) * T + t] = OPUSGPU_OK;
+                for (int f0 = 0; f0 < pp.rc; f0++, j++) {
+                    OgCeltHdr &hd = out[j];
+                    hd = W.celt[j];
+                    hd.stream = stream;
+                    hd.pcm_off += pcm_off;                   // the parser left the offset inside the Opus frame
+                    const OgCeltLeaf *lf = W.leaves.data() + hd.leaf_begin;
+                    for (uint32_t l = 0; l < hd.nleaves; l++)
+                        if (k1_wanted(hd, lf[l])) { cnt[k1_key(lf[l])]++; cnt[K1_NKEYS + lf[l].n]++; }
+                    hd.leaf_begin = uint32_t(hd.leaf_begin + leaf_base[w]);
+                    pcm_off += pp.fi[f0].frame_size;
+                }
+            }
+            b->nsamples[stream] = pcm_off;
+        }
+    };
+    b->pool->run(nw, place);
+    // counts -> first output index of every (key, worker): keys from the largest down, inside a key the workers in order
+    uint32_t total = 0;
+    for (int d = 255; d >= 0; d--) {
+        uint32_t any = 0;                                    // few of the 256 dimensions occur: skip the keys of the others
+        for (int w = 0; w < nw; w++) any |= b->key_count[ROW * size_t(w) + K1_NKEYS + size_t(d)];
+        if (!any) continue;
+        for (int k = d * K1_KQ + K1_KQ - 1; k >= d * K1_KQ; k--)
+            for (int w = 0; w < nw; w++) {
+                uint32_t &c = b->key_count[ROW * size_t(w) + size_t(k)];
+                const uint32_t here = c;
+                c = total;
+                total += here;
+            }
+    }
+    classes->assign(4 * size_t(rounds) + 4, 0);
+    for (int w = 0; w < nw; w++)
+        for (int d = 0; d < 256; d++) (*classes)[4 * size_t(round) + k1_class(d)] += b->key_count[ROW * size_t(w) + K1_NKEYS + d];
+    const std::function<void(int)> scatter = [&](int w) {
+        uint32_t *at = b->key_count.data() + ROW * size_t(w);
+        const OgCeltHdr *hd = b->h_celt.p + celt_base[w];
+        const size_t nc = workers[w].celt.size();
+        for (size_t j = 0; j < nc; j++) {
+            const OgCeltLeaf *lf = b->h_leaves.p + hd[j].leaf_begin;
+            for (uint32_t l = 0; l < hd[j].nleaves; l++)
+                if (k1_wanted(hd[j], lf[l])) b->h_refs.p[at[k1_key(lf[l])]++] = k1_ref(hd[j], hd[j].leaf_begin + l, uint32_t(celt_base[w] + j));
+        }
+    };
+    b->pool->run(nw, scatter);
+    return total;
+}
 
 extern "C" {
 
@@ -258,6 +337,12 @@ static int batch_send_impl(opusgpu_batch *b, const uint8_t *const *pkts, const u
         }
     }
 
+    // OPUSGPU_TIMING=1: one line per send on stderr, the milliseconds of its three phases (parse on the pool / merge / K1 sort)
+    static const bool timing = std::getenv("OPUSGPU_TIMING") != nullptr;
+    const auto now = [] { return std::chrono::steady_clock::now(); };
+    const auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point c) { return std::chrono::duration<double, std::milli>(c - a).count(); };
+    const auto t_begin = now();
+
     // ---- parse: static partition of the streams over the workers, one stream per task
     if (!b->pool) b->pool.reset(new ParsePool(worker_count()));
     const int nw = std::max(1, std::min<int>(b->pool->size(), int(n)));
@@ -288,6 +373,7 @@ static int batch_send_impl(opusgpu_batch *b, const uint8_t *const *pkts, const u
         }
     };
     b->pool->run(nw, run);
+    const auto t_parsed = now();
 
     // ---- merge: leaves concatenated per worker, frames regrouped by round
     std::vector<size_t> leaf_base(nw + 1, 0);
@@ -302,9 +388,6 @@ static int batch_send_impl(opusgpu_batch *b, const uint8_t *const *pkts, const u
     if ((rc = b->h_leaves.reserve(leaf_base[nw] + 1))) return rc;
     if ((rc = b->h_celt.reserve(tot_celt + 1))) return rc;
     if ((rc = b->h_silk.reserve(tot_silk + 1))) return rc;
-    for (int w = 0; w < nw; w++)
-        if (!workers[w].leaves.empty())
-            std::memcpy(b->h_leaves.p + leaf_base[w], workers[w].leaves.data(), workers[w].leaves.size() * sizeof(OgCeltLeaf));
     b->h_leaves.n = leaf_base[nw];
 
     // A stream's work must run in order: Opus frame f of a packet = rounds 4f .. 4f+3 (OG_ROUNDS_PER_FRAME); its SILK frames (up
@@ -314,27 +397,60 @@ static int batch_send_impl(opusgpu_batch *b, const uint8_t *const *pkts, const u
     uint32_t rounds = 0;
     const size_t np = size_t(n) * T;
     for (size_t i = 0; i < np; i++) if (parsed[i].rc > 0) rounds = std::max(rounds, RPF * (parsed[i].frame0 + uint32_t(parsed[i].rc)));
-    // Fast path: every packet of the send holds the same number F of frames, all CELT-only (no SILK, no redundant frames), and
-    // T F > 1 -- several packets per stream and / or code 1-3 packets.  The records are then laid out [stream][t][f] and the
-    // whole send is ONE launch in which a tail workgroup walks a stream's T F frames in time order (frames_per_group = T F),
-    // instead of a round of launches per frame.
+    // Uniform sends: every packet holds the same number F of frames, all CELT-only (no SILK, no redundant frames).  All their
+    // CELT records belong to one round, laid out [stream][t][f] -- the order in which the workers hold them -- so the workers
+    // finish the send themselves (merge_uniform below).  With T F > 1 (several packets per stream and / or code 1-3 packets)
+    // the whole send is moreover ONE launch in which a tail workgroup walks a stream's T F frames in time order
+    // (frames_per_group = T F), instead of a round of launches per frame.
     const uint32_t F = np && parsed[0].rc > 0 ? uint32_t(parsed[0].rc) : 0;
-    bool grouped = n > 0 && F > 0 && size_t(T) * F > 1;
-    for (size_t i = 0; i < np && grouped; i++) {
+    bool uniform = n > 0 && F > 0 && tot_silk == 0 && tot_celt == np * F && tot_celt <= OG_REF_FRAME_MASK;
+    for (size_t i = 0; i < np && uniform; i++) {
         const ParsedPacket &pp = parsed[i];
-        grouped = pp.rc == int(F);
-        for (int f = 0; f < pp.rc && grouped; f++)
-            grouped = pp.fi[f].nsilk == 0 && pp.fi[f].has_celt == 1 &&
+        uniform = pp.rc == int(F);
+        for (int f = 0; f < pp.rc && uniform; f++)
+            uniform = pp.fi[f].nsilk == 0 && pp.fi[f].has_celt == 1 &&
                       (workers[pp.worker].celt[pp.fi[f].celt_index].spread >> OG_X_SHIFT) == (OG_ROUND_MAIN << (OG_ROUND_SHIFT - OG_X_SHIFT));
     }
+    const bool grouped = uniform && size_t(T) * F > 1;
     if (grouped) rounds = 1;
+    if (uniform) {
+        if ((rc = b->h_refs.reserve(b->h_leaves.n + 1))) return rc;
+        const uint32_t round = grouped ? 0 : OG_ROUND_MAIN;
+        const uint32_t nref = merge_uniform(b, n, T, nw, stream_ids, errors, leaf_base, &b->ref_classes, rounds, round);
+        b->celt_round_off.assign(rounds + 1, uint32_t(tot_celt));
+        b->ref_round_off.assign(rounds + 1, nref);
+        for (uint32_t r = 0; r <= round; r++) b->celt_round_off[r] = b->ref_round_off[r] = 0;
+        b->silk_round_off.assign(rounds + 1, 0);
+        b->h_celt.n = tot_celt;
+        b->h_silk.n = 0;
+        b->h_refs.n = nref;
+        b->grouped_T = grouped ? T * F : 0;
+        b->pending = true;
+        if (std::getenv("OPUSGPU_CHECK_SORT")) {            // self-check (tests): the one-thread sort of the same round must agree
+            std::vector<OgLeafRef> want(b->h_leaves.n + 1);
+            uint32_t cls[4];
+            const uint32_t nw2 = opusgpu_sort_pvq_leaves(b->h_celt.p, uint32_t(tot_celt), b->h_leaves.p, want.data(), uint32_t(want.size()), cls);
+            if (nw2 != nref || std::memcmp(want.data(), b->h_refs.p, size_t(nref) * sizeof(OgLeafRef)) != 0 ||
+                std::memcmp(cls, &b->ref_classes[4 * round], sizeof cls) != 0) {
+                std::fprintf(stderr, "opusgpu: the threaded K1 sort differs from opusgpu_sort_pvq_leaves\n");
+                return OPUSGPU_DEVICE;
+            }
+        }
+        if (timing)
+            std::fprintf(stderr, "opusgpu send: %u x %u packets, %d threads: parse %.3f ms, merge + sort on the threads %.3f ms\n", n, T, nw,
+                         ms(t_begin, t_parsed), ms(t_parsed, now()));
+        return OPUSGPU_OK;
+    }
+    for (int w = 0; w < nw; w++)
+        if (!workers[w].leaves.empty())
+            std::memcpy(b->h_leaves.p + leaf_base[w], workers[w].leaves.data(), workers[w].leaves.size() * sizeof(OgCeltLeaf));
     std::vector<uint32_t> ccount(rounds + 1, 0), scount(rounds + 1, 0);
     for (size_t i = 0; i < np; i++) {
         const ParsedPacket &pp = parsed[i];
         for (int f = 0; f < pp.rc; f++) {
             const uint32_t r0 = RPF * (pp.frame0 + uint32_t(f));
             for (uint32_t c = 0; c < pp.fi[f].has_celt; c++)
-                ccount[grouped ? 0 : r0 + (workers[pp.worker].celt[pp.fi[f].celt_index + c].spread >> OG_ROUND_SHIFT)]++;
+                ccount[r0 + (workers[pp.worker].celt[pp.fi[f].celt_index + c].spread >> OG_ROUND_SHIFT)]++;
             for (uint32_t k = 0; k < pp.fi[f].nsilk; k++) scount[r0 + k]++;
         }
     }
@@ -368,8 +484,7 @@ static int batch_send_impl(opusgpu_batch *b, const uint8_t *const *pkts, const u
                     hd.stream = pp.stream;
                     hd.pcm_off += pcm_off;              // the parser left the offset inside the Opus frame
                     hd.leaf_begin = uint32_t(hd.leaf_begin + leaf_base[w]);
-                    // (grouped: the workers' blocks of streams are consecutive, so filling in order gives [stream][t])
-                    b->h_celt.p[cfill[grouped ? 0 : RPF * f + (hd.spread >> OG_ROUND_SHIFT)]++] = hd;
+                    b->h_celt.p[cfill[RPF * f + (hd.spread >> OG_ROUND_SHIFT)]++] = hd;
                 }
                 pcm_off += fi.frame_size;
             }
@@ -379,6 +494,7 @@ static int batch_send_impl(opusgpu_batch *b, const uint8_t *const *pkts, const u
     }
     b->h_celt.n = tot_celt;
     b->h_silk.n = tot_silk;
+    const auto t_merged = now();
     // K1 work lists: per round, that round's PVQ leaves sorted by size; frame indices are relative to the round
     if ((rc = b->h_refs.reserve(b->h_leaves.n + 1))) return rc;
     b->ref_round_off.assign(rounds + 1, 0);
@@ -391,8 +507,11 @@ static int batch_send_impl(opusgpu_batch *b, const uint8_t *const *pkts, const u
         b->ref_round_off[r + 1] = nref;
     }
     b->h_refs.n = nref;
-    b->grouped_T = grouped ? T * F : 0;
+    b->grouped_T = 0;
     b->pending = true;
+    if (timing)
+        std::fprintf(stderr, "opusgpu send: %u x %u packets, %d threads: parse %.3f ms, merge %.3f ms, sort %.3f ms\n", n, T, nw,
+                     ms(t_begin, t_parsed), ms(t_parsed, t_merged), ms(t_merged, now()));
     return OPUSGPU_OK;
 }
 

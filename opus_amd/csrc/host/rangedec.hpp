@@ -33,15 +33,13 @@ public:
     int tell() const { return nbits_total_ - ilog(rng_); }               // entropy.rs:375
     int tell_frac() const                                                // entropy.rs:380-392
     {
-        int l = ilog(rng_);
-        uint32_t r = rng_ >> (l - 16);
-        for (int i = 0; i < 3; i++) {
-            r = (r * r) >> 15;
-            int b = (int)(r >> 16);
-            l = 2 * l + b;
-            r >>= b;
-        }
-        return nbits_total_ * 8 - l;
+        // The reference squares the top 16 bits of rng three times and collects one bit each time.  That recurrence is monotonic
+        // in r = rng >> (l - 16), so its three bits are the number of thresholds at or below r (the seven values of r in
+        // [2^15, 2^16) where the recurrence's result steps; tests/test_host_parse.py derives them from the loop again).
+        const int l = ilog(rng_);
+        const uint32_t r = rng_ >> (l - 16);
+        const int frac = (r >= 35734u) + (r >= 38968u) + (r >= 42496u) + (r >= 46341u) + (r >= 50536u) + (r >= 55110u) + (r >= 60098u);
+        return nbits_total_ * 8 - (l * 8 + frac);
     }
     void to_end() { nbits_total_ += storage_bits() - tell(); }           // entropy.rs:540
 

@@ -147,6 +147,26 @@ class BatchDecoder:
         _chk(self._lib.opusgpu_batch_send(self._h, arr, lens, ids, n, errs), "batch_send")
         return list(errs)
 
+    def send_packed(self, packets, lens=None):
+        """packets: C-contiguous uint8 array [n, bytes] (or [n, T, bytes]: T consecutive packets per stream), one row per
+        packet; lens: bytes used of each row (default: all).  The same call as send() / send_multi() without a Python
+        object per packet: the pointer array is computed from the array's address.  Returns the error codes as an array."""
+        import numpy as np
+        assert packets.dtype == np.uint8 and packets.flags.c_contiguous and packets.ndim in (2, 3)
+        n, T = packets.shape[0], (packets.shape[1] if packets.ndim == 3 else 1)
+        width = packets.shape[-1]
+        ptrs = packets.ctypes.data + np.arange(n * T, dtype=np.uint64) * np.uint64(width)
+        ln = np.full(n * T, width, np.uint32) if lens is None else np.ascontiguousarray(lens, np.uint32).reshape(n * T)
+        errs = np.zeros(n * T, np.int32)
+        pp = C.cast(ptrs.ctypes.data, C.POINTER(C.c_char_p))
+        lp, ep = ln.ctypes.data_as(C.POINTER(C.c_uint32)), errs.ctypes.data_as(C.POINTER(C.c_int32))
+        if packets.ndim == 3:
+            _chk(self._lib.opusgpu_batch_send_multi(self._h, pp, lp, None, n, T, ep), "batch_send_multi")
+            self._cap = max(getattr(self, "_cap", 5760), 5760 * T)
+        else:
+            _chk(self._lib.opusgpu_batch_send(self._h, pp, lp, None, n, ep), "batch_send")
+        return errs
+
     def send_multi(self, packets, stream_ids=None):
         """packets: list (one entry per stream) of equally long lists of consecutive packets; returns per-stream lists of
         error codes.  The stream's PCM row then holds the packets' output back to back."""

@@ -27,11 +27,11 @@ def build_celt_steps(parser, packets, T, nsteps, first_frame=0):
         leaf_parts, leaf_off, pf_on = [], 0, 0
         for t in range(T):
             f = first_frame + k * T + t
-            pk = [packets[s, f].tobytes() for s in range(S)]
+            pk = np.ascontiguousarray(packets[:, f])
             t0 = time.perf_counter()
-            errs = parser.send(pk)
+            errs = parser.send_packed(pk)                    # the timed region is the C call (opusgpu_batch_send) and its pointer array
             t_parse += time.perf_counter() - t0
-            assert not any(errs), errs
+            assert not errs.any(), errs
             celt, leaves, _ = parser.sideinfo()
             assert len(celt) == S
             hb = np.frombuffer(celt, dtype=np.uint8).reshape(S, HS).copy()

@@ -1,5 +1,6 @@
 """GPU parity: the HIP CELT path, called through the C ABI, against the CPU oracle."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -366,3 +367,38 @@ def test_multi_frame_packets_in_one_launch():
                 g = multi.read(s)
                 assert g.shape == w.shape, (vid, i, s)
                 check_pcm(w, g, f"vector {vid} packets {i}, {i + 1} stream {s} (send_multi)")
+
+
+@pytest.mark.gpu
+def test_uniform_send_finished_on_the_threads():
+    """CELT-only sends of equal frame count are merged and sorted by the parse threads (engine.cpp merge_uniform): the
+    records, PCM and error codes must be those of the general path -- here forced by one stream that brings a different
+    frame count -- and of send_packed (pointer array computed from a numpy array); the K1 work list is checked inside
+    the library on every send of the test session (OPUSGPU_CHECK_SORT, tests/conftest.py)."""
+    assert os.environ.get("OPUSGPU_CHECK_SORT")
+    ns, nf = 301, 5                                      # 301 streams: the workers' blocks differ in size
+    pk = synth.celt_fb_stereo_packets(range(ns), nf, 160)
+    a, b, c = BatchDecoder(ns, 2, 0), BatchDecoder(ns, 2, 0), BatchDecoder(ns + 1, 2, 0)
+    two = bytes([0xFD]) + pk[0, 0, 1:].tobytes()         # code 1: two frames of 80 bytes in the extra stream
+    for f in range(nf):
+        rows = [pk[s, f].tobytes() for s in range(ns)]
+        assert not any(a.send(rows))
+        assert not b.send_packed(np.ascontiguousarray(pk[:, f])).any()
+        assert not any(c.send(rows + [two]))
+        sa, sb, sc = a.sideinfo(), b.sideinfo(), c.sideinfo()
+        assert bytes(sa[0]) == bytes(sb[0]) and bytes(sa[1]) == bytes(sb[1])
+        assert len(sc[0]) == ns + 2
+        for d in (a, b, c):
+            d.decode()
+        for s in (0, 1, 150, 299, 300):
+            ga, gb, gc = a.read(s), b.read(s), c.read(s)
+            assert ga.shape == (960, 2) and np.array_equal(ga, gb) and np.array_equal(ga, gc), (f, s)
+    # several packets per stream per call: [n, T, bytes]
+    m1, m2 = BatchDecoder(ns, 2, 0), BatchDecoder(ns, 2, 0)
+    e1 = m1.send_multi([[pk[s, f].tobytes() for f in range(4)] for s in range(ns)])
+    e2 = m2.send_packed(np.ascontiguousarray(pk[:, :4]))
+    assert not any(any(e) for e in e1) and not e2.any()
+    assert bytes(m1.sideinfo()[0]) == bytes(m2.sideinfo()[0])
+    m1.decode(), m2.decode()
+    for s in (0, 77, 300):
+        assert np.array_equal(m1.read(s), m2.read(s)) and m1.read(s).shape == (4 * 960, 2)

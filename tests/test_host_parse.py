@@ -1,6 +1,7 @@
 """Host layer (C++ parser behind the C ABI) against the CPU oracle: framing, side-info records, final range.
 No GPU: these call only the opusgpu_parse_* / opusgpu_packet_parse entry points."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -219,3 +220,30 @@ def test_sort_pvq_leaves_orders_by_size_then_pulses():
             # a buffer that is too small is refused, not overrun
             if got:
                 assert lib.opusgpu_sort_pvq_leaves(hp.celt, 1, hp.leaves, refs, got - 1, classes) == 0
+
+
+def test_tell_frac_thresholds_match_the_squaring_loop():
+    """the host range decoder's tell_frac (host/rangedec.hpp) counts thresholds instead of running the reference's three
+    squarings (entropy.rs:380-392): the recurrence must be monotonic over all 32768 arguments and step exactly at the
+    constants in the header"""
+    import re
+
+    def frac(r):
+        l = 0
+        for _ in range(3):
+            r = (r * r) >> 15
+            b = r >> 16
+            l = 2 * l + b
+            r >>= b
+        return l
+
+    steps, prev = [], 0
+    for r in range(1 << 15, 1 << 16):
+        f = frac(r)
+        assert f in (prev, prev + 1)
+        if f != prev:
+            steps.append(r)
+        prev = f
+    src = open(os.path.join(os.path.dirname(__file__), "..", "opus_amd", "csrc", "host", "rangedec.hpp")).read()
+    body = src[src.index("int tell_frac() const"):src.index("void to_end()")]
+    assert [int(x) for x in re.findall(r"r >= (\d+)u", body)] == steps and len(steps) == 7
