@@ -74,6 +74,8 @@ struct Worker {
     std::vector<OgCeltHdr> celt;
     std::vector<OgCeltLeaf> leaves;
     std::vector<OgSilkFrame> silk;
+    std::vector<uint32_t> ccount, scount;    // CELT / SILK records per round among this worker's packets, then: where its first goes
+    void reach(size_t nrounds) { if (ccount.size() < nrounds) { ccount.resize(nrounds, 0); scount.resize(nrounds, 0); } }
 };
 
 // Parse threads of a batch: started once, parked on a condition variable between batch_send calls (a send of 4096 packets
@@ -350,7 +352,7 @@ static int batch_send_impl(opusgpu_batch *b, const uint8_t *const *pkts, const u
     std::vector<ParsedPacket> &parsed = b->parsed;
     if (int(workers.size()) < nw) workers.resize(nw);
     if (parsed.size() < size_t(n) * T) parsed.resize(size_t(n) * T);
-    for (auto &W : workers) { W.celt.clear(); W.leaves.clear(); W.silk.clear(); }      // capacity stays
+    for (auto &W : workers) { W.celt.clear(); W.leaves.clear(); W.silk.clear(); W.ccount.clear(); W.scount.clear(); }   // capacity stays
     const std::function<void(int)> run = [&](int w) {
         Worker &W = workers[w];
         const uint32_t lo = uint32_t(uint64_t(n) * w / nw), hi = uint32_t(uint64_t(n) * (w + 1) / nw);
@@ -366,6 +368,12 @@ static int batch_send_impl(opusgpu_batch *b, const uint8_t *const *pkts, const u
                 if (pp.rc < 0) {                        // a bad packet never poisons the batch
                     W.celt.resize(pp.celt0); W.leaves.resize(pp.leaf0); W.silk.resize(pp.silk0);
                 } else {
+                    for (int f = 0; f < pp.rc; f++) {       // the rounds its records will run in (see the merge below)
+                        const uint32_t r0 = OG_ROUNDS_PER_FRAME * (frames_before + uint32_t(f));
+                        W.reach(r0 + OG_ROUNDS_PER_FRAME);
+                        for (uint32_t c = 0; c < pp.fi[f].has_celt; c++) W.ccount[r0 + (W.celt[pp.fi[f].celt_index + c].spread >> OG_ROUND_SHIFT)]++;
+                        for (uint32_t k = 0; k < pp.fi[f].nsilk; k++) W.scount[r0 + k]++;
+                    }
                     frames_before += uint32_t(pp.rc);
                 }
                 pp.ncelt = W.celt.size() - pp.celt0; pp.nleaf = W.leaves.size() - pp.leaf0; pp.nsilk = W.silk.size() - pp.silk0;
@@ -396,7 +404,7 @@ static int batch_send_impl(opusgpu_batch *b, const uint8_t *const *pkts, const u
     constexpr uint32_t RPF = OG_ROUNDS_PER_FRAME;
     uint32_t rounds = 0;
     const size_t np = size_t(n) * T;
-    for (size_t i = 0; i < np; i++) if (parsed[i].rc > 0) rounds = std::max(rounds, RPF * (parsed[i].frame0 + uint32_t(parsed[i].rc)));
+    for (int w = 0; w < nw; w++) rounds = std::max(rounds, uint32_t(workers[w].ccount.size()));     // RPF x the most frames of a stream
     // Uniform sends: every packet holds the same number F of frames, all CELT-only (no SILK, no redundant frames).  All their
     // CELT records belong to one round, laid out [stream][t][f] -- the order in which the workers hold them -- so the workers
     // finish the send themselves (merge_uniform below).  With T F > 1 (several packets per stream and / or code 1-3 packets)
@@ -441,57 +449,59 @@ static int batch_send_impl(opusgpu_batch *b, const uint8_t *const *pkts, const u
                          ms(t_begin, t_parsed), ms(t_parsed, now()));
         return OPUSGPU_OK;
     }
-    for (int w = 0; w < nw; w++)
-        if (!workers[w].leaves.empty())
-            std::memcpy(b->h_leaves.p + leaf_base[w], workers[w].leaves.data(), workers[w].leaves.size() * sizeof(OgCeltLeaf));
-    std::vector<uint32_t> ccount(rounds + 1, 0), scount(rounds + 1, 0);
-    for (size_t i = 0; i < np; i++) {
-        const ParsedPacket &pp = parsed[i];
-        for (int f = 0; f < pp.rc; f++) {
-            const uint32_t r0 = RPF * (pp.frame0 + uint32_t(f));
-            for (uint32_t c = 0; c < pp.fi[f].has_celt; c++)
-                ccount[r0 + (workers[pp.worker].celt[pp.fi[f].celt_index + c].spread >> OG_ROUND_SHIFT)]++;
-            for (uint32_t k = 0; k < pp.fi[f].nsilk; k++) scount[r0 + k]++;
-        }
-    }
+    // The records of a round lie in the order of the workers' blocks of streams.  Per-round counts came with the parse; one pass
+    // turns them into the rounds' offsets and into every worker's first index in every round, and the workers place their own
+    // records (and copy their leaves).
     b->celt_round_off.assign(rounds + 1, 0);
     b->silk_round_off.assign(rounds + 1, 0);
     for (uint32_t r = 0; r < rounds; r++) {
-        b->celt_round_off[r + 1] = b->celt_round_off[r] + ccount[r];
-        b->silk_round_off[r + 1] = b->silk_round_off[r] + scount[r];
+        uint32_t c = b->celt_round_off[r], k = b->silk_round_off[r];
+        for (int w = 0; w < nw; w++) {
+            Worker &W = workers[w];
+            W.reach(rounds);
+            const uint32_t wc = W.ccount[r], wk = W.scount[r];
+            W.ccount[r] = c; W.scount[r] = k;
+            c += wc; k += wk;
+        }
+        b->celt_round_off[r + 1] = c;
+        b->silk_round_off[r + 1] = k;
     }
-    std::vector<uint32_t> cfill(b->celt_round_off.begin(), b->celt_round_off.end()), sfill(b->silk_round_off.begin(), b->silk_round_off.end());
-    for (int w = 0; w < nw; w++) {
+    const std::function<void(int)> place = [&](int w) {
+        Worker &W = workers[w];
+        if (!W.leaves.empty()) std::memcpy(b->h_leaves.p + leaf_base[w], W.leaves.data(), W.leaves.size() * sizeof(OgCeltLeaf));
+        uint32_t *cfill = W.ccount.data(), *sfill = W.scount.data();
         const uint32_t lo = uint32_t(uint64_t(n) * w / nw), hi = uint32_t(uint64_t(n) * (w + 1) / nw);
         for (uint32_t i = lo; i < hi; i++) {
-          uint32_t pcm_off = 0;
-          for (uint32_t t = 0; t < T; t++) {
-            const ParsedPacket &pp = parsed[size_t(i) * T + t];
-            if (errors) errors[size_t(i) * T + t] = pp.rc < 0 ? pp.rc : OPUSGPU_OK;
-            for (int f0 = 0; f0 < pp.rc; f0++) {
-                const OgFrameInfo &fi = pp.fi[f0];
-                const uint32_t f = pp.frame0 + uint32_t(f0);
-                uint32_t sub = 0;                       // SILK frames of one Opus frame are consecutive 20 ms pieces
-                for (uint32_t k = 0; k < fi.nsilk; k++) {
-                    OgSilkFrame sf = workers[w].silk[fi.silk_index + k];
-                    sf.stream = pp.stream;
-                    sf.pcm_off = pcm_off + sub;
-                    sub += uint32_t(sf.f_size) * (sf.bandwidth == 0 ? 6u : sf.bandwidth == 1 ? 4u : 3u);
-                    b->h_silk.p[sfill[RPF * f + k]++] = sf;
+            uint32_t pcm_off = 0;
+            for (uint32_t t = 0; t < T; t++) {
+                const ParsedPacket &pp = parsed[size_t(i) * T + t];
+                if (errors) errors[size_t(i) * T + t] = pp.rc < 0 ? pp.rc : OPUSGPU_OK;
+                for (int f0 = 0; f0 < pp.rc; f0++) {
+                    const OgFrameInfo &fi = pp.fi[f0];
+                    const uint32_t f = pp.frame0 + uint32_t(f0);
+                    uint32_t sub = 0;                   // SILK frames of one Opus frame are consecutive 20 ms pieces
+                    for (uint32_t k = 0; k < fi.nsilk; k++) {
+                        OgSilkFrame &sf = b->h_silk.p[sfill[RPF * f + k]++];
+                        sf = W.silk[fi.silk_index + k];
+                        sf.stream = pp.stream;
+                        sf.pcm_off = pcm_off + sub;
+                        sub += uint32_t(sf.f_size) * (sf.bandwidth == 0 ? 6u : sf.bandwidth == 1 ? 4u : 3u);
+                    }
+                    for (uint32_t c = 0; c < fi.has_celt; c++) {
+                        const OgCeltHdr &src = W.celt[fi.celt_index + c];
+                        OgCeltHdr &hd = b->h_celt.p[cfill[RPF * f + (src.spread >> OG_ROUND_SHIFT)]++];
+                        hd = src;
+                        hd.stream = pp.stream;
+                        hd.pcm_off += pcm_off;          // the parser left the offset inside the Opus frame
+                        hd.leaf_begin = uint32_t(hd.leaf_begin + leaf_base[w]);
+                    }
+                    pcm_off += fi.frame_size;
                 }
-                for (uint32_t c = 0; c < fi.has_celt; c++) {
-                    OgCeltHdr hd = workers[w].celt[fi.celt_index + c];
-                    hd.stream = pp.stream;
-                    hd.pcm_off += pcm_off;              // the parser left the offset inside the Opus frame
-                    hd.leaf_begin = uint32_t(hd.leaf_begin + leaf_base[w]);
-                    b->h_celt.p[cfill[RPF * f + (hd.spread >> OG_ROUND_SHIFT)]++] = hd;
-                }
-                pcm_off += fi.frame_size;
+                b->nsamples[pp.stream] = pcm_off;
             }
-            b->nsamples[pp.stream] = pcm_off;
-          }
         }
-    }
+    };
+    b->pool->run(nw, place);
     b->h_celt.n = tot_celt;
     b->h_silk.n = tot_silk;
     const auto t_merged = now();
