@@ -413,7 +413,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     elapsed = sharding.max_over_ranks(elapsed, dev)
-    assert bool(torch.isfinite(pcm).all())
+    assert a.no_verify or bool(torch.isfinite(pcm).all())         # (profiling knobs that skip stages leave garbage: --no-verify)
 
     # ---- outside the timed region: the last step's PCM of a sample of streams (first, last, interior) against the CPU oracle,
     #      which decodes those streams from their first packet (all nsteps * T frames: the decoder state carries over)

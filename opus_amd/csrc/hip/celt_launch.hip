@@ -18,9 +18,16 @@
 // end of round 2, two batches for the two small classes: 177 us against 160.)
 struct OgPvqClasses { uint32_t cnt[4], wg0[4]; };      // leaves per class (largest first); first workgroup of each class
 #define OG_K1_BATCHES(c) 1u
+#ifndef OG_K1_SMALL_PROBES
+#define OG_K1_SMALL_PROBES 4          /* table probes per cwrsi iteration for the leaves of at most 8 bins (celt_pvq.h: og_cwrsi_wide) */
+#endif
 // Register budget: six wavefronts per SIMD (80 VGPRs, which the kernel meets without spilling now that the rotation works in
 // blocks of four coefficients; measured, round 2: 203 us at the compiler's own choice of 110 VGPRs = four per SIMD, 189 us at
 // five, 202 us at six while that took 29 spills; with blocks of four: 157 us at six, 160 us at seven = 72 VGPRs with 4 spills).
+// The launch is as long as the chains of its largest leaves (tools/k1_classes.sh: the two large classes alone 123 us, the two
+// small ones alone 118 us, everything 153-158 us).  Measured without effect on that: s_setprio 3 for the large-class wavefronts
+// (153 us either way: they are not short of issue slots), the next rotation block fetched while the current one is rotated
+// (7 spills at 80 VGPRs: 162 us).  Four table probes per cwrsi step for N <= 8 (OG_K1_SMALL_PROBES): that class alone 74 -> 66 us.
 template <bool DBG>                   // DBG: stage dumps / profiling stamps wanted (the plain instantiation carries none of that code)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void og_pvq_all_kernel(const OgLeafRef *__restrict__ refs, OgPvqClasses cl,
                                                          const OgCeltLeaf *__restrict__ leaves,
@@ -72,7 +79,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         case 0: og_pvq_lane(cur, clf, work, U2, x + tid, 16, dbg_pulses, stamps); break;
         case 1: og_pvq_lane(cur, clf, work, U2, x + tid, 32, dbg_pulses, stamps); break;
         case 2: og_pvq_lane(cur, clf, work, U2, x + (tid >> 6) * (24 * 64) + (tid & 63), 64, dbg_pulses, stamps); break;
-        default: og_pvq_lane(cur, clf, work, U2, x + (tid >> 6) * (8 * 64) + (tid & 63), 64, dbg_pulses, stamps); break;
+        default: og_pvq_lane<OG_K1_SMALL_PROBES>(cur, clf, work, U2, x + (tid >> 6) * (8 * 64) + (tid & 63), 64, dbg_pulses, stamps); break;
         }
         stamps = nullptr;
     }

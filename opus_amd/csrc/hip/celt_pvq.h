@@ -87,6 +87,75 @@ OG_DEV uint32_t og_cwrsi(const uint32_t *U2, int n, int k, uint32_t i, float *x,
     return yy;
 }
 
+// The same walk with P table probes per iteration instead of two, for the leaves whose time goes into the search: N <= 8 bins
+// carry 19 pulses on average at the bench's rate, and with two probes a coefficient of m pulses costs 1 + ceil(m / 2)
+// iterations.  With b = k + 1 (new coefficient) or b = kk (search), the probes are U(n, b), U(n, b-1) .. U(n, b-P+1), clamped at
+// U(n, 0) = 0: a new coefficient takes its sign from the first and is finished in the same iteration if it has fewer than P - 1
+// pulses; a search iteration settles P candidates.  P = 2 is og_cwrsi above, instruction for instruction.
+template <int P>
+OG_DEV uint32_t og_cwrsi_wide(const uint32_t *U2, int n, int k, uint32_t i, float *x, int xs, int logb, int *cm_out, int16_t *dbg)
+{
+    uint32_t yy = 0;
+    int cm = 0, pos = 0, s = 0, k0 = k, kk = k, phase = 0;
+    const int nb = n >> logb, blocks = 1 << logb;
+    int bl = nb, bi = 0;
+#define OG_PUT(v)                                                                                                   \
+    {                                                                                                               \
+        x[pos * xs] = (float)(v);                                                                                   \
+        if (dbg) dbg[pos] = (int16_t)(v);                                                                           \
+        yy += (uint32_t)OG_MUL24((v), (v));                                 /* |v| <= 176 */                        \
+        if (v) cm |= 1 << bi;                                                                                       \
+        pos++;                                                                                                      \
+        if (--bl == 0) { bl = nb; bi++; }                                                                           \
+    }
+    while (n > 2 && k > 0) {
+        const bool p1 = phase != 0;
+        const int b = p1 ? kk : k + 1;
+        int kj[P];
+        uint32_t pr[P];
+#pragma unroll
+        for (int j = 0; j < P; j++) { kj[j] = b - j > 0 ? b - j : 0; pr[j] = og_u2(U2, n, kj[j]); }
+        const int s0 = -(int)(i >= pr[0]);                                      // a new coefficient's sign
+        const uint32_t iref = p1 ? i : i - (pr[0] & (uint32_t)s0);
+        // the first probe at or below the index (for a new coefficient the first probe is the sign's, not a candidate)
+        bool hit = false;
+        int found = 0;
+        uint32_t sub = 0;
+#pragma unroll
+        for (int j = P - 1; j >= 0; j--) {
+            const bool h = pr[j] <= iref && (j > 0 || p1) && (j != 1 || p1 || !s0);
+            hit = hit || h;
+            found = h ? kj[j] : found;
+            sub = h ? pr[j] : sub;
+        }
+        s = p1 ? s : s0;
+        k0 = p1 ? k0 : k;
+        const int val = (k0 - found + s) ^ s;                                   // (used on a hit only)
+        i = iref - (hit ? sub : 0u);
+        k = hit ? found : k;
+        kk = b - P;
+        phase = hit ? 0 : 1;
+        if (hit) { OG_PUT(val) n--; }
+    }
+    for (; n > 2; n--) OG_PUT(0)                                               // every pulse placed: the rest is zeros
+    {
+        uint32_t p = 2 * (uint32_t)k + 1;                                      // n == 2
+        s = -(int)(i >= p);
+        i -= p & (uint32_t)s;
+        k0 = k;
+        k = (int)((i + 1) >> 1);
+        if (k) i -= 2 * (uint32_t)k - 1;
+        int val = (k0 - k + s) ^ s;
+        OG_PUT(val)
+        s = -(int)i;                                                            // n == 1
+        val = (k + s) ^ s;
+        OG_PUT(val)
+    }
+#undef OG_PUT
+    *cm_out = blocks <= 1 ? 1 : cm;
+    return yy;
+}
+
 // RFC 6716 vq.c exp_rotation1 (celt/decoder.rs:676-692).  The reference loops walk x[i], x[i+stride] in place; the
 // `stride` residue classes are independent first-order recurrences, so each runs with its carry in a register
 // (same order within a class; each step's two outputs are one multiply and one fused multiply-add, so the carried value
@@ -195,13 +264,16 @@ OG_DEV void og_exp_rotation(float *x, int xs, int len, int logb, int k, int spre
 #else
 #define OG_PVQ_STAMP(k) {}
 #endif
+template <int P = 2>                  // table probes per cwrsi iteration
 OG_DEV uint32_t og_pvq_leaf(const uint32_t *U2, const OgCeltLeaf &lf, int spread, float *x, int xs, int16_t *dbg,
                             uint64_t *stamps /* profiling aid, may be null */)
 {
     OG_PVQ_STAMP(0)
     const int logb = lf.meta & OG_L_LOGB_MASK;
     int cm;
-    const uint32_t yy = og_cwrsi(U2, lf.n, lf.k, lf.index, x, xs, logb, &cm, dbg);
+    uint32_t yy;
+    if constexpr (P == 2) yy = og_cwrsi(U2, lf.n, lf.k, lf.index, x, xs, logb, &cm, dbg);
+    else yy = og_cwrsi_wide<P>(U2, lf.n, lf.k, lf.index, x, xs, logb, &cm, dbg);
     OG_PVQ_STAMP(1)
     const float g = lf.gain * og_frsq((float)yy);
     for (int i = 0; i < lf.n; i++) x[i * xs] *= g;
@@ -212,6 +284,7 @@ OG_DEV uint32_t og_pvq_leaf(const uint32_t *U2, const OgCeltLeaf &lf, int spread
 
 // K1 body for one lane.  xl = this lane's vector storage (element stride xs), at least lf.n elements.
 // ref.frame carries the frame's `spread` in its top bits (opusgpu_sideinfo.h); lf = leaves[ref.leaf], fetched by the caller.
+template <int P = 2>
 OG_DEV void og_pvq_lane(const OgLeafRef ref, const OgCeltLeaf lf, void *work,
                         const uint32_t *U2, float *xl, int xs, int16_t *dbg_pulses, uint64_t *stamps)
 {
@@ -223,7 +296,7 @@ OG_DEV void og_pvq_lane(const OgLeafRef ref, const OgCeltLeaf lf, void *work,
     if (!zeros) {
         const int spread = (int)(ref.frame >> OG_REF_SPREAD_SHIFT);
         int16_t *dbg = dbg_pulses ? dbg_pulses + (size_t)frame * 1920 + ch * 960 + lf.pos : nullptr;
-        cm = og_pvq_leaf(U2, lf, spread, xl, xs, dbg, stamps);
+        cm = og_pvq_leaf<P>(U2, lf, spread, xl, xs, dbg, stamps);
     }
     // the leaf's n values out, in the widest pieces its place in the row allows: one value to an even place, two to a
     // multiple of four, then fours, then the rest (a wavefront's leaves lie in 64 different rows: a store instruction costs

@@ -27,7 +27,10 @@ extern "C" int emu_launch_celt(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, u
         const uint32_t nref = opusgpu_sort_pvq_leaves(hdr, nframes, leaves, refs.data(), total + 1, classes);
         for (uint32_t r = 0; r < nref; r++) {           // order is irrelevant to the result
             float x[176];
-            og_pvq_lane(refs[r], leaves[refs[r].leaf], work.data(), T.pvq_u2, x, 1, dbg ? dbg->pulses : nullptr, nullptr);
+            if (leaves[refs[r].leaf].n <= 8)             // as the kernel: the smallest size class probes four table entries per step
+                og_pvq_lane<4>(refs[r], leaves[refs[r].leaf], work.data(), T.pvq_u2, x, 1, dbg ? dbg->pulses : nullptr, nullptr);
+            else
+                og_pvq_lane(refs[r], leaves[refs[r].leaf], work.data(), T.pvq_u2, x, 1, dbg ? dbg->pulses : nullptr, nullptr);
         }
     }
     // the band plan in both its forms (three steps / one lane start to end, celt_plan.h): they must agree on everything the
@@ -105,7 +108,7 @@ extern "C" void emu_plan_stats(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, u
 }
 
 // The kernel's cwrsi alone (celt_pvq.h), for known-answer and exhaustive comparisons with the oracle's.
-extern "C" uint32_t emu_cwrsi(int n, int k, uint32_t i, int blocks, int32_t *y, int32_t *cm)
+extern "C" uint32_t emu_cwrsi(int n, int k, uint32_t i, int blocks, int32_t *y, int32_t *cm, int probes)
 {
     static OgCeltTables T;
     static bool init = false;
@@ -115,7 +118,10 @@ extern "C" uint32_t emu_cwrsi(int n, int k, uint32_t i, int blocks, int32_t *y, 
     int m = 0;
     int logb = 0;
     while ((1 << logb) < blocks) logb++;                // blocks is a power of two
-    const uint32_t yy = og_cwrsi(T.pvq_u2, n, k, i, x, 1, logb, &m, p);
+    const uint32_t yy = probes == 2 ? og_cwrsi(T.pvq_u2, n, k, i, x, 1, logb, &m, p)
+                      : probes == 3 ? og_cwrsi_wide<3>(T.pvq_u2, n, k, i, x, 1, logb, &m, p)
+                      : probes == 4 ? og_cwrsi_wide<4>(T.pvq_u2, n, k, i, x, 1, logb, &m, p)
+                                    : og_cwrsi_wide<2>(T.pvq_u2, n, k, i, x, 1, logb, &m, p);     // (22: the wide form at two probes)
     for (int j = 0; j < n; j++) y[j] = p[j];
     *cm = m;
     return yy;

@@ -127,16 +127,17 @@ def test_kernel_cwrsi_kats_and_exhaustive(emu):
     the oracle on every index of small codebooks, and on random indices of large ones (incl. the largest, V < 2^32)"""
     L = orc.lib()
     emu.emu_cwrsi.restype = C.c_uint32
-    emu.emu_cwrsi.argtypes = [C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
+    emu.emu_cwrsi.argtypes = [C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
 
     def both(n, k, i, blocks=1):
-        y, cm = (C.c_int32 * n)(), C.c_int32()
-        norm = emu.emu_cwrsi(n, k, i, blocks, y, C.byref(cm))
         ry = (C.c_int * n)()
         rnorm = L.orc_cwrsi(n, k, i, ry)
-        assert norm == rnorm and list(y) == list(ry), (n, k, i, list(y), list(ry))
-        if blocks > 1:
-            assert cm.value == L.orc_extract_collapse_mask(ry, n, blocks), (n, k, i)
+        for probes in (2, 4, 3, 22):                    # og_cwrsi, and og_cwrsi_wide with 4 (what the kernel runs for N <= 8), 3 and 2 probes
+            y, cm = (C.c_int32 * n)(), C.c_int32()
+            norm = emu.emu_cwrsi(n, k, i, blocks, y, C.byref(cm), probes)
+            assert norm == rnorm and list(y) == list(ry), (probes, n, k, i, list(y), list(ry))
+            if blocks > 1:
+                assert cm.value == L.orc_extract_collapse_mask(ry, n, blocks), (probes, n, k, i)
         return list(y), norm
 
     for kat in orc.kats()["cwrsi"]:
