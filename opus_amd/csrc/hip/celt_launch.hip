@@ -28,6 +28,98 @@ struct OgPvqClasses { uint32_t cnt[4], wg0[4]; };      // leaves per class (larg
 // small ones alone 118 us, everything 153-158 us).  Measured without effect on that: s_setprio 3 for the large-class wavefronts
 // (153 us either way: they are not short of issue slots), the next rotation block fetched while the current one is rotated
 // (7 spills at 80 VGPRs: 162 us).  Four table probes per cwrsi step for N <= 8 (OG_K1_SMALL_PROBES): that class alone 74 -> 66 us.
+// The two large size classes: a wavefront holds L = 16 / 32 leaves and the launch is as long as the chain of its largest leaf
+// (one lane walks up to 176 bins), so the leaf's other NS = 64 / L lanes -- idle during cwrsi, which is serial -- take part in
+// what follows it.  exp_rotation1 with stride s is s independent chains (the residue classes of the position mod s; the
+// backward pass of a class touches that class only), and the blocks of a transient frame are independent as well: the
+// (block, class) pairs are dealt over the leaf's lanes, each chain run start to end by one lane exactly as og_exp_rotation
+// runs it (the same values, bit for bit).  The stride-1 pass of a one-block leaf stays one lane's.  The leaf's values then go
+// out in 16-byte pieces dealt over its lanes.
+template <int NS>
+__device__ void og_coop_rot_pass(float *xl, int xs, int len, int B, int stride, float c, float s, int sub)
+{
+    const int nf = len - stride, nbk = len - 2 * stride;
+    if (nf <= 0) return;
+    const int R = stride < nf ? stride : nf;            // classes with at least one step
+    const int qf = stride == 1 ? nf : og_idiv_small(nf, stride), remf = nf - qf * stride;
+    int qb = 0, remb = 0;
+    if (nbk > 0) { qb = stride == 1 ? nbk : og_idiv_small(nbk, stride); remb = nbk - qb * stride; }
+    int blk = 0, r = sub;
+    while (r >= R && blk < B) { r -= R; blk++; }
+    while (blk < B) {
+        float *xb = xl + blk * len * xs;
+        og_rot_fwd(xb, xs, r, stride, qf + (r < remf), c, s);
+        if (r < nbk) {
+            const int cnt = qb + (r < remb);
+            og_rot_bwd(xb, xs, r + (cnt - 1) * stride, stride, cnt, c, s);
+        }
+        r += NS;
+        while (r >= R && blk < B) { r -= R; blk++; }
+    }
+}
+
+template <int L>
+__device__ __attribute__((noinline)) void og_pvq_coop(const OgLeafRef ref, const OgCeltLeaf lf, bool has, void *work, const uint32_t *U2, float *x, uint32_t tid,
+                            int16_t *dbg_pulses, uint64_t *stamps)
+{
+    constexpr int NS = 64 / L;
+    const int owner = (int)tid & (L - 1), sub = (int)tid / L;
+    float *xl = x + owner;                              // the leaf's vector: x[j * L + owner]
+    const uint32_t frame = ref.frame & OG_REF_FRAME_MASK;
+    const int ch = (lf.meta & OG_L_CH_Y) ? 1 : 0, spread = (int)(ref.frame >> OG_REF_SPREAD_SHIFT);
+    const bool zeros = lf.k == 0;                       // (see og_pvq_lane)
+    uint32_t cm = 0;
+    if (has && !zeros) {
+        int16_t *dbg = dbg_pulses ? dbg_pulses + (size_t)frame * 1920 + ch * 960 + lf.pos : nullptr;
+        cm = og_pvq_leaf<0, false>(U2, lf, spread, xl, L, dbg, stamps);
+    }
+    // the leaf's lanes learn what they need from its first lane
+    const uint32_t w_rot = (has && !zeros) ? (uint32_t)lf.n | (uint32_t)lf.k << 8 | (uint32_t)(lf.meta & OG_L_LOGB_MASK) << 16 | (uint32_t)spread << 20 | 1u << 24 : 0u;
+    const uint32_t w_out = has ? (uint32_t)lf.pos | (uint32_t)ch << 16 | (uint32_t)zeros << 17 | (uint32_t)lf.n << 18 | 1u << 26 : 0u;
+    const uint32_t rot = (uint32_t)__shfl((int)w_rot, owner), out = (uint32_t)__shfl((int)w_out, owner), fr = (uint32_t)__shfl((int)frame, owner);
+    const int len = (int)(rot & 255u), k = (int)((rot >> 8) & 255u), logb = (int)((rot >> 16) & 7u), spr = (int)((rot >> 20) & 3u);
+    const bool active = (rot >> 24) != 0 && !(2 * k >= len || spr == 0);
+    float c = 0.f, s = 0.f;
+    int stride2 = 0;
+    const int B = 1 << logb, ln = len >> logb;
+    if (active) {                                       // og_exp_rotation's parameters
+        const float gain = (float)len * og_frcp((float)(len + (20 - 5 * spr) * k));
+        const float theta = 0.5f * gain * gain;
+        c = og_cos_halfpi(theta);
+        s = og_cos_halfpi(1.f - theta);
+        if (len >= 8 * B) {
+            stride2 = 1;
+            while ((stride2 * stride2 + stride2) * B + (B >> 2) < len) stride2++;
+        }
+    }
+    __syncthreads();                                    // (one wavefront: orders its LDS traffic; the first lanes' vectors are written)
+    if (active && stride2) og_coop_rot_pass<NS>(xl, L, ln, B, stride2, s, c, sub);
+    __syncthreads();
+    if (active) og_coop_rot_pass<NS>(xl, L, ln, B, 1, c, s, sub);
+    __syncthreads();
+    if (out >> 26) {
+        const int pos = (int)(out & 0xFFFFu), n = (int)((out >> 18) & 255u);
+        const bool zr = ((out >> 17) & 1u) != 0;
+        float *dst = og_work_coef(work, fr) + ((out >> 16) & 1u) * 960 + pos;
+#define OG_XV(j) (zr ? 0.f : xl[(j) * L])
+        int head = (4 - (pos & 3)) & 3;                 // values in front of the first 16-byte boundary of the row
+        if (head > n) head = n;
+        const int body = (n - head) >> 2, tail = (n - head) & 3;
+        if (sub == 0) {
+            for (int i = 0; i < head; i++) dst[i] = OG_XV(i);
+            for (int i = head + 4 * body; i < n; i++) dst[i] = OG_XV(i);
+        }
+        for (int q = sub; q < body; q += NS) {
+            const int i = head + 4 * q;
+            *(OgF4s *)(dst + i) = OgF4s{OG_XV(i), OG_XV(i + 1), OG_XV(i + 2), OG_XV(i + 3)};
+        }
+        (void)tail;
+#undef OG_XV
+    }
+    if (has && !zeros) OG_ATOMIC_OR(og_work_cm(work, frame) + ch * 24 + lf.band, cm);
+    if (stamps) stamps[3] = (uint64_t)__builtin_readcyclecounter();
+}
+
 template <bool DBG>                   // DBG: stage dumps / profiling stamps wanted (the plain instantiation carries none of that code)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void og_pvq_all_kernel(const OgLeafRef *__restrict__ refs, OgPvqClasses cl,
                                                          const OgCeltLeaf *__restrict__ leaves,
@@ -68,6 +160,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         for (uint32_t p = tid; p < (15 * OG_U2_STRIDE + 1) / 4; p += 64 * nw) ((uint4 *)U2)[p] = src[p];
     }
     __syncthreads();                                    // wavefronts that have ended no longer take part in the barrier
+    if (c <= 1 && OG_K1_BATCHES(c) == 1u) {             // the large classes: one wavefront, every lane stays (og_pvq_coop)
+        uint64_t *st0 = dbg_cycles && tid == 0 && (b - cl.wg0[c]) < 4096 ? dbg_cycles + (size_t)nframes * 64 + ((size_t)(c == 0 ? 176 : 64) * 4096 + (b - cl.wg0[c])) * 4 : nullptr;
+        if (c == 0) og_pvq_coop<16>(ref, lf, live && g < cnt, work, U2, x, tid, dbg_pulses, st0);
+        else og_pvq_coop<32>(ref, lf, live && g < cnt, work, U2, x, tid, dbg_pulses, st0);
+        return;
+    }
     if (!live) return;
     const int nmax = c == 0 ? 176 : c == 1 ? 64 : c == 2 ? 24 : 8;
     uint64_t *stamps = dbg_cycles && tid == 0 && (b - cl.wg0[c]) < 4096 ? dbg_cycles + (size_t)nframes * 64 + ((size_t)nmax * 4096 + (b - cl.wg0[c])) * 4 : nullptr;
@@ -76,8 +174,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         const OgCeltLeaf clf = lf;
         if (r + 1 < nbat && g + lanes < cnt) { ref = refs[base + g + lanes]; lf = leaves[ref.leaf]; }     // in flight during this batch
         switch (c) {
-        case 0: og_pvq_lane(cur, clf, work, U2, x + tid, 16, dbg_pulses, stamps); break;
-        case 1: og_pvq_lane(cur, clf, work, U2, x + tid, 32, dbg_pulses, stamps); break;
+        case 0: og_pvq_lane<0>(cur, clf, work, U2, x + tid, 16, dbg_pulses, stamps); break;      // (0: the walk for sparse leaves)
+        case 1: og_pvq_lane<0>(cur, clf, work, U2, x + tid, 32, dbg_pulses, stamps); break;
         case 2: og_pvq_lane(cur, clf, work, U2, x + (tid >> 6) * (24 * 64) + (tid & 63), 64, dbg_pulses, stamps); break;
         default: og_pvq_lane<OG_K1_SMALL_PROBES>(cur, clf, work, U2, x + (tid >> 6) * (8 * 64) + (tid & 63), 64, dbg_pulses, stamps); break;
         }

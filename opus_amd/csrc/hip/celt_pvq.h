@@ -87,6 +87,71 @@ OG_DEV uint32_t og_cwrsi(const uint32_t *U2, int n, int k, uint32_t i, float *x,
     return yy;
 }
 
+// The same walk for the leaves that are mostly zeros (N > 24 bins carry 3-4 pulses on average at the bench's rate, and a lane
+// walks up to 176 positions one iteration each: the longest chain of the whole launch): a new coefficient that is zero looks at
+// the next position in the same iteration -- the probes U(n-1, k), U(n-1, k+1) do not depend on the first pair -- and two zeros
+// are finished per iteration.  Everything else is og_cwrsi.
+OG_DEV uint32_t og_cwrsi_sparse(const uint32_t *U2, int n, int k, uint32_t i, float *x, int xs, int logb, int *cm_out, int16_t *dbg)
+{
+    uint32_t yy = 0;
+    int cm = 0, pos = 0, s = 0, k0 = k, kk = k, phase = 0;
+    const int nb = n >> logb, blocks = 1 << logb;
+    int bl = nb, bi = 0;
+#define OG_PUT(v)                                                                                                   \
+    {                                                                                                               \
+        x[pos * xs] = (float)(v);                                                                                   \
+        if (dbg) dbg[pos] = (int16_t)(v);                                                                           \
+        yy += (uint32_t)OG_MUL24((v), (v));                                 /* |v| <= 176 */                        \
+        if (v) cm |= 1 << bi;                                                                                       \
+        pos++;                                                                                                      \
+        if (--bl == 0) { bl = nb; bi++; }                                                                           \
+    }
+    while (n > 2 && k > 0) {
+        const int kb = phase ? (kk > 0 ? kk - 1 : 0) : kk + 1;
+        const uint32_t pA = og_u2(U2, n, kk), pB = og_u2(U2, n, kb);
+        const uint32_t pC = og_u2(U2, n - 1, k), pD = og_u2(U2, n - 1, k + 1);  // the next position's pair (used by a new coefficient only: kk == k there)
+        // phase 0 (new coefficient)
+        const int s0 = -(int)(i >= pB);
+        const uint32_t i0 = i - (pB & (uint32_t)s0);
+        const bool zero0 = !s0 && pA <= i0;                                     // this coefficient is zero
+        const uint32_t iz = i0 - pA;                                            // ... and the index the next one starts from
+        const bool p1 = phase != 0;
+        const bool zero1 = !p1 && zero0 && n > 3 && iz < pD && pC <= iz;        // the next one is zero as well
+        // phase 1 (search)
+        const bool atA = pA <= i, atB = pB <= i, hit1 = atA || atB;
+        const int found1 = atA ? kk : kk - 1;
+        const uint32_t i1 = i - (atA ? pA : pB);
+        // the step taken
+        const bool emit = p1 ? hit1 : zero0;
+        s = p1 ? s : s0;
+        k0 = p1 ? k0 : k;
+        const int val = (p1 && hit1) ? ((k0 - found1 + s) ^ s) : 0;
+        i = p1 ? (hit1 ? i1 : i) : (zero0 ? (zero1 ? iz - pC : iz) : i0);
+        k = (p1 && hit1) ? found1 : k;
+        kk = p1 ? (hit1 ? found1 : kk - 2) : (zero0 ? kk : k - 1);
+        phase = p1 ? (hit1 ? 0 : 1) : (zero0 ? 0 : 1);
+        if (emit) { OG_PUT(val) n--; }
+        if (zero1) { OG_PUT(0) n--; }
+    }
+    for (; n > 2; n--) OG_PUT(0)                                               // every pulse placed: the rest is zeros
+    {
+        uint32_t p = 2 * (uint32_t)k + 1;                                      // n == 2
+        s = -(int)(i >= p);
+        i -= p & (uint32_t)s;
+        k0 = k;
+        k = (int)((i + 1) >> 1);
+        if (k) i -= 2 * (uint32_t)k - 1;
+        int val = (k0 - k + s) ^ s;
+        OG_PUT(val)
+        s = -(int)i;                                                            // n == 1
+        val = (k + s) ^ s;
+        OG_PUT(val)
+    }
+#undef OG_PUT
+    *cm_out = blocks <= 1 ? 1 : cm;
+    return yy;
+}
+
 // The same walk with P table probes per iteration instead of two, for the leaves whose time goes into the search: N <= 8 bins
 // carry 19 pulses on average at the bench's rate, and with two probes a coefficient of m pulses costs 1 + ceil(m / 2)
 // iterations.  With b = k + 1 (new coefficient) or b = kk (search), the probes are U(n, b), U(n, b-1) .. U(n, b-P+1), clamped at
@@ -264,7 +329,7 @@ OG_DEV void og_exp_rotation(float *x, int xs, int len, int logb, int k, int spre
 #else
 #define OG_PVQ_STAMP(k) {}
 #endif
-template <int P = 2>                  // table probes per cwrsi iteration
+template <int P = 2, bool ROT = true>  // P: table probes per cwrsi iteration; 0: the form for sparse leaves (og_cwrsi_sparse).  ROT: rotate here
 OG_DEV uint32_t og_pvq_leaf(const uint32_t *U2, const OgCeltLeaf &lf, int spread, float *x, int xs, int16_t *dbg,
                             uint64_t *stamps /* profiling aid, may be null */)
 {
@@ -273,12 +338,13 @@ OG_DEV uint32_t og_pvq_leaf(const uint32_t *U2, const OgCeltLeaf &lf, int spread
     int cm;
     uint32_t yy;
     if constexpr (P == 2) yy = og_cwrsi(U2, lf.n, lf.k, lf.index, x, xs, logb, &cm, dbg);
+    else if constexpr (P == 0) yy = og_cwrsi_sparse(U2, lf.n, lf.k, lf.index, x, xs, logb, &cm, dbg);
     else yy = og_cwrsi_wide<P>(U2, lf.n, lf.k, lf.index, x, xs, logb, &cm, dbg);
     OG_PVQ_STAMP(1)
     const float g = lf.gain * og_frsq((float)yy);
     for (int i = 0; i < lf.n; i++) x[i * xs] *= g;
     OG_PVQ_STAMP(2)
-    og_exp_rotation(x, xs, lf.n, logb, lf.k, spread);
+    if constexpr (ROT) og_exp_rotation(x, xs, lf.n, logb, lf.k, spread);
     return (uint32_t)cm << lf.cmshift;
 }
 

@@ -27,7 +27,9 @@ extern "C" int emu_launch_celt(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, u
         const uint32_t nref = opusgpu_sort_pvq_leaves(hdr, nframes, leaves, refs.data(), total + 1, classes);
         for (uint32_t r = 0; r < nref; r++) {           // order is irrelevant to the result
             float x[176];
-            if (leaves[refs[r].leaf].n <= 8)             // as the kernel: the smallest size class probes four table entries per step
+            if (leaves[refs[r].leaf].n > 24)             // as the kernel: the two large size classes take two zeros per step,
+                og_pvq_lane<0>(refs[r], leaves[refs[r].leaf], work.data(), T.pvq_u2, x, 1, dbg ? dbg->pulses : nullptr, nullptr);
+            else if (leaves[refs[r].leaf].n <= 8)        // the smallest one probes four table entries per step
                 og_pvq_lane<4>(refs[r], leaves[refs[r].leaf], work.data(), T.pvq_u2, x, 1, dbg ? dbg->pulses : nullptr, nullptr);
             else
                 og_pvq_lane(refs[r], leaves[refs[r].leaf], work.data(), T.pvq_u2, x, 1, dbg ? dbg->pulses : nullptr, nullptr);
@@ -118,7 +120,8 @@ extern "C" uint32_t emu_cwrsi(int n, int k, uint32_t i, int blocks, int32_t *y, 
     int m = 0;
     int logb = 0;
     while ((1 << logb) < blocks) logb++;                // blocks is a power of two
-    const uint32_t yy = probes == 2 ? og_cwrsi(T.pvq_u2, n, k, i, x, 1, logb, &m, p)
+    const uint32_t yy = probes == 0 ? og_cwrsi_sparse(T.pvq_u2, n, k, i, x, 1, logb, &m, p)
+                      : probes == 2 ? og_cwrsi(T.pvq_u2, n, k, i, x, 1, logb, &m, p)
                       : probes == 3 ? og_cwrsi_wide<3>(T.pvq_u2, n, k, i, x, 1, logb, &m, p)
                       : probes == 4 ? og_cwrsi_wide<4>(T.pvq_u2, n, k, i, x, 1, logb, &m, p)
                                     : og_cwrsi_wide<2>(T.pvq_u2, n, k, i, x, 1, logb, &m, p);     // (22: the wide form at two probes)

@@ -132,7 +132,7 @@ def test_kernel_cwrsi_kats_and_exhaustive(emu):
     def both(n, k, i, blocks=1):
         ry = (C.c_int * n)()
         rnorm = L.orc_cwrsi(n, k, i, ry)
-        for probes in (2, 4, 3, 22):                    # og_cwrsi, and og_cwrsi_wide with 4 (what the kernel runs for N <= 8), 3 and 2 probes
+        for probes in (2, 4, 0, 3, 22):                 # og_cwrsi; og_cwrsi_wide<4> (the kernel's for N <= 8); og_cwrsi_sparse (N > 24); wide<3>, wide<2>
             y, cm = (C.c_int32 * n)(), C.c_int32()
             norm = emu.emu_cwrsi(n, k, i, blocks, y, C.byref(cm), probes)
             assert norm == rnorm and list(y) == list(ry), (probes, n, k, i, list(y), list(ry))
