@@ -91,8 +91,10 @@ enum { OG_X_NONE = 0, OG_X_RED_HEAD = 1, OG_X_AFTER_RED_HEAD = 2, OG_X_RED_TAIL 
 #define OG_X_SHIFT 4
 #define OG_ROUND_SHIFT 6
 /* launch rounds of one Opus frame: its SILK frames (up to three 20 ms pieces) take rounds 0-2, each round's CELT records run
- * after its SILK frames: 0 = redundant frame in front / overlap flush, 2 = the frame's own CELT part, 3 = redundant frame behind */
-enum { OG_ROUND_HEAD = 0, OG_ROUND_MAIN = 2, OG_ROUND_TAIL = 3, OG_ROUNDS_PER_FRAME = 4 };
+ * after its SILK frames: 0 = redundant frame in front / overlap flush, 1 = the overlap flush when a redundant frame took round 0
+ * (never two records of one stream in one round: they would race on its state), 2 = the frame's own CELT part, 3 = redundant
+ * frame behind */
+enum { OG_ROUND_HEAD = 0, OG_ROUND_FLUSH = 1, OG_ROUND_MAIN = 2, OG_ROUND_TAIL = 3, OG_ROUNDS_PER_FRAME = 4 };
 
 typedef struct {             /* one PVQ leaf (K > 0) to expand: the unit of work of the K1 kernel */
     uint32_t leaf;           /* index into the launch's leaf array */

@@ -33,6 +33,7 @@ extern "C" int opusgpu_opus_head_parse(const uint8_t *e, size_t len, OgOpusHead 
         out->mapping[1] = 1;
         return OPUSGPU_OK;
     }
+    if (out->mapping_family == 1 && out->channels > 8) return OPUSGPU_CONFIG_INVALID;   // RFC 7845 5.1.1.2: Vorbis order, 1..8 channels
     if (len < size_t(21) + out->channels) return OPUSGPU_CONFIG_INCOMPLETE;   // decoder.rs:151-157, :167
     out->stream_count = e[19];
     out->coupled_count = e[20];

@@ -5,7 +5,11 @@
 // synthesis state in HBM, pinned side-info staging and one HIP stream.  batch_send is the host half of
 // Dec::send_packet (decoder.rs:48-127), batch_decode the device half.
 #include <hip/hip_runtime_api.h>
+#include <pthread.h>
+#include <sched.h>
 #include <algorithm>
+#include <cctype>
+#include <string>
 #include <chrono>
 #include <cstdio>
 #include <cmath>
@@ -30,14 +34,20 @@ template <class T>
 struct DeviceBuf {                       // grow-only device array
     T *p = nullptr;
     size_t cap = 0;
-    int reserve(size_t n)
+    // Kernels of the previous decode (asynchronous) may still be reading the old block: it is freed only after `stream`
+    // has drained (the contents are not carried over: every user refills the array before it launches).
+    int reserve(size_t n, hipStream_t stream)
     {
         if (n <= cap) return OPUSGPU_OK;
         size_t want = std::max(n, cap * 2);
-        if (p) OG_HIP(hipFree(p));
-        p = nullptr; cap = 0;
-        OG_HIP(hipMalloc((void **)&p, want * sizeof(T)));
-        cap = want;
+        T *q = nullptr;
+        OG_HIP(hipMalloc((void **)&q, want * sizeof(T)));
+        if (p) {
+            hipError_t e = hipStreamSynchronize(stream);
+            if (e == hipSuccess) e = hipFree(p);
+            if (e != hipSuccess) { (void)hipFree(q); return og::device_fail(e, "DeviceBuf::reserve"); }
+        }
+        p = q; cap = want;
         return OPUSGPU_OK;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
@@ -80,12 +90,55 @@ struct Worker {
 
 // Parse threads of a batch: started once, parked on a condition variable between batch_send calls (a send of 4096 packets
 // is ~5 ms of parsing on 16 threads: creating and joining the threads every call showed up next to it).
+// CPUs local to the GPU (a rank's parse threads stay on its GPU's NUMA node, so that eight ranks on one host do
+// not drag each other's side-info across sockets): the PCI device's local_cpulist from sysfs, cut to what the process may
+// run on.  Empty (no pinning) when anything is missing or OPUSGPU_PIN=0.
+static std::vector<int> gpu_local_cpus(int device)
+{
+    std::vector<int> cpus;
+    if (const char *e = std::getenv("OPUSGPU_PIN")) if (e[0] == '0') return cpus;
+    char bdf[32] = {0};
+    if (hipDeviceGetPCIBusId(bdf, sizeof bdf, device) != hipSuccess) return cpus;
+    for (char *c = bdf; *c; c++) *c = char(std::tolower(*c));
+    const std::string path = std::string("/sys/bus/pci/devices/") + bdf + "/local_cpulist";
+    std::FILE *f = std::fopen(path.c_str(), "r");
+    if (!f) return cpus;
+    char line[4096] = {0};
+    const bool got = std::fgets(line, sizeof line, f) != nullptr;
+    std::fclose(f);
+    if (!got) return cpus;
+    cpu_set_t allowed;
+    CPU_ZERO(&allowed);
+    if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return cpus;
+    for (const char *q = line; *q && *q != '\n';) {       // "0-47,96-143"
+        char *end = nullptr;
+        long a = std::strtol(q, &end, 10), z = a;
+        if (end == q) break;
+        if (*end == '-') { const char *r = end + 1; z = std::strtol(r, &end, 10); if (end == r) break; }
+        for (long c = a; c <= z && c < CPU_SETSIZE; c++) if (c >= 0 && CPU_ISSET(int(c), &allowed)) cpus.push_back(int(c));
+        q = *end == ',' ? end + 1 : end;
+        if (*end != ',' ) break;
+    }
+    return cpus;
+}
+
 class ParsePool {
 public:
-    explicit ParsePool(int n) : n_(n)
+    ParsePool(int n, int device) : n_(n)
     {
-        for (int w = 1; w < n_; w++) threads_.emplace_back([this, w] { loop(w); });
+        const std::vector<int> cpus = gpu_local_cpus(device);
+        for (int w = 1; w < n_; w++) {
+            threads_.emplace_back([this, w] { loop(w); });
+            if (!cpus.empty()) {                             // anywhere on the GPU's node: the scheduler places them inside it
+                cpu_set_t set;
+                CPU_ZERO(&set);
+                for (int c : cpus) CPU_SET(c, &set);
+                (void)pthread_setaffinity_np(threads_.back().native_handle(), sizeof set, &set);
+            }
+        }
+        pinned_ = int(cpus.size());
     }
+    int pinned_cpus() const { return pinned_; }
     ~ParsePool()
     {
         { std::lock_guard<std::mutex> lk(mu_); stop_ = true; gen_++; }
@@ -125,7 +178,7 @@ private:
             }
         }
     }
-    int n_, nw_ = 0, left_ = 0;
+    int n_, nw_ = 0, left_ = 0, pinned_ = 0;
     bool stop_ = false;
     uint64_t gen_ = 0;
     const std::function<void(int)> *job_ = nullptr;
@@ -346,7 +399,7 @@ static int batch_send_impl(opusgpu_batch *b, const uint8_t *const *pkts, const u
     const auto t_begin = now();
 
     // ---- parse: static partition of the streams over the workers, one stream per task
-    if (!b->pool) b->pool.reset(new ParsePool(worker_count()));
+    if (!b->pool) b->pool.reset(new ParsePool(worker_count(), b->device));
     const int nw = std::max(1, std::min<int>(b->pool->size(), int(n)));
     std::vector<Worker> &workers = b->workers;
     std::vector<ParsedPacket> &parsed = b->parsed;
@@ -368,13 +421,27 @@ static int batch_send_impl(opusgpu_batch *b, const uint8_t *const *pkts, const u
                 if (pp.rc < 0) {                        // a bad packet never poisons the batch
                     W.celt.resize(pp.celt0); W.leaves.resize(pp.leaf0); W.silk.resize(pp.silk0);
                 } else {
+                    // a round holds at most one CELT record of a stream: two would read-modify-write its state side by side
+                    bool clash = false;
+                    for (int f = 0; f < pp.rc && !clash; f++) {
+                        uint32_t used = 0;
+                        for (uint32_t c = 0; c < pp.fi[f].has_celt; c++) {
+                            const uint32_t bit = 1u << (W.celt[pp.fi[f].celt_index + c].spread >> OG_ROUND_SHIFT);
+                            clash = clash || (used & bit);
+                            used |= bit;
+                        }
+                    }
+                    if (clash) {
+                        pp.rc = OPUSGPU_INVALID_DATA;
+                        W.celt.resize(pp.celt0); W.leaves.resize(pp.leaf0); W.silk.resize(pp.silk0);
+                    }
                     for (int f = 0; f < pp.rc; f++) {       // the rounds its records will run in (see the merge below)
                         const uint32_t r0 = OG_ROUNDS_PER_FRAME * (frames_before + uint32_t(f));
                         W.reach(r0 + OG_ROUNDS_PER_FRAME);
                         for (uint32_t c = 0; c < pp.fi[f].has_celt; c++) W.ccount[r0 + (W.celt[pp.fi[f].celt_index + c].spread >> OG_ROUND_SHIFT)]++;
                         for (uint32_t k = 0; k < pp.fi[f].nsilk; k++) W.scount[r0 + k]++;
                     }
-                    frames_before += uint32_t(pp.rc);
+                    if (pp.rc > 0) frames_before += uint32_t(pp.rc);
                 }
                 pp.ncelt = W.celt.size() - pp.celt0; pp.nleaf = W.leaves.size() - pp.leaf0; pp.nsilk = W.silk.size() - pp.silk0;
             }
@@ -543,13 +610,12 @@ int opusgpu_batch_decode(opusgpu_batch *b)
     if (!b->pending) return OPUSGPU_OK;
     OG_HIP(hipSetDevice(b->device));
     int rc;
-    if ((rc = b->d_celt.reserve(b->h_celt.n + 1)) || (rc = b->d_leaves.reserve(b->h_leaves.n + 1)) ||
-        (rc = b->d_silk.reserve(b->h_silk.n + 1)))
+    if ((rc = b->d_celt.reserve(b->h_celt.n + 1, b->stream)) || (rc = b->d_leaves.reserve(b->h_leaves.n + 1, b->stream)) ||
+        (rc = b->d_silk.reserve(b->h_silk.n + 1, b->stream)) || (rc = b->d_refs.reserve(b->h_refs.n + 1, b->stream)))
         return rc;
     if (b->h_celt.n) OG_HIP(hipMemcpyAsync(b->d_celt.p, b->h_celt.p, b->h_celt.n * sizeof(OgCeltHdr), hipMemcpyHostToDevice, b->stream));
     if (b->h_leaves.n) OG_HIP(hipMemcpyAsync(b->d_leaves.p, b->h_leaves.p, b->h_leaves.n * sizeof(OgCeltLeaf), hipMemcpyHostToDevice, b->stream));
     if (b->h_silk.n) OG_HIP(hipMemcpyAsync(b->d_silk.p, b->h_silk.p, b->h_silk.n * sizeof(OgSilkFrame), hipMemcpyHostToDevice, b->stream));
-    if ((rc = b->d_refs.reserve(b->h_refs.n + 1))) return rc;
     if (b->h_refs.n) OG_HIP(hipMemcpyAsync(b->d_refs.p, b->h_refs.p, b->h_refs.n * sizeof(OgLeafRef), hipMemcpyHostToDevice, b->stream));
     OG_HIP(hipEventRecord(b->h2d_done, b->stream));
     b->h2d_in_flight = true;
@@ -557,7 +623,7 @@ int opusgpu_batch_decode(opusgpu_batch *b)
         uint32_t maxc = 0;
         for (size_t r = 0; r + 1 < b->celt_round_off.size(); r++) maxc = std::max(maxc, b->celt_round_off[r + 1] - b->celt_round_off[r]);
         const size_t need = opusgpu_celt_work_bytes(maxc), had = b->d_work.cap;
-        if ((rc = b->d_work.reserve(need))) return rc;
+        if ((rc = b->d_work.reserve(need, b->stream))) return rc;
         if (b->d_work.cap != had) OG_HIP(hipMemsetAsync(b->d_work.p, 0, b->d_work.cap, b->stream));   // zero once per (re)allocation
     }
     const size_t rounds = b->celt_round_off.empty() ? 0 : b->celt_round_off.size() - 1;
@@ -644,6 +710,7 @@ struct opusgpu_decoder {
     // by any mono decoder); output channel c is channel `mapping[c]` of the decoded set -- 2s, 2s+1 for coupled stream s,
     // then one per mono stream -- or silence for 255
     uint32_t streams = 1, coupled = 0;
+    bool multi = false;                 // decode through the mapping table (false: family 0's implicit mono / stereo layout)
     std::vector<uint8_t> mapping;
     opusgpu_batch *batch_mono = nullptr;
     ~opusgpu_decoder() { delete batch; delete batch_mono; }
@@ -699,7 +766,11 @@ int opusgpu_decoder_configure(opusgpu_decoder *d)
     if (e.empty()) { d->streams = 1; d->coupled = 1; d->mapping = {0, 1}; }
     delete d->batch_mono;
     d->batch_mono = nullptr;
-    const bool multi = d->streams > 1 || channels > 2;
+    // the plain path is mapping family 0's implicit layout (one stream; mono, or one coupled pair in order); anything else --
+    // family 1 / 255 with one stream and a mapping of its own included -- goes through the mapping table
+    d->multi = !(d->streams == 1 && channels <= 2 && d->coupled == uint32_t(channels - 1) && d->mapping[0] == 0 &&
+                 (channels == 1 || d->mapping[1] == 1));
+    const bool multi = d->multi;
     int rc = OPUSGPU_OK;
     if (!multi) rc = opusgpu_batch_create(&d->batch, 1, channels, d->device);
     else {
@@ -739,7 +810,27 @@ static int send_multistream(opusgpu_decoder *d, const uint8_t *pkt, size_t len, 
     int rc = OPUSGPU_OK;
     if (M && (rc = opusgpu_batch_send(d->batch, pk.data(), ln.data(), nullptr, M, err.data()))) return rc;
     if (S > M && (rc = opusgpu_batch_send(d->batch_mono, pk.data() + M, ln.data() + M, nullptr, S - M, err.data() + M))) return rc;
-    for (uint32_t s = 0; s < S; s++) if (err[s]) return err[s];
+    int bad = OPUSGPU_OK;
+    for (uint32_t s = 0; s < S && !bad; s++) bad = err[s];
+    if (bad) {
+        // One stream's packet did not parse: the streams that did have advanced their host state, so they are decoded (their
+        // device state follows) and the bad ones conceal -- host and device stay in step on every stream; the caller gets the
+        // error and no frame for this packet.
+        std::fill(ln.begin(), ln.end(), 0u);
+        std::vector<uint32_t> ids;
+        for (int half = 0; half < 2; half++) {
+            opusgpu_batch *bt = half ? d->batch_mono : d->batch;
+            const uint32_t lo = half ? M : 0, hi = half ? S : M;
+            if (!bt || hi == lo) continue;
+            (void)opusgpu_batch_decode(bt);
+            ids.clear();
+            for (uint32_t s = lo; s < hi; s++) if (err[s]) ids.push_back(s - lo);
+            if (ids.empty()) continue;
+            std::vector<int32_t> e2(ids.size(), 0);
+            if (opusgpu_batch_send(bt, pk.data(), ln.data(), ids.data(), uint32_t(ids.size()), e2.data()) == OPUSGPU_OK) (void)opusgpu_batch_decode(bt);
+        }
+        return bad;
+    }
     if (M && (rc = opusgpu_batch_decode(d->batch))) return rc;             // both batches' kernels are in flight before the first read
     if (S > M && (rc = opusgpu_batch_decode(d->batch_mono))) return rc;
     std::vector<float> dec(size_t(OPUSGPU_MAX_FRAME) * 2);
@@ -770,7 +861,7 @@ int opusgpu_decoder_send_packet(opusgpu_decoder *d, const uint8_t *pkt, size_t l
     std::vector<float> out;
     size_t n = 0;
     int rc;
-    if (d->streams > 1 || d->channels > 2) {
+    if (d->multi) {
         if ((rc = send_multistream(d, pkt, len, out, &n))) return rc;
     } else {
         const uint8_t *pk[1] = {pkt};
@@ -812,8 +903,10 @@ int opusgpu_decoder_flush(opusgpu_decoder *d)
     if (!d) return OPUSGPU_BAD_ARG;
     d->queue.clear();
     d->skip_left = d->pre_skip;
-    if (d->batch) return opusgpu_batch_flush(d->batch, 0);
-    return OPUSGPU_OK;
+    int rc = OPUSGPU_OK;                                // every stream of both batches (multistream: coupled, then mono)
+    for (opusgpu_batch *bt : {d->batch, d->batch_mono})
+        for (uint32_t s = 0; bt && s < bt->nstreams && !rc; s++) rc = opusgpu_batch_flush(bt, s);
+    return rc;
 }
 
 }  // extern "C"

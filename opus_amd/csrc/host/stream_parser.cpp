@@ -116,7 +116,7 @@ int StreamParser::parse(const uint8_t *pkt, size_t len, OgFrameInfo *frames, std
         if (redundancy && celt_to_silk) {
             RangeDec r2(rdata, uint32_t(rbytes));
             celt.emplace_back();
-            (void)celt_parse_frame(celt_, r2, 240, 0, p.celt_end_band(), p.stereo + 1, &celt.back(), leaves);
+            if (celt_parse_frame(celt_, r2, 240, 0, p.celt_end_band(), p.stereo + 1, &celt.back(), leaves) < 0) return OPUSGPU_INVALID_DATA;
             tag(celt.back(), OG_X_RED_HEAD, OG_ROUND_HEAD);
             red_range = r2.rng();
             fi.has_celt++;
@@ -127,7 +127,7 @@ int StreamParser::parse(const uint8_t *pkt, size_t len, OgFrameInfo *frames, std
         if (p.mode != MODE_SILK && N <= 960) {                              // decoder.rs:117-123
             const int start = p.mode == MODE_HYBRID ? 17 : 0;
             celt.emplace_back();
-            (void)celt_parse_frame(celt_, rd, N, start, p.celt_end_band(), p.stereo + 1, &celt.back(), leaves);
+            if (celt_parse_frame(celt_, rd, N, start, p.celt_end_band(), p.stereo + 1, &celt.back(), leaves) < 0) return OPUSGPU_INVALID_DATA;
             if (p.mode == MODE_HYBRID) celt.back().flags |= OG_F_ACCUM;
             tag(celt.back(), redundancy && celt_to_silk ? OG_X_AFTER_RED_HEAD : OG_X_NONE, OG_ROUND_MAIN);
             fi.has_celt++;
@@ -136,9 +136,13 @@ int StreamParser::parse(const uint8_t *pkt, size_t len, OgFrameInfo *frames, std
             static const uint8_t kSilence[2] = {0xFF, 0xFF};
             RangeDec r3(kSilence, 2);
             celt.emplace_back();
-            (void)celt_parse_frame(celt_, r3, 120, 0, p.celt_end_band(), p.stereo + 1, &celt.back(), leaves);
+            (void)celt_parse_frame(celt_, r3, 120, 0, p.celt_end_band(), p.stereo + 1, &celt.back(), leaves);     // (a silent frame: cannot fail)
             celt.back().flags |= OG_F_ACCUM;
-            tag(celt.back(), OG_X_NONE, OG_ROUND_HEAD);
+            // One record per stream per round (the tail kernel reads and writes the stream's state): behind a redundant frame in
+            // front (round HEAD) the flush takes the round after it and stores no PCM -- its 2.5 ms are the redundant frame's
+            // (orc_opus.c: the flush is added, then overwritten); the CELT state runs redundant frame -> flush, as in the oracle.
+            if (redundancy && celt_to_silk) tag(celt.back(), OG_X_RED_TAIL /* a 120-sample record of this kind stores nothing */, OG_ROUND_FLUSH);
+            else tag(celt.back(), OG_X_NONE, OG_ROUND_HEAD);
             fi.has_celt++;
         }
         if (redundancy && !celt_to_silk) {
@@ -146,7 +150,7 @@ int StreamParser::parse(const uint8_t *pkt, size_t len, OgFrameInfo *frames, std
             RangeDec r2(rdata, uint32_t(rbytes));
             celt_.reset();
             celt.emplace_back();
-            (void)celt_parse_frame(celt_, r2, 240, 0, p.celt_end_band(), p.stereo + 1, &celt.back(), leaves);
+            if (celt_parse_frame(celt_, r2, 240, 0, p.celt_end_band(), p.stereo + 1, &celt.back(), leaves) < 0) return OPUSGPU_INVALID_DATA;
             celt.back().pcm_off = uint32_t(N - 240);
             tag(celt.back(), OG_X_RED_TAIL, OG_ROUND_TAIL);
             red_range = r2.rng();

@@ -101,6 +101,26 @@ def test_emu_hybrid_and_mode_switching(emu, vid, n):
         check_pcm(ref.decode(p), d.decode(p), f"vector {vid} packet {i}")
 
 
+def crafted_hybrid_to_silk_with_redundant_head():
+    """Packets of vector 12 in an order of our own: three hybrid packets, then a SILK packet that opens with a CELT -> SILK
+    redundant frame -- a hybrid -> SILK switch WITH a redundant frame in front, which none of the 12 vectors holds: the
+    overlap flush then follows the redundant frame in a round of its own and stores no PCM (stream_parser.cpp)."""
+    _, pk = orc.load_vectors(ids=[12])[12]
+    return [pk[386], pk[387], pk[388], pk[137], pk[138], pk[139]]
+
+
+def test_emu_hybrid_to_silk_flush_behind_redundant_head(emu):
+    seq = crafted_hybrid_to_silk_with_redundant_head()
+    d, ref = EmuDecoder(emu, 2), orc.Decoder(2)
+    for i, p in enumerate(seq):
+        out, r = d.decode(p), ref.decode(p)
+        if i == 3:                                      # one record per round: redundant frame in 0, mute flush in 1
+            fi = d.hp.fi[0]
+            tags = [(d.hp.celt[fi.celt_index + c].spread >> 6, (d.hp.celt[fi.celt_index + c].spread >> 4) & 3) for c in range(fi.has_celt)]
+            assert tags == [(0, 1), (1, 3)], tags
+        check_pcm(r, out, f"crafted packet {i}")
+
+
 def test_lbrr_packets_decode(emu):
     """silk/decoder.rs:2070-2072 stops at an LBRR flag with Error::Unsupported; here the LBRR frames are read past (RFC 6716
     4.2.4-4.2.7, tests/test_lbrr.py): a packet whose LBRR flag is set decodes, and the same in the oracle"""

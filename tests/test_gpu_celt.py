@@ -176,6 +176,26 @@ def test_stage_dumps_bit_exact_pulses():
             f"case {i}: MDCT bins differ at {np.argwhere(df > 1e-5 * max(1.0, np.abs(tf).max()))[:8].tolist()} "
             f"lm {t.lm} transient {t.transient} C {t.C} anticollapse {t.anticollapse_on} silence {t.silence}")
         check_pcm(refpcm, pcm.cpu().numpy()[: refpcm.size].reshape(refpcm.shape), f"case {i}: pcm")
+        # the IMDCT stage on its own against ground truth: the kernel's samples before the window (the frame's scratch row)
+        # must be the O(N^2) f64 inverse MDCT of the kernel's own MDCT bins, block by block, >= 100 dB
+        row = cl.work[: 1920 * 4].view(torch.float32).cpu().numpy().reshape(2, 960)
+        gf = freq.cpu().numpy()
+        B = (1 << t.lm) if t.transient else 1
+        NB = N // B
+        want = np.zeros((2, N), np.float64)
+        L = orc.lib()
+        for ch in range(2):
+            for b in range(B):
+                src = np.ascontiguousarray(gf[ch, :N])
+                D = np.zeros(NB, np.float64)
+                L.orc_imdct_raw_direct(src[b:].ctypes.data_as(C.c_void_p), B, NB, D.ctypes.data_as(C.c_void_p))
+                want[ch, NB * b: NB * (b + 1)] = D
+        if np.abs(want).max() > 0:
+            err = ((row[:, :N] - want) ** 2).sum()
+            snr = 10 * np.log10((want ** 2).sum() / max(err, 1e-300))
+            assert snr >= 100.0, f"case {i}: IMDCT stage {snr:.1f} dB against the f64 direct transform (lm {t.lm}, blocks {B})"
+        else:
+            assert not row[:, :N].any()
 
 
 def test_full_size_properties():

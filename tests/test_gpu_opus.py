@@ -187,3 +187,20 @@ def test_lost_packets_and_redundant_frames_on_gpu(vid, npk):
         out, r = d.receive_frame(), ref.decode(b"" if lost else p)
         assert out.shape == r.shape, f"vector {vid} packet {i}"
         check_pcm(r, out, f"vector {vid} packet {i}{' (lost)' if lost else ''}")
+
+
+def test_hybrid_to_silk_flush_behind_redundant_head_on_gpu():
+    """a hybrid -> SILK switch that carries a CELT -> SILK redundant frame (crafted from vector 12's packets, see
+    tests/test_emu_silk.py): redundant frame and overlap flush run in rounds of their own, one after the other, and the
+    result is the oracle's -- several times, on fresh decoders: nothing may depend on workgroup timing"""
+    from test_emu_silk import crafted_hybrid_to_silk_with_redundant_head
+    seq = crafted_hybrid_to_silk_with_redundant_head()
+    extra, _ = orc.load_vectors(ids=[12], max_packets=1)[12]
+    for rep in range(4):
+        d = Decoder(0)
+        d.set_extradata(extra)
+        d.configure()
+        ref = orc.Decoder(2)
+        for i, p in enumerate(seq):
+            d.send_packet(p)
+            check_pcm(ref.decode(p), d.receive_frame(), f"rep {rep} crafted packet {i}")

@@ -93,6 +93,56 @@ def test_multistream_packets(family, mapping):
         check_pcm(want, out, f"packet {i}{' (lost)' if lost else ''}")
 
 
+@pytest.mark.gpu
+def test_multistream_flush_resets_every_stream():
+    """flush() on a multistream decoder (a seek): every stream of both batches starts over -- the packets that follow decode
+    exactly as on a fresh decoder, on the coupled stream and on the mono stream"""
+    pk = pairs(40)
+    mapping = [0, 2, 1]
+    head = opus_head(3, 1, 2, 1, mapping)
+    d, fresh = Decoder(0), Decoder(0)
+    for x in (d, fresh):
+        x.set_extradata(head)
+        x.configure()
+    for pa, pb in pk[:20]:                              # history of its own
+        d.send_packet(self_delimit(pa) + pb)
+        d.receive_frame()
+    d.flush()
+    for i, (pa, pb) in enumerate(pk[20:]):
+        p = self_delimit(pa) + pb
+        d.send_packet(p)
+        fresh.send_packet(p)
+        a, b = d.receive_frame(), fresh.receive_frame()
+        assert np.array_equal(a, b), f"packet {i} after the flush: max diff {np.abs(a - b).max()}"
+
+
+@pytest.mark.gpu
+def test_one_stream_family_255_goes_through_the_mapping_table():
+    """family 255 with ONE mono stream on two output channels, mapping {255, 0}: silence left, the stream right (such a header
+    used to take the plain stereo path, which ignores the table)"""
+    v = [bytes(p) for p in orc.load_vectors(ids=[11], max_packets=30)[11][1]]
+    d = Decoder(0)
+    d.set_extradata(opus_head(2, 255, 1, 0, [255, 0]))
+    d.configure()
+    ref = orc.Decoder(1)
+    for i, p in enumerate(v):
+        d.send_packet(p)
+        out, w = d.receive_frame(), ref.decode(p)
+        assert out.shape == (len(w), 2) and not out[:, 0].any(), f"packet {i}"
+        check_pcm(w[:, 0], out[:, 1], f"packet {i}")
+
+
+def test_family_1_with_more_than_8_channels_is_rejected():
+    """RFC 7845 5.1.1.2: mapping family 1 is defined for 1..8 channels"""
+    import ctypes as C
+    lib = A.load()
+    out = A.OpusHead()
+    head = opus_head(9, 1, 9, 0, list(range(9)))
+    assert lib.opusgpu_opus_head_parse(head, len(head), C.byref(out)) == A.CONFIG_INVALID
+    head = opus_head(8, 1, 8, 0, list(range(8)))
+    assert lib.opusgpu_opus_head_parse(head, len(head), C.byref(out)) == A.OK
+
+
 def test_undelimit_round_trip():
     """host framing: self-delimiting packet -> ordinary packet gives back the original bytes and the right length"""
     import ctypes as C
