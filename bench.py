@@ -48,9 +48,10 @@ def parse_args():
     ap.add_argument("--split", type=int, default=1,
                     help="issue each step as this many independent sub-batches of streams, each on a HIP stream of its own "
                          "(the sub-batches share nothing: their kernels may run side by side)")
-    ap.add_argument("--workload", choices=["c2", "c3"], default="c2",
+    ap.add_argument("--workload", choices=["c2", "c3", "c4"], default="c2",
                     help="c2 (default, the headline): BASELINE configs[1], synthetic CELT FB stereo 20 ms, 4096 streams per GPU; "
-                         "c3: BASELINE configs[2], SILK WB mono 20 ms, 16384 streams per GPU (SURVEY.md 8d)")
+                         "c3: BASELINE configs[2], SILK WB mono 20 ms, 16384 streams per GPU (SURVEY.md 8d); "
+                         "c4: BASELINE configs[3], hybrid SWB/FB + CELT of every frame size, 8192 streams per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle comparison of the last step's PCM")
     ap.add_argument("--parse-only", action="store_true",
@@ -311,6 +312,223 @@ def main_c3(a, rank, local_rank, world):
         dist.destroy_process_group()
 
 
+C4_STREAMS_PER_GPU = 8192
+C4_VECTORS = (5, 6, 7, 10)
+
+
+def vector_packets(ids):
+    """packets of the RFC 6716 vectors `ids` from tests/golden/opus_vectors.bin, in file order: {id: [bytes]}"""
+    import struct
+    b = open(os.path.join(ROOT, "tests", "golden", "opus_vectors.bin"), "rb").read()
+    assert b[:8] == b"OPVEC1\0\0"
+    (nvec,) = struct.unpack_from("<I", b, 8)
+    p, pool = 12, {}
+    for _ in range(nvec):
+        vid, el = struct.unpack_from("<II", b, p); p += 8 + el
+        (npk,) = struct.unpack_from("<I", b, p); p += 4
+        for _ in range(npk):
+            (l,) = struct.unpack_from("<H", b, p); p += 2
+            if vid in ids:
+                pool.setdefault(vid, []).append(b[p:p + l])
+            p += l
+    return pool
+
+
+def c4_alg_bytes(celt, silk):
+    """SURVEY.md 8(d) per-record algorithmic bytes for a mixed step (numpy views of the step's OgCeltHdr / OgSilkFrame records).
+    CELT record of N samples per channel, CC output channels: 1024 side-info + 4 N CC PCM write (+ the same read where it adds
+    onto the SILK output or cross-fades) + 1920 overlap r/w + 700 energies / seed, + 7712 post-filter history where the comb
+    filter is on.  SILK frame: per coded channel 1024 side-info + 5408 history r/w; + 4 x 48 kHz samples x CC PCM write + 128
+    resampler state."""
+    import numpy as np
+    from opus_amd import _abi as A
+    total = 0
+    if len(celt):
+        h = np.frombuffer(celt, dtype=np.uint8).reshape(len(celt), C.sizeof(A.CeltHdr))
+        lm = h[:, A.CeltHdr.lm.offset].astype(np.int64) & 3
+        fl = h[:, A.CeltHdr.flags.offset].astype(np.int64)
+        sp = h[:, A.CeltHdr.spread.offset].astype(np.int64)
+        cc = np.where(fl & 32, 2, 1)
+        n = 120 << lm
+        g = h[:, A.CeltHdr.pf_gain_q.offset:A.CeltHdr.pf_gain_q.offset + 3].astype(np.int64)
+        pf = (g[:, 0] != 0) | (g[:, 1] != 0) | ((lm != 0) & (g[:, 2] != 0))
+        rmw = ((fl & 64) != 0) | (((sp >> 4) & 3) != 0)
+        total += int((1024 + 4 * n * cc * np.where(rmw, 2, 1) + 1920 + 700 + np.where(pf, ALG_BYTES_PF, 0)).sum())
+    if len(silk):
+        k = np.frombuffer(silk, dtype=np.uint8).reshape(len(silk), C.sizeof(A.SilkFrame))
+        fl = k[:, A.SilkFrame.flags.offset].astype(np.int64)
+        bw = k[:, A.SilkFrame.bandwidth.offset].astype(np.int64)
+        fs = k[:, A.SilkFrame.f_size.offset:A.SilkFrame.f_size.offset + 2].copy().view(np.uint16)[:, 0].astype(np.int64)
+        nch = np.where(fl & 1, 2, 1)
+        cc = np.where(fl & 2, 2, 1)
+        out48 = fs * np.where(bw == 0, 6, np.where(bw == 1, 4, 3))
+        total += int((nch * (1024 + 5408) + 4 * out48 * cc + 128).sum())
+    return total
+
+
+def main_c4(a, rank, local_rank, world):
+    """--workload c4: BASELINE configs[3].  A step = one packet of every stream -- hybrid SWB / FB 10 and 20 ms
+    (vectors 05, 06), CELT of every bandwidth and frame size, 2.5-20 ms, transients included (07), hybrid <-> CELT switching with
+    redundant frames (10) -- as the launches opusgpu_batch_decode makes of it: the SILK frames by depth (og_silk_synth_kernel +
+    og_silk_output_kernel), then every CELT record of the step in one K1 / plan / spectrum launch and one tail launch over the
+    streams' runs.  Side-info and launch plans of all steps are pre-parsed and resident in HBM; PCM stays in HBM."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from opus_amd import BatchDecoder, _abi as A, parse_packet, sharding
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(a.backend, device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    lib = A.load()
+    S = a.streams if a.streams != STREAMS_PER_GPU else C4_STREAMS_PER_GPU
+    K, W = a.steps, a.warmup
+    nsteps = K + W
+    pools = vector_packets(C4_VECTORS)
+    ids = sharding.shard_stream_ids(rank, world, S)
+
+    def packet(s, k):                                   # stream s replays one of the four vectors from its own offset, in file order
+        g = int(ids[s])
+        v = pools[C4_VECTORS[g % 4]]
+        return v[((g // 4) * 7919 + k) % len(v)]
+
+    parser = BatchDecoder(S, 2, local_rank)             # host half only: packets -> side-info + launch plan
+    steps, t_parse, audio_s, alg_total, rec_total = [], 0.0, 0.0, 0, [0, 0]
+    max_celt, stride = 1, 5760 * 2
+    for k in range(nsteps):
+        pk = [packet(s, k) for s in range(S)]
+        lens = np.array([len(p) for p in pk], np.uint32)
+        rows = np.zeros((S, int(lens.max())), np.uint8)
+        for s, p in enumerate(pk):
+            rows[s, :len(p)] = np.frombuffer(p, np.uint8)
+        t0 = time.perf_counter()
+        errs = parser.send_packed(rows, lens)
+        t_parse += time.perf_counter() - t0
+        assert not errs.any()
+        celt, leaves, silk = parser.sideinfo()
+        pl = parser.plan()
+        up = lambda x: torch.from_numpy(np.frombuffer(x, dtype=np.uint8).copy() if len(x) else np.zeros(16, np.uint8)).to(dev)
+        st = dict(celt=up(celt), leaves=up(leaves), silk=up(silk), refs=torch.from_numpy(pl["refs"]).to(dev),
+                  runs=torch.from_numpy(pl["run_off"].astype(np.uint32).view(np.uint8).copy()).to(dev), ncelt=len(celt), nruns=pl["nruns"],
+                  run_len=pl["run_len"], classes=pl["class_counts"], depth_off=[int(x) for x in pl["silk_depth_off"]])
+        steps.append(st)
+        max_celt = max(max_celt, len(celt))
+        if k >= W:
+            _, _, nsamp = parser.device_pcm()
+            audio_s += float(np.asarray(nsamp, np.float64).sum()) / 48000.0
+            alg_total += c4_alg_bytes(celt, silk)
+            rec_total[0] += len(celt); rec_total[1] += len(silk)
+    parser.close()
+    HS, SS = C.sizeof(A.SilkFrame), C.sizeof(A.CeltState)
+    sstate = torch.zeros(lib.opusgpu_silk_state_bytes(S), dtype=torch.uint8, device=dev)
+    cstate = torch.zeros(S * SS, dtype=torch.uint8, device=dev)
+    work = torch.zeros(lib.opusgpu_celt_work_bytes(max_celt), dtype=torch.uint8, device=dev)
+    pcm = torch.zeros(S * stride, dtype=torch.float32, device=dev)
+    strm = torch.cuda.Stream(dev)
+    ps = C.c_void_p(strm.cuda_stream)
+
+    def check(rc):
+        if rc:
+            raise RuntimeError(lib.opusgpu_last_error().decode())
+
+    def step(k):
+        st = steps[k]
+        off = st["depth_off"]
+        for d in range(len(off) - 1):
+            if off[d + 1] > off[d]:
+                check(lib.opusgpu_launch_silk(st["silk"].data_ptr() + off[d] * HS, off[d + 1] - off[d], sstate.data_ptr(), S, pcm.data_ptr(),
+                                              stride, None, ps))
+        if st["ncelt"]:
+            if st["run_len"]:
+                check(lib.opusgpu_launch_celt(st["celt"].data_ptr(), st["leaves"].data_ptr(), st["ncelt"], st["run_len"], st["refs"].data_ptr(),
+                                              st["classes"], work.data_ptr(), cstate.data_ptr(), pcm.data_ptr(), stride, None, ps))
+            else:
+                check(lib.opusgpu_launch_celt_runs(st["celt"].data_ptr(), st["leaves"].data_ptr(), st["ncelt"], st["runs"].data_ptr(), st["nruns"],
+                                                   st["refs"].data_ptr(), st["classes"], work.data_ptr(), cstate.data_ptr(), pcm.data_ptr(),
+                                                   stride, None, ps))
+
+    torch.cuda.synchronize(dev)
+    for k in range(W):
+        step(k)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(strm)
+    for k in range(W, nsteps):
+        step(k)
+    ev1.record(strm)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    elapsed = sharding.max_over_ranks(time.perf_counter() - t0)
+    step_s = ev0.elapsed_time(ev1) / K / 1e3
+    verify = None
+    if not a.no_verify:                                 # the last step's PCM of a few streams (one per vector and more) against the CPU oracle
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import orc
+        from gpu_util import check_pcm
+        rows = pcm.view(S, stride).cpu().numpy()
+        sample = sorted({0, 1, 2, 3, S // 3, S // 2, S // 2 + 1, 2 * S // 3 + 2, S - 1})
+        worst = 0.0
+        for s in sample:
+            d = orc.Decoder(2)
+            for k in range(nsteps):
+                want = d.decode(packet(s, k))
+            worst = max(worst, check_pcm(want, rows[s][: want.size].reshape(want.shape), f"c4 stream {s}"))
+        verify = {"ok": True, "streams": sample, "max_scaled_err": float(f"{worst:.3e}"),
+                  "bar": "max abs err <= 1e-4 (scaled by the reference peak when that exceeds 1), SNR >= 90 dB vs the CPU oracle"}
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    total_audio = audio_s * world                       # (every rank decodes the same mix: weak scaling)
+    alg = alg_total / K
+    line = {"metric": "decoded audio-sec/sec (hybrid SWB/FB + CELT 2.5-20 ms mixed, 8192 streams)",
+            "value": round(total_audio / elapsed, 1), "unit": "audio-s/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "RFC 6716 vectors 05 / 06 / 07 / 10 replayed",
+            "verified": bool(verify and verify["ok"]), "verify": verify,
+            "config": {"workload": "BASELINE configs[3] (SURVEY.md 8d C4): hybrid SWB / FB 10 and 20 ms (RFC vectors 05, 06), CELT of every "
+                                   "bandwidth and frame size incl. transients (07), hybrid <-> CELT switching with redundant frames (10); stream s "
+                                   f"replays vector (05, 06, 07, 10)[s % 4] from its own offset, one packet per stream per step, {S} streams per "
+                                   "GPU; device-only: side-info and launch plan pre-parsed and resident in HBM, PCM stays in HBM",
+                       "streams_per_gpu": S, "mean_packet_ms": round(audio_s / K / S * 1e3, 2),
+                       "celt_records_per_step": round(rec_total[0] / K, 1), "silk_frames_per_step": round(rec_total[1] / K, 1),
+                       "parallelism": f"streams sharded over {world} GPU(s), one process per GPU, no collective in the data path; "
+                                      f"{a.backend} only for the barrier and the max of the elapsed times"},
+            "roofline": {"bound": "hbm", "achieved": round(alg / step_s / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(alg / step_s / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
+                         "kernel": "one step: opusgpu_launch_silk per SILK depth (og_silk_synth_kernel + og_silk_output_kernel) + one "
+                                   "opusgpu_launch_celt[_runs] (og_pvq_all_kernel + og_plan_kernel + og_celt_kernel + og_celt_tail_kernel)",
+                         "avg_launch_us": round(step_s * 1e6, 2), "algorithmic_bytes_per_launch": int(alg)},
+            "host_parse": {"value": round(audio_s / K * nsteps / t_parse, 1), "unit": "audio-s/s",
+                           "note": "packets -> side-info + launch plan on the host threads (untimed in `value`)"}}
+    if not a.no_cpu_baseline:
+        from concurrent.futures import ThreadPoolExecutor
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import orc
+        cores = min(16, os.cpu_count() or 1)
+        nst, nfr = cores * 4, 300
+
+        def work(s):
+            d = orc.Decoder(2)
+            return sum(len(d.decode(packet(s, k))) for k in range(nfr))
+        orc.lib()
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(cores) as ex:
+            done = sum(ex.map(work, range(nst)))
+        dt = time.perf_counter() - t0
+        line["cpu_baseline"] = {"value": round(done / 48000.0 / dt, 2), "unit": "audio-s/s", "cores": cores, "kind": "port",
+                                "sample": f"{nst} of the same streams x {nfr} packets on the CPU oracle (oracle/liborc.so, scalar C, -O2), "
+                                          "one stream per thread"}
+    print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     a = parse_args()
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
@@ -322,6 +540,8 @@ def main():
         sys.exit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {a.gpus}")
     if a.workload == "c3":
         return main_c3(a, rank, local_rank, world)
+    if a.workload == "c4":
+        return main_c4(a, rank, local_rank, world)
     import numpy as np
     import torch
     import torch.distributed as dist

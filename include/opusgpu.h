@@ -146,6 +146,20 @@ int opusgpu_batch_flush(opusgpu_batch *, uint32_t stream);
 /* Side-info the last batch_send produced (host memory owned by the batch; parity tests read it). */
 int opusgpu_batch_sideinfo(opusgpu_batch *, const OgCeltHdr **celt, uint32_t *ncelt, const OgCeltLeaf **leaves,
                            uint32_t *nleaves, const OgSilkFrame **silk, uint32_t *nsilk);
+/* The launch plan of that send (host memory owned by the batch, valid until the next batch_send): what batch_decode does with
+ * the side-info, for callers that keep several sends' side-info resident and issue the layer-3 launches themselves (bench.py's
+ * mixed-mode workload).  SILK frames are ordered by depth -- launch d = frames [silk_depth_off[d], silk_depth_off[d + 1]), the
+ * d-th SILK frame of every stream that has one; all of them run before the CELT launch, whose records are the whole `celt`
+ * array, stream run r = [run_off[r], run_off[r + 1]) (run_len != 0: every run has that many records). */
+typedef struct {
+    const OgLeafRef *refs;         /* K1 work list over all CELT records (opusgpu_sort_pvq_leaves' order) */
+    uint32_t nrefs, class_counts[4];
+    const uint32_t *run_off;       /* [nruns + 1] */
+    uint32_t nruns, run_len;
+    const uint32_t *silk_depth_off;/* [ndepths + 1] */
+    uint32_t ndepths;
+} OgBatchPlan;
+int opusgpu_batch_plan(opusgpu_batch *, OgBatchPlan *out);
 
 /* ------------------------------------------------------------------------------------------------
  * Layer 3a: host parser for one stream, no GPU involved.  What the reference's Rust host would keep
@@ -257,6 +271,16 @@ int opusgpu_launch_celt_frames(const OgCeltHdr *hdr, uint32_t nframes, uint32_t 
 int opusgpu_launch_celt_spectrum(const OgCeltHdr *hdr, uint32_t nframes, void *work, const OgCeltDebug *debug, void *stream);
 int opusgpu_launch_celt_tail(const OgCeltHdr *hdr, uint32_t nframes, uint32_t frames_per_group, void *work, OgCeltState *state,
                              float *pcm, size_t pcm_stride_floats, const OgCeltDebug *debug, void *stream);
+/* The same with groups of different sizes -- a mixed send, where the number of CELT records (frames of a packet, redundant
+ * frames, overlap flushes: everything decoder.rs:72-123 walks for one packet, for every packet of the send) differs from stream
+ * to stream: run r = records [run_off[r], run_off[r + 1]) of ONE stream, in the order they must run; run_off is a device
+ * array of nruns + 1 offsets.  K1, the plan and K2 are stateless, so all records of a send go through them in one launch
+ * whatever their order in time; only the tail walks a stream's records one after the other. */
+int opusgpu_launch_celt_tail_runs(const OgCeltHdr *hdr, uint32_t nframes, const uint32_t *run_off, uint32_t nruns, void *work,
+                                  OgCeltState *state, float *pcm, size_t pcm_stride_floats, const OgCeltDebug *debug, void *stream);
+int opusgpu_launch_celt_runs(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, uint32_t nframes, const uint32_t *run_off, uint32_t nruns,
+                             const OgLeafRef *refs, const uint32_t class_counts[4], void *work, OgCeltState *state, float *pcm,
+                             size_t pcm_stride_floats, const OgCeltDebug *debug, void *stream);
 
 /* opusgpu_launch_celt for callers that cannot allocate device memory or bring a workspace: code under HIP graph capture,
  * tight serving loops, harnesses that forbid hipMalloc.  It has no counterpart in the reference (which has no device at

@@ -64,6 +64,11 @@ class CeltState(C.Structure):
                 ("pos", C.c_uint32), ("pad_", C.c_uint32)]
 
 
+class BatchPlan(C.Structure):
+    _fields_ = [("refs", C.c_void_p), ("nrefs", C.c_uint32), ("class_counts", C.c_uint32 * 4), ("run_off", C.POINTER(C.c_uint32)),
+                ("nruns", C.c_uint32), ("run_len", C.c_uint32), ("silk_depth_off", C.POINTER(C.c_uint32)), ("ndepths", C.c_uint32)]
+
+
 class OpusHead(C.Structure):
     _fields_ = [("version", C.c_uint8), ("channels", C.c_uint8), ("pre_skip", C.c_uint16), ("input_sample_rate", C.c_uint32),
                 ("output_gain_q8", C.c_int16), ("mapping_family", C.c_uint8), ("stream_count", C.c_uint8),
@@ -109,6 +114,7 @@ PROTOTYPES = {
     "opusgpu_batch_flush": (C.c_int, [_P, C.c_uint32]),
     "opusgpu_batch_sideinfo": (C.c_int, [_P, C.POINTER(C.POINTER(CeltHdr)), C.POINTER(C.c_uint32), C.POINTER(C.POINTER(CeltLeaf)),
                                         C.POINTER(C.c_uint32), C.POINTER(C.POINTER(SilkFrame)), C.POINTER(C.c_uint32)]),
+    "opusgpu_batch_plan": (C.c_int, [_P, C.POINTER(BatchPlan)]),
     "opusgpu_parser_create": (C.c_int, [C.POINTER(_P), C.c_int]),
     "opusgpu_parser_destroy": (None, [_P]),
     "opusgpu_parser_reset": (None, [_P]),
@@ -123,6 +129,9 @@ PROTOTYPES = {
     "opusgpu_launch_celt_frames": (C.c_int, [_P, C.c_uint32, C.c_uint32, _P, _P, _P, C.c_size_t, C.POINTER(CeltDebug), _P]),
     "opusgpu_launch_celt_spectrum": (C.c_int, [_P, C.c_uint32, _P, C.POINTER(CeltDebug), _P]),
     "opusgpu_launch_celt_tail": (C.c_int, [_P, C.c_uint32, C.c_uint32, _P, _P, _P, C.c_size_t, C.POINTER(CeltDebug), _P]),
+    "opusgpu_launch_celt_tail_runs": (C.c_int, [_P, C.c_uint32, _P, C.c_uint32, _P, _P, _P, C.c_size_t, C.POINTER(CeltDebug), _P]),
+    "opusgpu_launch_celt_runs": (C.c_int, [_P, _P, C.c_uint32, _P, C.c_uint32, _P, C.POINTER(C.c_uint32), _P, _P, _P, C.c_size_t,
+                                          C.POINTER(CeltDebug), _P]),
     "opusgpu_noalloc_max_frames": (C.c_uint32, []),
     "opusgpu_launch_celt_noalloc": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, _P, C.POINTER(C.c_uint32), _P, _P, C.c_size_t, _P]),
     "opusgpu_sort_pvq_leaves": (C.c_uint32, [_P, C.c_uint32, _P, _P, C.c_uint32, C.POINTER(C.c_uint32)]),

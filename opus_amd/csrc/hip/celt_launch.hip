@@ -321,7 +321,10 @@ __global__ __launch_bounds__(OG_WG) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     og_celt_spectrum(hdr + f, og_work_plan(work, f), T, L, d, og_work_coef(work, f), stop, (int)f);
 }
 
+// Groups: frames_per_group consecutive records each, or -- group_off != null -- records [group_off[g], group_off[g + 1]) for
+// workgroup g (a stream's records of a mixed send: their number differs from stream to stream).
 __global__ __launch_bounds__(OG_WGT) void og_celt_tail_kernel(const OgCeltHdr *__restrict__ hdr, uint32_t nframes, uint32_t frames_per_group,
+                                                              const uint32_t *__restrict__ group_off,
                                                               const OgCeltTables *__restrict__ T, void *work, OgCeltState *state, float *pcm,
                                                               size_t pcm_stride, OgCeltDebug dbg)
 {
@@ -329,9 +332,17 @@ __global__ __launch_bounds__(OG_WGT) void og_celt_tail_kernel(const OgCeltHdr *_
     for (int p = threadIdx.x; p < 120; p += OG_WGT) L.window[p] = T->window[p];
     if (threadIdx.x < 12) (&L.taps[0][0])[threadIdx.x] = (&T->k.pf_taps[0][0])[threadIdx.x];
     __syncthreads();
-    const uint32_t f0 = blockIdx.x * frames_per_group;
-    if (f0 >= nframes) return;
-    const uint32_t nfr = nframes - f0 < frames_per_group ? nframes - f0 : frames_per_group;
+    uint32_t f0, nfr;
+    if (group_off) {
+        f0 = group_off[blockIdx.x];
+        const uint32_t f1 = group_off[blockIdx.x + 1];
+        if (f0 >= nframes || f1 <= f0) return;
+        nfr = (f1 < nframes ? f1 : nframes) - f0;
+    } else {
+        f0 = blockIdx.x * frames_per_group;
+        if (f0 >= nframes) return;
+        nfr = nframes - f0 < frames_per_group ? nframes - f0 : frames_per_group;
+    }
     og_celt_tail_group(hdr + f0, nfr, state, pcm, pcm_stride, L, dbg.cycles ? dbg.cycles + (size_t)f0 * 64 : nullptr, work, f0);
 }
 
@@ -469,11 +480,11 @@ int opusgpu_launch_celt_spectrum(const OgCeltHdr *hdr, uint32_t nframes, void *w
     return OPUSGPU_OK;
 }
 
-int opusgpu_launch_celt_tail(const OgCeltHdr *hdr, uint32_t nframes, uint32_t frames_per_group, void *work, OgCeltState *state,
-                             float *pcm, size_t pcm_stride_floats, const OgCeltDebug *debug, void *stream)
+static int launch_tail(const OgCeltHdr *hdr, uint32_t nframes, uint32_t frames_per_group, const uint32_t *group_off, uint32_t ngroups,
+                       void *work, OgCeltState *state, float *pcm, size_t pcm_stride_floats, const OgCeltDebug *debug, void *stream)
 {
     if (nframes == 0) return OPUSGPU_OK;
-    if (!hdr || !state || !pcm || !work || frames_per_group == 0) return OPUSGPU_BAD_ARG;
+    if (!hdr || !state || !pcm || !work || (group_off ? ngroups == 0 : frames_per_group == 0)) return OPUSGPU_BAD_ARG;
     int device = 0;
     OG_HIP(hipGetDevice(&device));
     const OgCeltTables *T;
@@ -481,11 +492,36 @@ int opusgpu_launch_celt_tail(const OgCeltHdr *hdr, uint32_t nframes, uint32_t fr
     if (rc) return rc;
     OgCeltDebug dbg = {nullptr, nullptr, nullptr, nullptr, nullptr};
     if (debug) dbg = *debug;
-    const uint32_t groups = (nframes + frames_per_group - 1) / frames_per_group;
-    hipLaunchKernelGGL(og_celt_tail_kernel, dim3(groups), dim3(OG_WGT), 0, (hipStream_t)stream, hdr, nframes, frames_per_group, T, work,
+    const uint32_t groups = group_off ? ngroups : (nframes + frames_per_group - 1) / frames_per_group;
+    hipLaunchKernelGGL(og_celt_tail_kernel, dim3(groups), dim3(OG_WGT), 0, (hipStream_t)stream, hdr, nframes, frames_per_group, group_off, T, work,
                        state, pcm, pcm_stride_floats, dbg);
     OG_HIP(hipGetLastError());
     return OPUSGPU_OK;
+}
+
+int opusgpu_launch_celt_tail(const OgCeltHdr *hdr, uint32_t nframes, uint32_t frames_per_group, void *work, OgCeltState *state,
+                             float *pcm, size_t pcm_stride_floats, const OgCeltDebug *debug, void *stream)
+{
+    return launch_tail(hdr, nframes, frames_per_group, nullptr, 0, work, state, pcm, pcm_stride_floats, debug, stream);
+}
+
+int opusgpu_launch_celt_tail_runs(const OgCeltHdr *hdr, uint32_t nframes, const uint32_t *run_off, uint32_t nruns, void *work,
+                                  OgCeltState *state, float *pcm, size_t pcm_stride_floats, const OgCeltDebug *debug, void *stream)
+{
+    if (nframes && !run_off) return OPUSGPU_BAD_ARG;
+    return launch_tail(hdr, nframes, 0, run_off, nruns, work, state, pcm, pcm_stride_floats, debug, stream);
+}
+
+int opusgpu_launch_celt_runs(const OgCeltHdr *hdr, const OgCeltLeaf *leaves, uint32_t nframes, const uint32_t *run_off, uint32_t nruns,
+                             const OgLeafRef *refs, const uint32_t class_counts[4], void *work, OgCeltState *state, float *pcm,
+                             size_t pcm_stride_floats, const OgCeltDebug *debug, void *stream)
+{
+    if (nframes == 0) return OPUSGPU_OK;
+    if (!state || !pcm || !run_off || nruns == 0) return OPUSGPU_BAD_ARG;
+    int rc = opusgpu_launch_celt_pvq(hdr, leaves, nframes, refs, class_counts, work, debug, stream);
+    if (rc) return rc;
+    if ((rc = opusgpu_launch_celt_spectrum(hdr, nframes, work, debug, stream))) return rc;
+    return opusgpu_launch_celt_tail_runs(hdr, nframes, run_off, nruns, work, state, pcm, pcm_stride_floats, debug, stream);
 }
 
 int opusgpu_launch_celt_frames(const OgCeltHdr *hdr, uint32_t nframes, uint32_t frames_per_group, void *work, OgCeltState *state,

@@ -74,7 +74,6 @@ struct ParsedPacket {                    // one thread-local parse result
     int rc = 0;                          // number of frames or error
     uint32_t stream = 0;
     int worker = 0;                      // whose local arrays fi[].celt_index / silk_index point into
-    uint32_t frame0 = 0;                 // Opus frames of the stream's earlier packets in this send (multi-packet sends)
     OgFrameInfo fi[48];
     size_t celt0 = 0, leaf0 = 0, silk0 = 0;   // offsets into the worker's local arrays
     size_t ncelt = 0, nleaf = 0, nsilk = 0;
@@ -84,8 +83,10 @@ struct Worker {
     std::vector<OgCeltHdr> celt;
     std::vector<OgCeltLeaf> leaves;
     std::vector<OgSilkFrame> silk;
-    std::vector<uint32_t> ccount, scount;    // CELT / SILK records per round among this worker's packets, then: where its first goes
-    void reach(size_t nrounds) { if (ccount.size() < nrounds) { ccount.resize(nrounds, 0); scount.resize(nrounds, 0); } }
+    std::vector<uint32_t> scount;            // SILK frames per depth (k-th SILK frame of its stream in this send) among this worker's
+                                             // packets, then: where its first of that depth goes
+    uint32_t nruns = 0;                      // streams of this worker with at least one CELT record in this send
+    void reach(size_t depth) { if (scount.size() < depth) scount.resize(depth, 0); }
 };
 
 // Parse threads of a batch: started once, parked on a condition variable between batch_send calls (a send of 4096 packets
@@ -214,20 +215,21 @@ struct opusgpu_batch {
     PinnedBuf<OgCeltLeaf> h_leaves;
     PinnedBuf<OgSilkFrame> h_silk;
     PinnedBuf<OgLeafRef> h_refs;                            // PVQ leaves per round, sorted by size (K1's work list)
-    std::vector<uint32_t> ref_round_off;
-    std::vector<uint32_t> ref_classes;                      // [rounds][4] leaves per K1 size class
-    std::vector<uint32_t> celt_round_off, silk_round_off;   // [rounds + 1]
+    uint32_t ref_classes[4] = {0, 0, 0, 0};                 // leaves per K1 size class
+    std::vector<uint32_t> silk_round_off;                   // [depths + 1]: SILK frames by depth (a stream's k-th SILK frame of the send)
+    PinnedBuf<uint32_t> h_runs;                             // CELT records of stream run r: [h_runs[r], h_runs[r + 1])
+    uint32_t nruns = 0, run_len = 0;                        // run_len != 0: every run has that many records (no offsets needed)
 
     DeviceBuf<OgCeltHdr> d_celt;
     DeviceBuf<OgCeltLeaf> d_leaves;
     DeviceBuf<OgSilkFrame> d_silk;
     DeviceBuf<OgLeafRef> d_refs;
+    DeviceBuf<uint32_t> d_runs;
     DeviceBuf<uint8_t> d_work;                              // K1 -> K2 scratch, kept zero-filled between launches
     OgCeltState *d_celt_state = nullptr;
     void *d_silk_state = nullptr;
     float *d_pcm = nullptr;
     size_t pcm_stride = 0;
-    uint32_t grouped_T = 0;                                 // the pending send is one launch of [stream][t] CELT records, t < grouped_T
     bool pending = false;
     hipEvent_t h2d_done = nullptr;                          // recorded behind the last H2D copy of batch_decode
     bool h2d_in_flight = false;                             // the pinned side-info may still be read by the copy engine
@@ -237,27 +239,29 @@ struct opusgpu_batch {
         (void)hipSetDevice(device);
         if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
         if (h2d_done) (void)hipEventDestroy(h2d_done);
-        h_celt.release(); h_leaves.release(); h_silk.release(); h_refs.release();
-        d_celt.release(); d_leaves.release(); d_silk.release(); d_refs.release(); d_work.release();
+        h_celt.release(); h_leaves.release(); h_silk.release(); h_refs.release(); h_runs.release();
+        d_celt.release(); d_leaves.release(); d_silk.release(); d_refs.release(); d_runs.release(); d_work.release();
         if (d_celt_state) (void)hipFree(d_celt_state);
         if (d_silk_state) (void)hipFree(d_silk_state);
         if (d_pcm) (void)hipFree(d_pcm);
     }
 };
 
-// The second half of a uniform send (batch_send_impl), on the parse threads: every worker copies its leaves and headers to
-// their places in the pinned arrays -- the records of the send form one round, [stream][t][f], which is the order the workers
-// hold them in -- and the K1 work list (opusgpu_sort_pvq_leaves' order exactly: key descending, then frame, then leaf) comes
-// from per-worker histograms, one prefix pass over them, and a scatter by every worker of its own leaves.
-// Returns the number of refs; class counts of the round go to (*classes)[4 * round ..].
-static uint32_t merge_uniform(opusgpu_batch *b, uint32_t n, uint32_t T, int nw, const uint32_t *stream_ids, int32_t *errors,
-                              const std::vector<size_t> &leaf_base, std::vector<uint32_t> *classes, uint32_t rounds, uint32_t round)
+// The second half of a send (batch_send_impl), on the parse threads.  What the device gets:
+//   * the send's CELT records as ONE launch, laid out [stream][time] -- the order in which the workers hold them -- with the
+//     stream runs' offsets (K1, the plan and K2 are stateless: only the tail kernel walks a stream's records in order);
+//   * its SILK frames by depth: the k-th SILK frame of every stream forms launch k (a stream's SILK frames are sequential in
+//     time; none depends on a CELT record, whereas a hybrid frame's CELT part adds onto the SILK output: all SILK launches
+//     run before the CELT one).
+// Every worker copies its leaves and records to their places in the pinned arrays and counts its PVQ leaves by key; the K1
+// work list (opusgpu_sort_pvq_leaves' order exactly: key descending, then frame, then leaf) then comes from one prefix pass
+// over the (key, worker) counts and a scatter by every worker of its own leaves.  Returns the number of refs.
+static uint32_t merge_send(opusgpu_batch *b, uint32_t n, uint32_t T, int nw, const uint32_t *stream_ids, int32_t *errors,
+                           const std::vector<size_t> &leaf_base, const std::vector<size_t> &celt_base, const std::vector<uint32_t> &run_base)
 {
     using namespace og;
     constexpr size_t ROW = K1_NKEYS + 256;                   // a worker's histogram: keys, then leaves per dimension n
     std::vector<Worker> &workers = b->workers;
-    std::vector<size_t> celt_base(size_t(nw) + 1, 0);
-    for (int w = 0; w < nw; w++) celt_base[w + 1] = celt_base[w] + workers[w].celt.size();
     if (b->key_count.size() < ROW * size_t(nw)) b->key_count.resize(ROW * size_t(nw));
     const std::function<void(int)> place = [&](int w) {
         Worker &W = workers[w];
@@ -266,26 +270,41 @@ static uint32_t merge_uniform(opusgpu_batch *b, uint32_t n, uint32_t T, int nw, 
         if (!W.leaves.empty()) std::memcpy(b->h_leaves.p + leaf_base[w], W.leaves.data(), W.leaves.size() * sizeof(OgCeltLeaf));
         const uint32_t lo = uint32_t(uint64_t(n) * w / nw), hi = uint32_t(uint64_t(n) * (w + 1) / nw);
         OgCeltHdr *out = b->h_celt.p + celt_base[w];
-        size_t j = 0;
+        uint32_t *sfill = W.scount.data();
+        uint32_t *runs = b->h_runs.p + run_base[w];
+        size_t j = 0;                                        // records of this worker placed so far (= index into W.celt)
         for (uint32_t i = lo; i < hi; i++) {
-            uint32_t pcm_off = 0;
+            uint32_t pcm_off = 0, depth = 0;
             const uint32_t stream = stream_ids ? stream_ids[i] : i;
+            const size_t j0 = j;
             for (uint32_t t = 0; t < T; t++) {
                 const ParsedPacket &pp = b->parsed[size_t(i) * T + t];
-                if (errors) errors[size_t(i) * T + t] = OPUSGPU_OK;
-                for (int f0 = 0; f0 < pp.rc; f0++, j++) {
-                    OgCeltHdr &hd = out[j];
-                    hd = W.celt[j];
-                    hd.stream = stream;
-                    hd.pcm_off += pcm_off;                   // the parser left the offset inside the Opus frame
-                    const OgCeltLeaf *lf = W.leaves.data() + hd.leaf_begin;
-                    for (uint32_t l = 0; l < hd.nleaves; l++)
-                        if (k1_wanted(hd, lf[l])) { cnt[k1_key(lf[l])]++; cnt[K1_NKEYS + lf[l].n]++; }
-                    hd.leaf_begin = uint32_t(hd.leaf_begin + leaf_base[w]);
-                    pcm_off += pp.fi[f0].frame_size;
+                if (errors) errors[size_t(i) * T + t] = pp.rc < 0 ? pp.rc : OPUSGPU_OK;
+                for (int f0 = 0; f0 < pp.rc; f0++) {
+                    const OgFrameInfo &fi = pp.fi[f0];
+                    uint32_t sub = 0;                        // SILK frames of one Opus frame are consecutive 20 ms pieces
+                    for (uint32_t k = 0; k < fi.nsilk; k++, depth++) {
+                        OgSilkFrame &sf = b->h_silk.p[sfill[depth]++];
+                        sf = W.silk[fi.silk_index + k];
+                        sf.stream = stream;
+                        sf.pcm_off = pcm_off + sub;
+                        sub += uint32_t(sf.f_size) * (sf.bandwidth == 0 ? 6u : sf.bandwidth == 1 ? 4u : 3u);
+                    }
+                    for (uint32_t c = 0; c < fi.has_celt; c++, j++) {      // (records were emitted in the order they must run)
+                        OgCeltHdr &hd = out[j];
+                        hd = W.celt[fi.celt_index + c];      // (== j: records are placed in the order they were emitted)
+                        hd.stream = stream;
+                        hd.pcm_off += pcm_off;               // the parser left the offset inside the Opus frame
+                        const OgCeltLeaf *lf = W.leaves.data() + hd.leaf_begin;
+                        for (uint32_t l = 0; l < hd.nleaves; l++)
+                            if (k1_wanted(hd, lf[l])) { cnt[k1_key(lf[l])]++; cnt[K1_NKEYS + lf[l].n]++; }
+                        hd.leaf_begin = uint32_t(hd.leaf_begin + leaf_base[w]);
+                    }
+                    pcm_off += fi.frame_size;
                 }
             }
             b->nsamples[stream] = pcm_off;
+            if (j > j0) *runs++ = uint32_t(celt_base[w] + j0);
         }
     };
     b->pool->run(nw, place);
@@ -303,9 +322,9 @@ static uint32_t merge_uniform(opusgpu_batch *b, uint32_t n, uint32_t T, int nw, 
                 total += here;
             }
     }
-    classes->assign(4 * size_t(rounds) + 4, 0);
+    for (int c = 0; c < 4; c++) b->ref_classes[c] = 0;
     for (int w = 0; w < nw; w++)
-        for (int d = 0; d < 256; d++) (*classes)[4 * size_t(round) + k1_class(d)] += b->key_count[ROW * size_t(w) + K1_NKEYS + d];
+        for (int d = 0; d < 256; d++) b->ref_classes[k1_class(d)] += b->key_count[ROW * size_t(w) + K1_NKEYS + d];
     const std::function<void(int)> scatter = [&](int w) {
         uint32_t *at = b->key_count.data() + ROW * size_t(w);
         const OgCeltHdr *hd = b->h_celt.p + celt_base[w];
@@ -377,7 +396,6 @@ static int batch_send_impl(opusgpu_batch *b, const uint8_t *const *pkts, const u
         b->h2d_in_flight = false;
     }
     std::fill(b->nsamples.begin(), b->nsamples.end(), 0);
-    b->grouped_T = 0;
     if (T > 1) {                                        // a stream's PCM row holds the whole send: T packets of up to 120 ms
         const size_t need = size_t(T) * OPUSGPU_MAX_FRAME * b->channels;
         if (need > b->pcm_stride) {
@@ -405,23 +423,22 @@ static int batch_send_impl(opusgpu_batch *b, const uint8_t *const *pkts, const u
     std::vector<ParsedPacket> &parsed = b->parsed;
     if (int(workers.size()) < nw) workers.resize(nw);
     if (parsed.size() < size_t(n) * T) parsed.resize(size_t(n) * T);
-    for (auto &W : workers) { W.celt.clear(); W.leaves.clear(); W.silk.clear(); W.ccount.clear(); W.scount.clear(); }   // capacity stays
+    for (auto &W : workers) { W.celt.clear(); W.leaves.clear(); W.silk.clear(); W.scount.clear(); W.nruns = 0; }   // capacity stays
     const std::function<void(int)> run = [&](int w) {
         Worker &W = workers[w];
         const uint32_t lo = uint32_t(uint64_t(n) * w / nw), hi = uint32_t(uint64_t(n) * (w + 1) / nw);
         for (uint32_t i = lo; i < hi; i++) {
-            uint32_t frames_before = 0;
+            uint32_t depth = 0;                         // SILK frames of this stream so far in the send
+            const size_t c0 = W.celt.size();
             for (uint32_t t = 0; t < T; t++) {
                 ParsedPacket &pp = parsed[size_t(i) * T + t];
                 pp.stream = stream_ids ? stream_ids[i] : i;
                 pp.worker = w;
-                pp.frame0 = frames_before;
                 pp.celt0 = W.celt.size(); pp.leaf0 = W.leaves.size(); pp.silk0 = W.silk.size();
                 pp.rc = b->parsers[pp.stream].parse(pkts[size_t(i) * T + t], lens[size_t(i) * T + t], pp.fi, W.celt, W.leaves, W.silk);
-                if (pp.rc < 0) {                        // a bad packet never poisons the batch
-                    W.celt.resize(pp.celt0); W.leaves.resize(pp.leaf0); W.silk.resize(pp.silk0);
-                } else {
-                    // a round holds at most one CELT record of a stream: two would read-modify-write its state side by side
+                if (pp.rc >= 0) {
+                    // the records of an Opus frame name the launch round each belongs to (OG_ROUND_*, for hosts that run a round of
+                    // launches per frame): never two of one stream in one round -- they would read-modify-write its state side by side
                     bool clash = false;
                     for (int f = 0; f < pp.rc && !clash; f++) {
                         uint32_t used = 0;
@@ -431,164 +448,84 @@ static int batch_send_impl(opusgpu_batch *b, const uint8_t *const *pkts, const u
                             used |= bit;
                         }
                     }
-                    if (clash) {
-                        pp.rc = OPUSGPU_INVALID_DATA;
-                        W.celt.resize(pp.celt0); W.leaves.resize(pp.leaf0); W.silk.resize(pp.silk0);
+                    if (clash) pp.rc = OPUSGPU_INVALID_DATA;
+                }
+                if (pp.rc < 0) {                        // a bad packet never poisons the batch
+                    W.celt.resize(pp.celt0); W.leaves.resize(pp.leaf0); W.silk.resize(pp.silk0);
+                } else {
+                    for (int f = 0; f < pp.rc; f++) {
+                        W.reach(depth + pp.fi[f].nsilk);
+                        for (uint32_t k = 0; k < pp.fi[f].nsilk; k++) W.scount[depth++]++;
                     }
-                    for (int f = 0; f < pp.rc; f++) {       // the rounds its records will run in (see the merge below)
-                        const uint32_t r0 = OG_ROUNDS_PER_FRAME * (frames_before + uint32_t(f));
-                        W.reach(r0 + OG_ROUNDS_PER_FRAME);
-                        for (uint32_t c = 0; c < pp.fi[f].has_celt; c++) W.ccount[r0 + (W.celt[pp.fi[f].celt_index + c].spread >> OG_ROUND_SHIFT)]++;
-                        for (uint32_t k = 0; k < pp.fi[f].nsilk; k++) W.scount[r0 + k]++;
-                    }
-                    if (pp.rc > 0) frames_before += uint32_t(pp.rc);
                 }
                 pp.ncelt = W.celt.size() - pp.celt0; pp.nleaf = W.leaves.size() - pp.leaf0; pp.nsilk = W.silk.size() - pp.silk0;
             }
+            if (W.celt.size() > c0) W.nruns++;
         }
     };
     b->pool->run(nw, run);
     const auto t_parsed = now();
 
-    // ---- merge: leaves concatenated per worker, frames regrouped by round
-    std::vector<size_t> leaf_base(nw + 1, 0);
-    size_t tot_celt = 0, tot_silk = 0;
+    // ---- merge: where every worker's leaves, CELT records, stream runs and SILK frames (by depth) go
+    std::vector<size_t> leaf_base(nw + 1, 0), celt_base(nw + 1, 0);
+    std::vector<uint32_t> run_base(nw + 1, 0);
+    size_t tot_silk = 0, depths = 0;
     for (int w = 0; w < nw; w++) {
         leaf_base[w + 1] = leaf_base[w] + workers[w].leaves.size();
-        tot_celt += workers[w].celt.size();
+        celt_base[w + 1] = celt_base[w] + workers[w].celt.size();
+        run_base[w + 1] = run_base[w] + workers[w].nruns;
         tot_silk += workers[w].silk.size();
+        depths = std::max(depths, workers[w].scount.size());
     }
+    const size_t tot_celt = celt_base[nw];
+    if (tot_celt > OG_REF_FRAME_MASK) return OPUSGPU_BAD_ARG;
     OG_HIP(hipSetDevice(b->device));
     int rc;
     if ((rc = b->h_leaves.reserve(leaf_base[nw] + 1))) return rc;
     if ((rc = b->h_celt.reserve(tot_celt + 1))) return rc;
     if ((rc = b->h_silk.reserve(tot_silk + 1))) return rc;
-    b->h_leaves.n = leaf_base[nw];
-
-    // A stream's work must run in order: Opus frame f of a packet = rounds 4f .. 4f+3 (OG_ROUNDS_PER_FRAME); its SILK frames (up
-    // to three 20 ms pieces) take rounds 4f+k, its CELT records run after the SILK frames of the round each names (OG_ROUND_*:
-    // the frame's own CELT part, which adds onto the SILK output in hybrid mode, in 4f+2; redundant frames in 4f+0 / 4f+3).
-    constexpr uint32_t RPF = OG_ROUNDS_PER_FRAME;
-    uint32_t rounds = 0;
-    const size_t np = size_t(n) * T;
-    for (int w = 0; w < nw; w++) rounds = std::max(rounds, uint32_t(workers[w].ccount.size()));     // RPF x the most frames of a stream
-    // Uniform sends: every packet holds the same number F of frames, all CELT-only (no SILK, no redundant frames).  All their
-    // CELT records belong to one round, laid out [stream][t][f] -- the order in which the workers hold them -- so the workers
-    // finish the send themselves (merge_uniform below).  With T F > 1 (several packets per stream and / or code 1-3 packets)
-    // the whole send is moreover ONE launch in which a tail workgroup walks a stream's T F frames in time order
-    // (frames_per_group = T F), instead of a round of launches per frame.
-    const uint32_t F = np && parsed[0].rc > 0 ? uint32_t(parsed[0].rc) : 0;
-    bool uniform = n > 0 && F > 0 && tot_silk == 0 && tot_celt == np * F && tot_celt <= OG_REF_FRAME_MASK;
-    for (size_t i = 0; i < np && uniform; i++) {
-        const ParsedPacket &pp = parsed[i];
-        uniform = pp.rc == int(F);
-        for (int f = 0; f < pp.rc && uniform; f++)
-            uniform = pp.fi[f].nsilk == 0 && pp.fi[f].has_celt == 1 &&
-                      (workers[pp.worker].celt[pp.fi[f].celt_index].spread >> OG_X_SHIFT) == (OG_ROUND_MAIN << (OG_ROUND_SHIFT - OG_X_SHIFT));
-    }
-    const bool grouped = uniform && size_t(T) * F > 1;
-    if (grouped) rounds = 1;
-    if (uniform) {
-        if ((rc = b->h_refs.reserve(b->h_leaves.n + 1))) return rc;
-        const uint32_t round = grouped ? 0 : OG_ROUND_MAIN;
-        const uint32_t nref = merge_uniform(b, n, T, nw, stream_ids, errors, leaf_base, &b->ref_classes, rounds, round);
-        b->celt_round_off.assign(rounds + 1, uint32_t(tot_celt));
-        b->ref_round_off.assign(rounds + 1, nref);
-        for (uint32_t r = 0; r <= round; r++) b->celt_round_off[r] = b->ref_round_off[r] = 0;
-        b->silk_round_off.assign(rounds + 1, 0);
-        b->h_celt.n = tot_celt;
-        b->h_silk.n = 0;
-        b->h_refs.n = nref;
-        b->grouped_T = grouped ? T * F : 0;
-        b->pending = true;
-        if (std::getenv("OPUSGPU_CHECK_SORT")) {            // self-check (tests): the one-thread sort of the same round must agree
-            std::vector<OgLeafRef> want(b->h_leaves.n + 1);
-            uint32_t cls[4];
-            const uint32_t nw2 = opusgpu_sort_pvq_leaves(b->h_celt.p, uint32_t(tot_celt), b->h_leaves.p, want.data(), uint32_t(want.size()), cls);
-            if (nw2 != nref || std::memcmp(want.data(), b->h_refs.p, size_t(nref) * sizeof(OgLeafRef)) != 0 ||
-                std::memcmp(cls, &b->ref_classes[4 * round], sizeof cls) != 0) {
-                std::fprintf(stderr, "opusgpu: the threaded K1 sort differs from opusgpu_sort_pvq_leaves\n");
-                return OPUSGPU_DEVICE;
-            }
-        }
-        if (timing)
-            std::fprintf(stderr, "opusgpu send: %u x %u packets, %d threads: parse %.3f ms, merge + sort on the threads %.3f ms\n", n, T, nw,
-                         ms(t_begin, t_parsed), ms(t_parsed, now()));
-        return OPUSGPU_OK;
-    }
-    // The records of a round lie in the order of the workers' blocks of streams.  Per-round counts came with the parse; one pass
-    // turns them into the rounds' offsets and into every worker's first index in every round, and the workers place their own
-    // records (and copy their leaves).
-    b->celt_round_off.assign(rounds + 1, 0);
-    b->silk_round_off.assign(rounds + 1, 0);
-    for (uint32_t r = 0; r < rounds; r++) {
-        uint32_t c = b->celt_round_off[r], k = b->silk_round_off[r];
+    if ((rc = b->h_refs.reserve(leaf_base[nw] + 1))) return rc;
+    if ((rc = b->h_runs.reserve(size_t(run_base[nw]) + 2))) return rc;
+    b->silk_round_off.assign(depths + 1, 0);
+    for (size_t d = 0; d < depths; d++) {               // counts -> every worker's first index at every depth
+        uint32_t k = b->silk_round_off[d];
         for (int w = 0; w < nw; w++) {
             Worker &W = workers[w];
-            W.reach(rounds);
-            const uint32_t wc = W.ccount[r], wk = W.scount[r];
-            W.ccount[r] = c; W.scount[r] = k;
-            c += wc; k += wk;
+            W.reach(depths);
+            const uint32_t wk = W.scount[d];
+            W.scount[d] = k;
+            k += wk;
         }
-        b->celt_round_off[r + 1] = c;
-        b->silk_round_off[r + 1] = k;
+        b->silk_round_off[d + 1] = k;
     }
-    const std::function<void(int)> place = [&](int w) {
-        Worker &W = workers[w];
-        if (!W.leaves.empty()) std::memcpy(b->h_leaves.p + leaf_base[w], W.leaves.data(), W.leaves.size() * sizeof(OgCeltLeaf));
-        uint32_t *cfill = W.ccount.data(), *sfill = W.scount.data();
-        const uint32_t lo = uint32_t(uint64_t(n) * w / nw), hi = uint32_t(uint64_t(n) * (w + 1) / nw);
-        for (uint32_t i = lo; i < hi; i++) {
-            uint32_t pcm_off = 0;
-            for (uint32_t t = 0; t < T; t++) {
-                const ParsedPacket &pp = parsed[size_t(i) * T + t];
-                if (errors) errors[size_t(i) * T + t] = pp.rc < 0 ? pp.rc : OPUSGPU_OK;
-                for (int f0 = 0; f0 < pp.rc; f0++) {
-                    const OgFrameInfo &fi = pp.fi[f0];
-                    const uint32_t f = pp.frame0 + uint32_t(f0);
-                    uint32_t sub = 0;                   // SILK frames of one Opus frame are consecutive 20 ms pieces
-                    for (uint32_t k = 0; k < fi.nsilk; k++) {
-                        OgSilkFrame &sf = b->h_silk.p[sfill[RPF * f + k]++];
-                        sf = W.silk[fi.silk_index + k];
-                        sf.stream = pp.stream;
-                        sf.pcm_off = pcm_off + sub;
-                        sub += uint32_t(sf.f_size) * (sf.bandwidth == 0 ? 6u : sf.bandwidth == 1 ? 4u : 3u);
-                    }
-                    for (uint32_t c = 0; c < fi.has_celt; c++) {
-                        const OgCeltHdr &src = W.celt[fi.celt_index + c];
-                        OgCeltHdr &hd = b->h_celt.p[cfill[RPF * f + (src.spread >> OG_ROUND_SHIFT)]++];
-                        hd = src;
-                        hd.stream = pp.stream;
-                        hd.pcm_off += pcm_off;          // the parser left the offset inside the Opus frame
-                        hd.leaf_begin = uint32_t(hd.leaf_begin + leaf_base[w]);
-                    }
-                    pcm_off += fi.frame_size;
-                }
-                b->nsamples[pp.stream] = pcm_off;
-            }
-        }
-    };
-    b->pool->run(nw, place);
+    const uint32_t nref = merge_send(b, n, T, nw, stream_ids, errors, leaf_base, celt_base, run_base);
+    b->h_leaves.n = leaf_base[nw];
     b->h_celt.n = tot_celt;
     b->h_silk.n = tot_silk;
-    const auto t_merged = now();
-    // K1 work lists: per round, that round's PVQ leaves sorted by size; frame indices are relative to the round
-    if ((rc = b->h_refs.reserve(b->h_leaves.n + 1))) return rc;
-    b->ref_round_off.assign(rounds + 1, 0);
-    b->ref_classes.assign(4 * size_t(rounds) + 4, 0);
-    uint32_t nref = 0;
-    for (uint32_t r = 0; r < rounds; r++) {
-        const uint32_t c0 = b->celt_round_off[r], cn = b->celt_round_off[r + 1] - c0;
-        nref += opusgpu_sort_pvq_leaves(b->h_celt.p + c0, cn, b->h_leaves.p, b->h_refs.p + nref, uint32_t(b->h_refs.cap - nref),
-                                        &b->ref_classes[4 * r]);
-        b->ref_round_off[r + 1] = nref;
-    }
     b->h_refs.n = nref;
-    b->grouped_T = 0;
+    b->nruns = run_base[nw];
+    b->h_runs.p[b->nruns] = uint32_t(tot_celt);
+    b->h_runs.n = size_t(b->nruns) + 1;
+    // runs of one length (every steady batch: one CELT frame per stream, or T F of them -- several packets per stream and / or
+    // code 1-3 packets) need no offsets: the tail kernel's fixed groups
+    b->run_len = b->nruns ? uint32_t(tot_celt / b->nruns) : 0;
+    if (b->run_len * size_t(b->nruns) != tot_celt) b->run_len = 0;
+    for (uint32_t r = 0; r < b->nruns && b->run_len; r++)
+        if (b->h_runs.p[r] != r * b->run_len) b->run_len = 0;
     b->pending = true;
+    if (std::getenv("OPUSGPU_CHECK_SORT") && tot_celt) {    // self-check (tests): the one-thread sort of the same records must agree
+        std::vector<OgLeafRef> want(b->h_leaves.n + 1);
+        uint32_t cls[4];
+        const uint32_t nw2 = opusgpu_sort_pvq_leaves(b->h_celt.p, uint32_t(tot_celt), b->h_leaves.p, want.data(), uint32_t(want.size()), cls);
+        if (nw2 != nref || std::memcmp(want.data(), b->h_refs.p, size_t(nref) * sizeof(OgLeafRef)) != 0 ||
+            std::memcmp(cls, b->ref_classes, sizeof cls) != 0) {
+            std::fprintf(stderr, "opusgpu: the threaded K1 sort differs from opusgpu_sort_pvq_leaves\n");
+            return OPUSGPU_DEVICE;
+        }
+    }
     if (timing)
-        std::fprintf(stderr, "opusgpu send: %u x %u packets, %d threads: parse %.3f ms, merge %.3f ms, sort %.3f ms\n", n, T, nw,
-                     ms(t_begin, t_parsed), ms(t_parsed, t_merged), ms(t_merged, now()));
+        std::fprintf(stderr, "opusgpu send: %u x %u packets, %d threads: parse %.3f ms, merge + sort on the threads %.3f ms\n", n, T, nw,
+                     ms(t_begin, t_parsed), ms(t_parsed, now()));
     return OPUSGPU_OK;
 }
 
@@ -610,32 +547,37 @@ int opusgpu_batch_decode(opusgpu_batch *b)
     if (!b->pending) return OPUSGPU_OK;
     OG_HIP(hipSetDevice(b->device));
     int rc;
+    const bool offsets = b->nruns && !b->run_len;       // runs of different lengths: the tail kernel needs their offsets
+    // (every device buffer grows before the first launch of this call: growing frees the old block, see DeviceBuf)
+    const size_t work_need = opusgpu_celt_work_bytes(uint32_t(b->h_celt.n)), work_had = b->d_work.cap;
     if ((rc = b->d_celt.reserve(b->h_celt.n + 1, b->stream)) || (rc = b->d_leaves.reserve(b->h_leaves.n + 1, b->stream)) ||
-        (rc = b->d_silk.reserve(b->h_silk.n + 1, b->stream)) || (rc = b->d_refs.reserve(b->h_refs.n + 1, b->stream)))
+        (rc = b->d_silk.reserve(b->h_silk.n + 1, b->stream)) || (rc = b->d_refs.reserve(b->h_refs.n + 1, b->stream)) ||
+        (rc = b->d_runs.reserve(b->h_runs.n + 1, b->stream)) || (rc = b->d_work.reserve(work_need, b->stream)))
         return rc;
     if (b->h_celt.n) OG_HIP(hipMemcpyAsync(b->d_celt.p, b->h_celt.p, b->h_celt.n * sizeof(OgCeltHdr), hipMemcpyHostToDevice, b->stream));
     if (b->h_leaves.n) OG_HIP(hipMemcpyAsync(b->d_leaves.p, b->h_leaves.p, b->h_leaves.n * sizeof(OgCeltLeaf), hipMemcpyHostToDevice, b->stream));
     if (b->h_silk.n) OG_HIP(hipMemcpyAsync(b->d_silk.p, b->h_silk.p, b->h_silk.n * sizeof(OgSilkFrame), hipMemcpyHostToDevice, b->stream));
     if (b->h_refs.n) OG_HIP(hipMemcpyAsync(b->d_refs.p, b->h_refs.p, b->h_refs.n * sizeof(OgLeafRef), hipMemcpyHostToDevice, b->stream));
+    if (offsets) OG_HIP(hipMemcpyAsync(b->d_runs.p, b->h_runs.p, b->h_runs.n * sizeof(uint32_t), hipMemcpyHostToDevice, b->stream));
     OG_HIP(hipEventRecord(b->h2d_done, b->stream));
     b->h2d_in_flight = true;
-    {
-        uint32_t maxc = 0;
-        for (size_t r = 0; r + 1 < b->celt_round_off.size(); r++) maxc = std::max(maxc, b->celt_round_off[r + 1] - b->celt_round_off[r]);
-        const size_t need = opusgpu_celt_work_bytes(maxc), had = b->d_work.cap;
-        if ((rc = b->d_work.reserve(need, b->stream))) return rc;
-        if (b->d_work.cap != had) OG_HIP(hipMemsetAsync(b->d_work.p, 0, b->d_work.cap, b->stream));   // zero once per (re)allocation
-    }
-    const size_t rounds = b->celt_round_off.empty() ? 0 : b->celt_round_off.size() - 1;
-    for (size_t r = 0; r < rounds; r++) {               // frame r of every packet; a stream's frames stay in order
-        const uint32_t s0 = b->silk_round_off[r], sn = b->silk_round_off[r + 1] - s0;
+    if (b->d_work.cap != work_had) OG_HIP(hipMemsetAsync(b->d_work.p, 0, b->d_work.cap, b->stream));   // zero once per (re)allocation
+    // SILK by depth (a stream's frames stay in order), then every CELT record of the send in one launch: decoder.rs:72-123's
+    // per-frame loop, cut where the data dependences are instead of where the packet boundaries are
+    for (size_t d = 0; d + 1 < b->silk_round_off.size(); d++) {
+        const uint32_t s0 = b->silk_round_off[d], sn = b->silk_round_off[d + 1] - s0;
         if (sn && (rc = opusgpu_launch_silk(b->d_silk.p + s0, sn, b->d_silk_state, b->nstreams, b->d_pcm, b->pcm_stride, nullptr, b->stream)))
             return rc;
-        const uint32_t c0 = b->celt_round_off[r], cn = b->celt_round_off[r + 1] - c0;
-        if (cn && (rc = opusgpu_launch_celt(b->d_celt.p + c0, b->d_leaves.p, cn, b->grouped_T ? b->grouped_T : 1, b->d_refs.p + b->ref_round_off[r],
-                                            &b->ref_classes[4 * r], b->d_work.p, b->d_celt_state, b->d_pcm,
-                                            b->pcm_stride, nullptr, b->stream)))
-            return rc;
+    }
+    const uint32_t cn = uint32_t(b->h_celt.n);
+    if (cn) {
+        if (offsets)
+            rc = opusgpu_launch_celt_runs(b->d_celt.p, b->d_leaves.p, cn, b->d_runs.p, b->nruns, b->d_refs.p, b->ref_classes, b->d_work.p,
+                                          b->d_celt_state, b->d_pcm, b->pcm_stride, nullptr, b->stream);
+        else
+            rc = opusgpu_launch_celt(b->d_celt.p, b->d_leaves.p, cn, b->run_len, b->d_refs.p, b->ref_classes, b->d_work.p, b->d_celt_state,
+                                     b->d_pcm, b->pcm_stride, nullptr, b->stream);
+        if (rc) return rc;
     }
     b->pending = false;
     return OPUSGPU_OK;
@@ -688,6 +630,20 @@ int opusgpu_batch_sideinfo(opusgpu_batch *b, const OgCeltHdr **celt, uint32_t *n
     if (nleaves) *nleaves = uint32_t(b->h_leaves.n);
     if (silk) *silk = b->h_silk.p;
     if (nsilk) *nsilk = uint32_t(b->h_silk.n);
+    return OPUSGPU_OK;
+}
+
+int opusgpu_batch_plan(opusgpu_batch *b, OgBatchPlan *out)
+{
+    if (!b || !out) return OPUSGPU_BAD_ARG;
+    out->refs = b->h_refs.p;
+    out->nrefs = uint32_t(b->h_refs.n);
+    for (int c = 0; c < 4; c++) out->class_counts[c] = b->ref_classes[c];
+    out->run_off = b->h_runs.p;
+    out->nruns = b->nruns;
+    out->run_len = b->run_len;
+    out->silk_depth_off = b->silk_round_off.data();
+    out->ndepths = b->silk_round_off.empty() ? 0 : uint32_t(b->silk_round_off.size() - 1);
     return OPUSGPU_OK;
 }
 

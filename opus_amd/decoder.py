@@ -217,6 +217,18 @@ class BatchDecoder:
             return out
         return take(ce, nc, A.CeltHdr), take(lv, nl, A.CeltLeaf), take(sk, ns, A.SilkFrame)
 
+    def plan(self):
+        """Launch plan of the last send(): dict of numpy copies -- refs (uint8 view of OgLeafRef[]), class_counts, run_off,
+        run_len, silk_depth_off (see OgBatchPlan in include/opusgpu.h)."""
+        import numpy as np
+        pl = A.BatchPlan()
+        _chk(self._lib.opusgpu_batch_plan(self._h, C.byref(pl)), "batch_plan")
+        refs = np.frombuffer(C.string_at(pl.refs, pl.nrefs * 8), np.uint8).copy() if pl.nrefs else np.zeros(8, np.uint8)
+        return dict(refs=refs, nrefs=pl.nrefs, class_counts=(C.c_uint32 * 4)(*pl.class_counts),
+                    run_off=np.ctypeslib.as_array(pl.run_off, (pl.nruns + 1,)).copy() if pl.nruns else np.zeros(1, np.uint32),
+                    nruns=pl.nruns, run_len=pl.run_len,
+                    silk_depth_off=np.ctypeslib.as_array(pl.silk_depth_off, (pl.ndepths + 1,)).copy() if pl.ndepths else np.zeros(1, np.uint32))
+
     def flush(self, stream):
         _chk(self._lib.opusgpu_batch_flush(self._h, stream), "batch_flush")
 

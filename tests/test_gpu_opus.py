@@ -204,3 +204,31 @@ def test_hybrid_to_silk_flush_behind_redundant_head_on_gpu():
         for i, p in enumerate(seq):
             d.send_packet(p)
             check_pcm(ref.decode(p), d.receive_frame(), f"rep {rep} crafted packet {i}")
+
+
+def test_mixed_modes_c4_shape_8192_streams():
+    """BASELINE config 4 at full size through layer 2: 8192 streams on vectors 05 / 06 / 07 / 10 (hybrid SWB / FB, CELT of every
+    frame size with transients, hybrid <-> CELT switching with redundant frames), one packet per stream per step.  Every step is
+    the SILK launches by depth + ONE CELT launch whose tail walks the streams' runs (1 .. 8+ records each); a sample of streams
+    is compared with the oracle at every step, the rest must be finite."""
+    import torch
+    V = orc.load_vectors(ids=[5, 6, 7, 10])
+    vids = (5, 6, 7, 10)
+    ns, steps = 8192, 6
+    dec = BatchDecoder(ns, 2, 0)
+
+    def packet(s, k):
+        v = V[vids[s % 4]][1]
+        return v[((s // 4) * 7919 + k) % len(v)]
+    sample = sorted({0, 1, 2, 3, 1366, 2731, 4097, 6002, 8190, 8191})
+    refs = {s: orc.Decoder(2) for s in sample}
+    lens_seen = set()
+    for k in range(steps):
+        pk = [packet(s, k) for s in range(ns)]
+        assert not any(dec.send(pk))
+        pl = dec.plan()
+        lens_seen |= set(np.diff(pl["run_off"]).tolist())
+        dec.decode()
+        for s in sample:
+            check_pcm(refs[s].decode(pk[s]), dec.read(s), f"stream {s} (vector {vids[s % 4]}) step {k}")
+    assert len(lens_seen) > 2, "runs of several lengths in one launch"
