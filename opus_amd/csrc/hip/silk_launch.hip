@@ -7,7 +7,8 @@
 
 __global__ __launch_bounds__(64) void og_silk_synth_kernel(const OgSilkFrame *__restrict__ frames, uint32_t nframes, OgSilkArrays A)
 {
-    og_silk_channel(frames, nframes, A, blockIdx.x * 64 + threadIdx.x);
+    __shared__ OgSilkLds L;
+    og_silk_synth_wave(frames, nframes, A, blockIdx.x * OG_SK_SLOTS, L);
 }
 
 __global__ __launch_bounds__(OG_WG) void og_silk_output_kernel(const OgSilkFrame *__restrict__ frames, OgSilkArrays A,
@@ -44,13 +45,10 @@ static int silk_tables_for_device(int device, const OgSilkTables **out)
 OgSilkArrays silk_arrays(void *state, uint32_t nstreams)
 {
     OgSilkArrays A;
-    const size_t ns = 2 * size_t(nstreams), nst = (ns + 63) / 64 * 64;      // slots, and slots rounded up to whole tiles
+    const size_t ns = 2 * size_t(nstreams);
     float *p = (float *)state;
-    A.out = p; p += size_t(OG_SILK_OUT_ROWS) * nst;
-    A.lpc = p; p += 16 * nst;
-    A.res = p; p += size_t(OG_SILK_RES_ROWS) * nst;
-    A.rs_hist = p; p += size_t(nstreams) * 64;
-    A.frame = p;                                        // (16-byte aligned: every array before it is a multiple of four floats)
+    A.slots = p; p += size_t(OG_SILK_SLOT) * ns;
+    A.rs_hist = p;
     A.nslots = uint32_t(ns);
     A.nstreams = nstreams;
     return A;
@@ -62,8 +60,7 @@ extern "C" {
 
 size_t opusgpu_silk_state_bytes(uint32_t nstreams)
 {
-    const size_t ns = 2 * size_t(nstreams), nst = (ns + 63) / 64 * 64;
-    return sizeof(float) * ((size_t(OG_SILK_OUT_ROWS) + 16 + OG_SILK_RES_ROWS) * nst + OG_SILK_FRAME_STRIDE * ns + size_t(nstreams) * 64);
+    return sizeof(float) * (size_t(OG_SILK_SLOT) * 2 * size_t(nstreams) + size_t(nstreams) * 64);
 }
 
 int opusgpu_launch_silk(const OgSilkFrame *frames, uint32_t nframes, void *state, uint32_t nstreams, float *pcm,
@@ -77,7 +74,7 @@ int opusgpu_launch_silk(const OgSilkFrame *frames, uint32_t nframes, void *state
     int rc = og::silk_tables_for_device(device, &T);
     if (rc) return rc;
     OgSilkArrays A = og::silk_arrays(state, nstreams);
-    hipLaunchKernelGGL(og_silk_synth_kernel, dim3((2 * nframes + 63) / 64), dim3(64), 0, (hipStream_t)stream, frames, nframes, A);
+    hipLaunchKernelGGL(og_silk_synth_kernel, dim3((2 * nframes + OG_SK_SLOTS - 1) / OG_SK_SLOTS), dim3(64), 0, (hipStream_t)stream, frames, nframes, A);
     hipLaunchKernelGGL(og_silk_output_kernel, dim3(nframes), dim3(OG_WG), 0, (hipStream_t)stream, frames, A, T, pcm,
                        pcm_stride_floats, debug_internal);
     OG_HIP(hipGetLastError());

@@ -8,8 +8,7 @@ void og_fill_silk_tables(OgSilkTables *t);
 
 extern "C" size_t emu_silk_state_floats(uint32_t nstreams)
 {
-    const size_t ns = 2 * size_t(nstreams), nst = (ns + 63) / 64 * 64;
-    return (size_t(OG_SILK_OUT_ROWS) + 16 + OG_SILK_RES_ROWS) * nst + OG_SILK_FRAME_STRIDE * ns + size_t(nstreams) * 64 + 4;
+    return size_t(OG_SILK_SLOT) * 2 * size_t(nstreams) + size_t(nstreams) * 64 + 4;
 }
 
 extern "C" int emu_launch_silk(const OgSilkFrame *frames, uint32_t nframes, float *state, uint32_t nstreams, float *pcm,
@@ -19,16 +18,15 @@ extern "C" int emu_launch_silk(const OgSilkFrame *frames, uint32_t nframes, floa
     static bool init = false;
     if (!init) { og_fill_silk_tables(&T); init = true; }
     OgSilkArrays A;
-    const size_t ns = 2 * size_t(nstreams), nst = (ns + 63) / 64 * 64;
-    float *p = state;
-    A.out = p; p += size_t(OG_SILK_OUT_ROWS) * nst;
-    A.lpc = p; p += 16 * nst;
-    A.res = p; p += size_t(OG_SILK_RES_ROWS) * nst;
-    A.rs_hist = p; p += size_t(nstreams) * 64;
-    A.frame = (float *)(((uintptr_t)p + 15) & ~(uintptr_t)15);      // 16-byte aligned rows (the numpy buffer may not be)
-    A.nslots = uint32_t(ns);
+    A.slots = state;
+    A.rs_hist = state + size_t(OG_SILK_SLOT) * 2 * size_t(nstreams);
+    A.nslots = 2 * nstreams;
     A.nstreams = nstreams;
-    for (uint32_t i = 0; i < 2 * nframes; i++) og_silk_channel(frames, nframes, A, i);
+    static OgSilkLds Ls;
+    for (uint32_t i = 0; i < 2 * nframes; i += OG_SK_SLOTS) {
+        std::memset(&Ls, 0xA5, sizeof Ls);             // LDS starts undefined on the device
+        og_silk_synth_wave(frames, nframes, A, i, Ls);
+    }
     static OgSilkOutLds L;
     for (uint32_t f = 0; f < nframes; f++) {
         std::memset(&L, 0xA5, sizeof L);
