@@ -53,6 +53,8 @@ def parse_args():
                          "c3: BASELINE configs[2], SILK WB mono 20 ms, 16384 streams per GPU (SURVEY.md 8d); "
                          "c4: BASELINE configs[3], hybrid SWB/FB + CELT of every frame size, 8192 streams per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side-stream", action="store_true", help="c4: every launch of a step on one stream (default: the stateless CELT "
+                                                                  "kernels on a side stream beside the SILK launches, as opusgpu_batch_decode does)")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle comparison of the last step's PCM")
     ap.add_argument("--parse-only", action="store_true",
                     help="host half only (packets -> side-info through the C ABI parser), no GPU; with --backend gloo this is "
@@ -432,21 +434,40 @@ def main_c4(a, rank, local_rank, world):
         if rc:
             raise RuntimeError(lib.opusgpu_last_error().decode())
 
-    def step(k):
+    side = torch.cuda.Stream(dev)
+    pside = C.c_void_p(side.cuda_stream)
+    fork, join = torch.cuda.Event(), torch.cuda.Event()
+
+    def step(k):                                        # what opusgpu_batch_decode issues for the step (engine.cpp)
         st = steps[k]
         off = st["depth_off"]
+        beside = st["ncelt"] and len(off) > 1 and not a.no_side_stream
+        front = pside if beside else ps
+        if beside:                                      # the stateless CELT kernels beside the SILK launches
+            fork.record(strm)
+            side.wait_event(fork)
+        if st["ncelt"] and beside:
+            check(lib.opusgpu_launch_celt_pvq(st["celt"].data_ptr(), st["leaves"].data_ptr(), st["ncelt"], st["refs"].data_ptr(), st["classes"],
+                                              work.data_ptr(), None, front))
+            check(lib.opusgpu_launch_celt_spectrum(st["celt"].data_ptr(), st["ncelt"], work.data_ptr(), None, front))
+            join.record(side)
         for d in range(len(off) - 1):
             if off[d + 1] > off[d]:
                 check(lib.opusgpu_launch_silk(st["silk"].data_ptr() + off[d] * HS, off[d + 1] - off[d], sstate.data_ptr(), S, pcm.data_ptr(),
                                               stride, None, ps))
         if st["ncelt"]:
-            if st["run_len"]:
-                check(lib.opusgpu_launch_celt(st["celt"].data_ptr(), st["leaves"].data_ptr(), st["ncelt"], st["run_len"], st["refs"].data_ptr(),
-                                              st["classes"], work.data_ptr(), cstate.data_ptr(), pcm.data_ptr(), stride, None, ps))
+            if beside:
+                strm.wait_event(join)
             else:
-                check(lib.opusgpu_launch_celt_runs(st["celt"].data_ptr(), st["leaves"].data_ptr(), st["ncelt"], st["runs"].data_ptr(), st["nruns"],
-                                                   st["refs"].data_ptr(), st["classes"], work.data_ptr(), cstate.data_ptr(), pcm.data_ptr(),
-                                                   stride, None, ps))
+                check(lib.opusgpu_launch_celt_pvq(st["celt"].data_ptr(), st["leaves"].data_ptr(), st["ncelt"], st["refs"].data_ptr(), st["classes"],
+                                                  work.data_ptr(), None, ps))
+                check(lib.opusgpu_launch_celt_spectrum(st["celt"].data_ptr(), st["ncelt"], work.data_ptr(), None, ps))
+            if st["run_len"]:
+                check(lib.opusgpu_launch_celt_tail(st["celt"].data_ptr(), st["ncelt"], st["run_len"], work.data_ptr(), cstate.data_ptr(),
+                                                   pcm.data_ptr(), stride, None, ps))
+            else:
+                check(lib.opusgpu_launch_celt_tail_runs(st["celt"].data_ptr(), st["ncelt"], st["runs"].data_ptr(), st["nruns"], work.data_ptr(),
+                                                        cstate.data_ptr(), pcm.data_ptr(), stride, None, ps))
 
     torch.cuda.synchronize(dev)
     for k in range(W):

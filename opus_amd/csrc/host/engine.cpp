@@ -231,6 +231,8 @@ struct opusgpu_batch {
     float *d_pcm = nullptr;
     size_t pcm_stride = 0;
     bool pending = false;
+    hipStream_t side = nullptr;                             // the stateless CELT kernels of a mixed send run here, beside its SILK launches
+    hipEvent_t fork = nullptr, join = nullptr;
     hipEvent_t h2d_done = nullptr;                          // recorded behind the last H2D copy of batch_decode
     bool h2d_in_flight = false;                             // the pinned side-info may still be read by the copy engine
 
@@ -238,7 +240,10 @@ struct opusgpu_batch {
     {
         (void)hipSetDevice(device);
         if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
+        if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); }
         if (h2d_done) (void)hipEventDestroy(h2d_done);
+        if (fork) (void)hipEventDestroy(fork);
+        if (join) (void)hipEventDestroy(join);
         h_celt.release(); h_leaves.release(); h_silk.release(); h_refs.release(); h_runs.release();
         d_celt.release(); d_leaves.release(); d_silk.release(); d_refs.release(); d_runs.release(); d_work.release();
         if (d_celt_state) (void)hipFree(d_celt_state);
@@ -362,7 +367,10 @@ int opusgpu_batch_create(opusgpu_batch **out, uint32_t nstreams, int channels, i
     b->seen.assign(nstreams, 0);
     b->pcm_stride = size_t(OPUSGPU_MAX_FRAME) * channels;
     hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&b->h2d_done, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&b->fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&b->join, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc((void **)&b->d_celt_state, size_t(nstreams) * sizeof(OgCeltState));
     if (e == hipSuccess) e = hipMemsetAsync(b->d_celt_state, 0, size_t(nstreams) * sizeof(OgCeltState), b->stream);
     if (e == hipSuccess) e = hipMalloc(&b->d_silk_state, opusgpu_silk_state_bytes(nstreams));
@@ -562,21 +570,36 @@ int opusgpu_batch_decode(opusgpu_batch *b)
     OG_HIP(hipEventRecord(b->h2d_done, b->stream));
     b->h2d_in_flight = true;
     if (b->d_work.cap != work_had) OG_HIP(hipMemsetAsync(b->d_work.p, 0, b->d_work.cap, b->stream));   // zero once per (re)allocation
-    // SILK by depth (a stream's frames stay in order), then every CELT record of the send in one launch: decoder.rs:72-123's
-    // per-frame loop, cut where the data dependences are instead of where the packet boundaries are
+    // SILK by depth (a stream's frames stay in order), and every CELT record of the send in one launch: decoder.rs:72-123's
+    // per-frame loop, cut where the data dependences are instead of where the packet boundaries are.  K1, the plan and the
+    // spectrum kernel touch neither decoder state nor PCM: in a send that also has SILK frames they run on a side stream beside
+    // the SILK launches (which are latency-bound and leave most of the chip idle); the tail kernel, which adds hybrid frames'
+    // CELT part onto the SILK output, follows both.
+    const uint32_t cn = uint32_t(b->h_celt.n);
+    const bool beside = cn && b->h_silk.n;
+    if (beside) {
+        OG_HIP(hipEventRecord(b->fork, b->stream));
+        OG_HIP(hipStreamWaitEvent(b->side, b->fork, 0));
+        if ((rc = opusgpu_launch_celt_pvq(b->d_celt.p, b->d_leaves.p, cn, b->d_refs.p, b->ref_classes, b->d_work.p, nullptr, b->side))) return rc;
+        if ((rc = opusgpu_launch_celt_spectrum(b->d_celt.p, cn, b->d_work.p, nullptr, b->side))) return rc;
+        OG_HIP(hipEventRecord(b->join, b->side));
+    }
     for (size_t d = 0; d + 1 < b->silk_round_off.size(); d++) {
         const uint32_t s0 = b->silk_round_off[d], sn = b->silk_round_off[d + 1] - s0;
         if (sn && (rc = opusgpu_launch_silk(b->d_silk.p + s0, sn, b->d_silk_state, b->nstreams, b->d_pcm, b->pcm_stride, nullptr, b->stream)))
             return rc;
     }
-    const uint32_t cn = uint32_t(b->h_celt.n);
     if (cn) {
+        if (beside) OG_HIP(hipStreamWaitEvent(b->stream, b->join, 0));
+        else {
+            if ((rc = opusgpu_launch_celt_pvq(b->d_celt.p, b->d_leaves.p, cn, b->d_refs.p, b->ref_classes, b->d_work.p, nullptr, b->stream))) return rc;
+            if ((rc = opusgpu_launch_celt_spectrum(b->d_celt.p, cn, b->d_work.p, nullptr, b->stream))) return rc;
+        }
         if (offsets)
-            rc = opusgpu_launch_celt_runs(b->d_celt.p, b->d_leaves.p, cn, b->d_runs.p, b->nruns, b->d_refs.p, b->ref_classes, b->d_work.p,
-                                          b->d_celt_state, b->d_pcm, b->pcm_stride, nullptr, b->stream);
+            rc = opusgpu_launch_celt_tail_runs(b->d_celt.p, cn, b->d_runs.p, b->nruns, b->d_work.p, b->d_celt_state, b->d_pcm, b->pcm_stride,
+                                               nullptr, b->stream);
         else
-            rc = opusgpu_launch_celt(b->d_celt.p, b->d_leaves.p, cn, b->run_len, b->d_refs.p, b->ref_classes, b->d_work.p, b->d_celt_state,
-                                     b->d_pcm, b->pcm_stride, nullptr, b->stream);
+            rc = opusgpu_launch_celt_tail(b->d_celt.p, cn, b->run_len, b->d_work.p, b->d_celt_state, b->d_pcm, b->pcm_stride, nullptr, b->stream);
         if (rc) return rc;
     }
     b->pending = false;
