@@ -67,6 +67,12 @@ int opusgpu_decoder_configure(opusgpu_decoder *);
  * lost packet: the span of the last frame is concealed (the previous frame's overlap fades out, then silence) and the decoder
  * restarts on the next packet; the reference has no concealment and panics on an empty packet (packet.rs:215-225). */
 int opusgpu_decoder_send_packet(opusgpu_decoder *, const uint8_t *pkt, size_t len);
+/* In-band FEC recovery (RFC 6716 4.2.4-4.2.7; libopus' decode_fec) -- the reference returns Error::Unsupported at the LBRR
+ * flag (silk/decoder.rs:2070-2072): when a packet was lost and the NEXT one has arrived, send the next one here first.  Queues
+ * the lost packet's audio over the next packet's duration -- its LBRR frames (low-rate copies of the lost packet's SILK frames)
+ * decoded into the running decoder state; frames without a copy, the CELT part of a hybrid packet, and all of a CELT-only
+ * packet or one without LBRR frames are concealed as by send_packet(len 0) -- then call send_packet with the same packet. */
+int opusgpu_decoder_send_packet_fec(opusgpu_decoder *, const uint8_t *pkt, size_t len);
 /* Decoder::receive_frame (decoder.rs:128-132, unimplemented!() in the reference): pops the oldest
  * decoded packet as interleaved f32 @ 48 kHz.  OPUSGPU_MORE_DATA_NEEDED when the queue is empty. */
 int opusgpu_decoder_receive_frame(opusgpu_decoder *, float *pcm, size_t cap_floats, size_t *nsamples, int *channels);
@@ -131,6 +137,10 @@ int opusgpu_batch_send(opusgpu_batch *, const uint8_t *const *pkts, const uint32
  * frames_per_group), instead of one round of launches per frame.  No counterpart in the reference (one packet per call). */
 int opusgpu_batch_send_multi(opusgpu_batch *, const uint8_t *const *pkts, const uint32_t *lens, const uint32_t *stream_ids,
                              uint32_t nstreams, uint32_t packets_per_stream, int32_t *errors);
+/* opusgpu_decoder_send_packet_fec for a batch: every packet of the call is the successor of a lost packet of its stream; the
+ * send holds the lost packets' audio (decode it, read it, then send the same packets with opusgpu_batch_send). */
+int opusgpu_batch_send_fec(opusgpu_batch *, const uint8_t *const *pkts, const uint32_t *lens, const uint32_t *stream_ids,
+                           uint32_t n, int32_t *errors);
 /* Device half: H2D of the side-info, then the kernels, on the batch's HIP stream.  Asynchronous: the next batch_send
  * may follow at once (it waits for this call's H2D copies, not for its kernels, before it rewrites the staging arrays);
  * batch_pcm / batch_read results are valid after batch_sync (batch_read synchronises itself). */
@@ -194,6 +204,12 @@ int opusgpu_parser_parse(opusgpu_parser *, const uint8_t *pkt, size_t len, OgFra
                          OgCeltHdr *celt, uint32_t celt_cap, uint32_t *ncelt,
                          OgCeltLeaf *leaves, uint32_t leaf_cap, uint32_t *nleaves,
                          OgSilkFrame *silk, uint32_t silk_cap, uint32_t *nsilk);
+/* The same for in-band FEC recovery (opusgpu_decoder_send_packet_fec): pkt follows a lost packet; the records are the lost
+ * packet's audio as far as pkt's LBRR frames hold it. */
+int opusgpu_parser_parse_fec(opusgpu_parser *, const uint8_t *pkt, size_t len, OgFrameInfo *frames /* [48] */,
+                             OgCeltHdr *celt, uint32_t celt_cap, uint32_t *ncelt,
+                             OgCeltLeaf *leaves, uint32_t leaf_cap, uint32_t *nleaves,
+                             OgSilkFrame *silk, uint32_t silk_cap, uint32_t *nsilk);
 /* Packet::from_slice alone (packet.rs:202-317). */
 typedef struct {
     int32_t mode, bandwidth, frame_size, stereo, code, nframes, padding;

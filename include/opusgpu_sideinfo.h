@@ -156,7 +156,9 @@ enum {                       /* OgSilkFrame.flags */
     OG_SF_STEREO = 1,        /* packet codes mid + side (silk/decoder.rs:1946) */
     OG_SF_STEREO_OUT = 2,    /* stream has two output channels (silk/decoder.rs:1916) */
     OG_SF_MID_ONLY = 4,      /* side not coded in this frame (silk/decoder.rs:2005-2009) */
-    OG_SF_RESAMPLER_RESET = 8/* clear the 48 kHz resampler history first (stream start / after a CELT-only packet) */
+    OG_SF_RESAMPLER_RESET = 8,/* clear the 48 kHz resampler history first (stream start / after a CELT-only packet) */
+    OG_SF_CONCEAL = 16       /* a frame with nothing to decode (in-band FEC recovery of a packet whose successor carries no LBRR
+                                copy of this frame, RFC 6716 4.2.4): silence at the internal rate, through the resampler */
 };
 
 typedef struct {             /* one SILK frame (mid + side) of one stream */

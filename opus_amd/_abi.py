@@ -95,6 +95,7 @@ PROTOTYPES = {
     "opusgpu_decoder_set_extradata": (C.c_int, [_P, C.c_char_p, C.c_size_t]),
     "opusgpu_decoder_configure": (C.c_int, [_P]),
     "opusgpu_decoder_send_packet": (C.c_int, [_P, C.c_char_p, C.c_size_t]),
+    "opusgpu_decoder_send_packet_fec": (C.c_int, [_P, C.c_char_p, C.c_size_t]),
     "opusgpu_decoder_receive_frame": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
     "opusgpu_decoder_flush": (C.c_int, [_P]),
     "opusgpu_opus_head_parse": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(OpusHead)]),
@@ -105,6 +106,7 @@ PROTOTYPES = {
     "opusgpu_batch_create": (C.c_int, [C.POINTER(_P), C.c_uint32, C.c_int, C.c_int]),
     "opusgpu_batch_destroy": (None, [_P]),
     "opusgpu_batch_send": (C.c_int, [_P, C.POINTER(C.c_char_p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_int32)]),
+    "opusgpu_batch_send_fec": (C.c_int, [_P, C.POINTER(C.c_char_p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_int32)]),
     "opusgpu_batch_send_multi": (C.c_int, [_P, C.POINTER(C.c_char_p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32,
                                            C.POINTER(C.c_int32)]),
     "opusgpu_batch_decode": (C.c_int, [_P]),
@@ -121,6 +123,9 @@ PROTOTYPES = {
     "opusgpu_parser_parse": (C.c_int, [_P, C.c_char_p, C.c_size_t, C.POINTER(FrameInfo), C.POINTER(CeltHdr), C.c_uint32,
                                       C.POINTER(C.c_uint32), C.POINTER(CeltLeaf), C.c_uint32, C.POINTER(C.c_uint32),
                                       C.POINTER(SilkFrame), C.c_uint32, C.POINTER(C.c_uint32)]),
+    "opusgpu_parser_parse_fec": (C.c_int, [_P, C.c_char_p, C.c_size_t, C.POINTER(FrameInfo), C.POINTER(CeltHdr), C.c_uint32,
+                                          C.POINTER(C.c_uint32), C.POINTER(CeltLeaf), C.c_uint32, C.POINTER(C.c_uint32),
+                                          C.POINTER(SilkFrame), C.c_uint32, C.POINTER(C.c_uint32)]),
     "opusgpu_packet_parse": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(Packet)]),
     "opusgpu_packet_undelimit": (C.c_int, [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
     "opusgpu_init": (C.c_int, [C.c_int]),

@@ -384,7 +384,9 @@ OG_DEV void og_silk_output(const OgSilkFrame *f, const OgSilkArrays &A, const Og
         const int c = q >> 5, i = q & 31;
         L.x[c][i] = rs_reset ? 0.f : hist[c * 32 + i];
     }
-    if (stereo && stereo_out) {                                              // unmix_ms, silk/decoder.rs:2012-2061
+    if (f->flags & OG_SF_CONCEAL) {                                          // nothing to decode for this frame: silence in
+        for (int i = tid; i < fs; i += OG_WG) { L.x[0][32 + i] = 0.f; L.x[1][32 + i] = 0.f; }
+    } else if (stereo && stereo_out) {                                       // unmix_ms, silk/decoder.rs:2012-2061
         const float w0 = f->w0, w1 = f->w1, w0p = f->prev_w0, w1p = f->prev_w1;
         const int n1 = bw == 0 ? 64 : bw == 1 ? 96 : 128;
         const float w0d = (w0 - w0p) / (float)n1, w1d = (w1 - w1p) / (float)n1;

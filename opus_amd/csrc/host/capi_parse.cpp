@@ -71,14 +71,14 @@ int opusgpu_parser_create(opusgpu_parser **out, int channels)
 void opusgpu_parser_destroy(opusgpu_parser *p) { delete p; }
 void opusgpu_parser_reset(opusgpu_parser *p) { if (p) p->sp.reset(); }
 
-int opusgpu_parser_parse(opusgpu_parser *p, const uint8_t *pkt, size_t len, OgFrameInfo *frames,
-                         OgCeltHdr *celt, uint32_t celt_cap, uint32_t *ncelt,
-                         OgCeltLeaf *leaves, uint32_t leaf_cap, uint32_t *nleaves,
-                         OgSilkFrame *silk, uint32_t silk_cap, uint32_t *nsilk)
+static int parser_parse(opusgpu_parser *p, bool fec, const uint8_t *pkt, size_t len, OgFrameInfo *frames,
+                        OgCeltHdr *celt, uint32_t celt_cap, uint32_t *ncelt,
+                        OgCeltLeaf *leaves, uint32_t leaf_cap, uint32_t *nleaves,
+                        OgSilkFrame *silk, uint32_t silk_cap, uint32_t *nsilk)
 {
     if (!p || !frames || !ncelt || !nleaves || !nsilk) return OPUSGPU_BAD_ARG;
     p->celt.clear(); p->leaves.clear(); p->silk.clear();
-    int n = p->sp.parse(pkt, len, frames, p->celt, p->leaves, p->silk);
+    int n = fec ? p->sp.parse_fec(pkt, len, frames, p->celt, p->leaves, p->silk) : p->sp.parse(pkt, len, frames, p->celt, p->leaves, p->silk);
     if (n < 0) return n;
     if (*ncelt + p->celt.size() > celt_cap || *nleaves + p->leaves.size() > leaf_cap || *nsilk + p->silk.size() > silk_cap)
         return OPUSGPU_BAD_ARG;
@@ -89,6 +89,22 @@ int opusgpu_parser_parse(opusgpu_parser *p, const uint8_t *pkt, size_t len, OgFr
     if (!p->silk.empty()) std::memcpy(silk + *nsilk, p->silk.data(), p->silk.size() * sizeof(OgSilkFrame));
     *ncelt += uint32_t(p->celt.size()); *nleaves += uint32_t(p->leaves.size()); *nsilk += uint32_t(p->silk.size());
     return n;
+}
+
+int opusgpu_parser_parse(opusgpu_parser *p, const uint8_t *pkt, size_t len, OgFrameInfo *frames,
+                         OgCeltHdr *celt, uint32_t celt_cap, uint32_t *ncelt,
+                         OgCeltLeaf *leaves, uint32_t leaf_cap, uint32_t *nleaves,
+                         OgSilkFrame *silk, uint32_t silk_cap, uint32_t *nsilk)
+{
+    return parser_parse(p, false, pkt, len, frames, celt, celt_cap, ncelt, leaves, leaf_cap, nleaves, silk, silk_cap, nsilk);
+}
+
+int opusgpu_parser_parse_fec(opusgpu_parser *p, const uint8_t *pkt, size_t len, OgFrameInfo *frames,
+                             OgCeltHdr *celt, uint32_t celt_cap, uint32_t *ncelt,
+                             OgCeltLeaf *leaves, uint32_t leaf_cap, uint32_t *nleaves,
+                             OgSilkFrame *silk, uint32_t silk_cap, uint32_t *nsilk)
+{
+    return parser_parse(p, true, pkt, len, frames, celt, celt_cap, ncelt, leaves, leaf_cap, nleaves, silk, silk_cap, nsilk);
 }
 
 size_t opusgpu_sizeof_celt_state(void) { return sizeof(OgCeltState); }

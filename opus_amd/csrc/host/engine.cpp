@@ -387,7 +387,7 @@ void opusgpu_batch_destroy(opusgpu_batch *b) { delete b; }
 
 // n streams, T consecutive packets each: packet t of the i-th stream of the call is pkts[i * T + t]
 static int batch_send_impl(opusgpu_batch *b, const uint8_t *const *pkts, const uint32_t *lens, const uint32_t *stream_ids,
-                           uint32_t n, uint32_t T, int32_t *errors)
+                           uint32_t n, uint32_t T, int32_t *errors, bool fec = false)
 {
     if (!b || T == 0 || (n && (!pkts || !lens))) return OPUSGPU_BAD_ARG;
     std::fill(b->seen.begin(), b->seen.end(), 0);
@@ -443,21 +443,9 @@ static int batch_send_impl(opusgpu_batch *b, const uint8_t *const *pkts, const u
                 pp.stream = stream_ids ? stream_ids[i] : i;
                 pp.worker = w;
                 pp.celt0 = W.celt.size(); pp.leaf0 = W.leaves.size(); pp.silk0 = W.silk.size();
-                pp.rc = b->parsers[pp.stream].parse(pkts[size_t(i) * T + t], lens[size_t(i) * T + t], pp.fi, W.celt, W.leaves, W.silk);
-                if (pp.rc >= 0) {
-                    // the records of an Opus frame name the launch round each belongs to (OG_ROUND_*, for hosts that run a round of
-                    // launches per frame): never two of one stream in one round -- they would read-modify-write its state side by side
-                    bool clash = false;
-                    for (int f = 0; f < pp.rc && !clash; f++) {
-                        uint32_t used = 0;
-                        for (uint32_t c = 0; c < pp.fi[f].has_celt; c++) {
-                            const uint32_t bit = 1u << (W.celt[pp.fi[f].celt_index + c].spread >> OG_ROUND_SHIFT);
-                            clash = clash || (used & bit);
-                            used |= bit;
-                        }
-                    }
-                    if (clash) pp.rc = OPUSGPU_INVALID_DATA;
-                }
+                og::StreamParser &sp = b->parsers[pp.stream];
+                pp.rc = fec ? sp.parse_fec(pkts[size_t(i) * T + t], lens[size_t(i) * T + t], pp.fi, W.celt, W.leaves, W.silk)
+                            : sp.parse(pkts[size_t(i) * T + t], lens[size_t(i) * T + t], pp.fi, W.celt, W.leaves, W.silk);
                 if (pp.rc < 0) {                        // a bad packet never poisons the batch
                     W.celt.resize(pp.celt0); W.leaves.resize(pp.leaf0); W.silk.resize(pp.silk0);
                 } else {
@@ -541,6 +529,12 @@ extern "C" int opusgpu_batch_send(opusgpu_batch *b, const uint8_t *const *pkts, 
                                   uint32_t n, int32_t *errors)
 {
     return batch_send_impl(b, pkts, lens, stream_ids, n, 1, errors);
+}
+
+extern "C" int opusgpu_batch_send_fec(opusgpu_batch *b, const uint8_t *const *pkts, const uint32_t *lens, const uint32_t *stream_ids,
+                                      uint32_t n, int32_t *errors)
+{
+    return batch_send_impl(b, pkts, lens, stream_ids, n, 1, errors, true);
 }
 
 extern "C" int opusgpu_batch_send_multi(opusgpu_batch *b, const uint8_t *const *pkts, const uint32_t *lens, const uint32_t *stream_ids,
@@ -855,6 +849,33 @@ int opusgpu_decoder_send_packet(opusgpu_decoder *d, const uint8_t *pkt, size_t l
         out.resize(n * d->channels);
     }
     if (d->skip_left) {                                 // RFC 7845 4.2: the first pre_skip samples are decoder warm-up
+        const size_t drop = std::min<size_t>(d->skip_left, n);
+        out.erase(out.begin(), out.begin() + drop * d->channels);
+        d->skip_left -= uint32_t(drop);
+    }
+    if (d->out_gain != 1.f) for (float &v : out) v *= d->out_gain;
+    d->queue.push_back(std::move(out));
+    return OPUSGPU_OK;
+}
+
+int opusgpu_decoder_send_packet_fec(opusgpu_decoder *d, const uint8_t *pkt, size_t len)
+{
+    if (!d) return OPUSGPU_BAD_ARG;
+    if (!d->configured) return OPUSGPU_CONFIG_INCOMPLETE;
+    if (len > 0xFFFFFFFFu) return OPUSGPU_INVALID_DATA;
+    if (d->multi) return OPUSGPU_UNSUPPORTED;           // (multistream: send the lost packet as len 0)
+    const uint8_t *pk[1] = {pkt};
+    uint32_t ln[1] = {uint32_t(len)};
+    int32_t err = 0;
+    int rc = opusgpu_batch_send_fec(d->batch, pk, ln, nullptr, 1, &err);
+    if (rc) return rc;
+    if (err) return err;
+    if ((rc = opusgpu_batch_decode(d->batch))) return rc;
+    std::vector<float> out(size_t(OPUSGPU_MAX_FRAME) * d->channels);
+    size_t n = 0;
+    if ((rc = opusgpu_batch_read(d->batch, 0, out.data(), out.size(), &n))) return rc;
+    out.resize(n * d->channels);
+    if (d->skip_left) {
         const size_t drop = std::min<size_t>(d->skip_left, n);
         out.erase(out.begin(), out.begin() + drop * d->channels);
         d->skip_left -= uint32_t(drop);

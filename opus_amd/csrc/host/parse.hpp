@@ -59,8 +59,10 @@ struct SilkHostState {
 };
 // Parses the SILK part of one Opus frame (1-3 internal 20 ms frames); appends one OgSilkFrame each.
 // Returns number of internal frames, or <0.  LBRR frames (where the reference returns Unsupported, silk/decoder.rs:2070) are
-// parsed and dropped.
+// parsed and dropped -- or, with `fec`, decoded IN PLACE of the regular frames, which are then not read: the packet's LBRR frames
+// are the previous packet's audio (RFC 6716 4.2.4-4.2.7; libopus' decode_fec), recovered into the running decoder state; a 20 ms
+// frame without an LBRR copy comes out as an OG_SF_CONCEAL record.
 int silk_parse(SilkHostState &st, RangeDec &rd, int bandwidth, int duration_ms, int stereo_pkt,
-               std::vector<OgSilkFrame> &out);
+               std::vector<OgSilkFrame> &out, bool fec = false);
 
 }  // namespace og

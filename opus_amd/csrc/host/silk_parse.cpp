@@ -373,7 +373,7 @@ struct ChanParser {
 
 }  // namespace
 
-int silk_parse(SilkHostState &st, RangeDec &rd, int bw, int duration_ms, int stereo, std::vector<OgSilkFrame> &out)
+int silk_parse(SilkHostState &st, RangeDec &rd, int bw, int duration_ms, int stereo, std::vector<OgSilkFrame> &out, bool fec)
 {
     // Silk::setup (silk/decoder.rs:1942-1977)
     const int frames = duration_ms <= 20 ? 1 : duration_ms / 20;
@@ -398,6 +398,79 @@ int silk_parse(SilkHostState &st, RangeDec &rd, int bw, int duration_ms, int ste
         const int sym = frames == 1 ? 1 : rd.icdf_table(frames == 2 ? kLbrr40 : kLbrr60);
         for (int i = 0; i < frames; i++) lbrr[ch][i] = (sym >> i) & 1;
     }
+    auto new_frame = [&]() -> OgSilkFrame & {
+        out.emplace_back();
+        OgSilkFrame &f = out.back();
+        std::memset(&f, 0, sizeof f);
+        f.bandwidth = uint8_t(bw);
+        f.f_size = uint16_t(sf_size * subframes);
+        f.flags = uint8_t((stereo ? OG_SF_STEREO : 0) | (st.stereo_out ? OG_SF_STEREO_OUT : 0));
+        if (st.resampler_reset) { f.flags |= OG_SF_RESAMPLER_RESET; st.resampler_reset = false; }
+        f.prev_w0 = st.prev_w0;
+        f.prev_w1 = st.prev_w1;
+        return f;
+    };
+    auto stereo_weights = [&]() {                        // parse_stereo_weight, :1979-2010
+        static const int kW[16] = {-13732, -10050, -8266, -7526, -6500, -5000, -2950, -820,
+                                   820, 2950, 5000, 6500, 7526, 8266, 10050, 13732};
+        const int n = rd.icdf(ICDF_SILK_STEREO_STAGE1);
+        const int i0 = rd.icdf(ICDF_SILK_STEREO_STAGE2) + 3 * (n / 5);
+        const int i1 = rd.icdf(ICDF_SILK_STEREO_STAGE3) * 2 + 1;
+        const int i2 = rd.icdf(ICDF_SILK_STEREO_STAGE2) + 3 * (n % 5);
+        const int i3 = rd.icdf(ICDF_SILK_STEREO_STAGE3) * 2 + 1;
+        const int w0 = kW[i0] + (((kW[i0 + 1] - kW[i0]) * 6554) >> 16) * i1;
+        const int w1 = kW[i2] + (((kW[i2 + 1] - kW[i2]) * 6554) >> 16) * i3;
+        st.w0 = float(w0 - w1) / 8192.f;
+        st.w1 = float(w1) / 8192.f;
+    };
+    auto side_absent = [&](OgSilkFrame &f, bool midonly) {
+        // side absent: the reference flushes it when mid-only (silk/decoder.rs:2097-2099); the device clears the
+        // side history on OG_S_RESET without OG_S_CODED
+        std::memset(&f.ch[1], 0, sizeof f.ch[1]);
+        f.ch[1].order = f.ch[0].order; f.ch[1].subframes = uint8_t(subframes); f.ch[1].sf_size = uint8_t(sf_size);
+        if (midonly) {
+            f.flags |= OG_SF_MID_ONLY;
+            if (st.side.coded) st.side.flush();
+            f.ch[1].flags = OG_S_RESET;                 // unmix_ms of this very frame reads the cleared side history
+            st.side.flushed = false;
+        }
+    };
+    if (fec) {
+        // In-band FEC recovery (RFC 6716 4.2.4-4.2.7; the reference stops at the LBRR flag, silk/decoder.rs:2070-2072): the LBRR
+        // frames of this packet are low-rate copies of the PREVIOUS packet's frames.  They are decoded into the running state in
+        // place of the lost packet; the caller sends the packet again, plainly, for its own audio.
+        SilkChanHost scratch;
+        OgSilkChan dropped;
+        for (int i = 0; i < frames; i++) {
+            OgSilkFrame &f = new_frame();
+            if (lbrr[0][i]) {
+                bool midonly = false;
+                if (stereo) {
+                    stereo_weights();
+                    if (!lbrr[1][i]) midonly = rd.icdf(ICDF_SILK_MID_ONLY) != 0;
+                }
+                f.w0 = st.w0;
+                f.w1 = st.w1;
+                ChanParser{st.mid, rd, f.ch[0]}.frame(bw, subframes, sf_size, true, i == 0 || !lbrr[0][i - 1]);
+                if (stereo && lbrr[1][i]) ChanParser{st.side, rd, f.ch[1]}.frame(bw, subframes, sf_size, true, i == 0 || !lbrr[1][i - 1]);
+                else side_absent(f, midonly);
+                if (stereo && st.stereo_out) { st.prev_w0 = st.w0; st.prev_w1 = st.w1; }
+            } else {
+                // no copy of this frame: silence, and both channels start over (a side-only copy is read past)
+                if (stereo && lbrr[1][i]) ChanParser{scratch, rd, dropped}.frame(bw, subframes, sf_size, true, i == 0 || !lbrr[1][i - 1]);
+                f.flags |= OG_SF_CONCEAL;
+                f.w0 = st.w0;
+                f.w1 = st.w1;
+                st.mid.flush(); st.side.flush();
+                for (int c = 0; c < 2; c++) {
+                    f.ch[c].order = uint8_t(bw == 2 ? 16 : 10); f.ch[c].subframes = uint8_t(subframes); f.ch[c].sf_size = uint8_t(sf_size);
+                    f.ch[c].flags = OG_S_RESET;
+                }
+                st.mid.flushed = st.side.flushed = false;
+            }
+        }
+        return frames;
+    }
     if (any_lbrr[0] || any_lbrr[1]) {
         SilkChanHost scratch[2];
         OgSilkChan dropped;
@@ -414,48 +487,18 @@ int silk_parse(SilkHostState &st, RangeDec &rd, int bw, int duration_ms, int ste
             }
     }
     for (int i = 0; i < frames; i++) {
-        out.emplace_back();
-        OgSilkFrame &f = out.back();
-        std::memset(&f, 0, sizeof f);
-        f.bandwidth = uint8_t(bw);
-        f.f_size = uint16_t(sf_size * subframes);
-        f.flags = uint8_t((stereo ? OG_SF_STEREO : 0) | (st.stereo_out ? OG_SF_STEREO_OUT : 0));
-        if (st.resampler_reset) { f.flags |= OG_SF_RESAMPLER_RESET; st.resampler_reset = false; }
+        OgSilkFrame &f = new_frame();
         const bool first = i == 0;
         bool midonly = false;
-        f.prev_w0 = st.prev_w0;
-        f.prev_w1 = st.prev_w1;
-        if (stereo) {                                                        // parse_stereo_weight, :1979-2010
-            static const int kW[16] = {-13732, -10050, -8266, -7526, -6500, -5000, -2950, -820,
-                                       820, 2950, 5000, 6500, 7526, 8266, 10050, 13732};
-            const int n = rd.icdf(ICDF_SILK_STEREO_STAGE1);
-            const int i0 = rd.icdf(ICDF_SILK_STEREO_STAGE2) + 3 * (n / 5);
-            const int i1 = rd.icdf(ICDF_SILK_STEREO_STAGE3) * 2 + 1;
-            const int i2 = rd.icdf(ICDF_SILK_STEREO_STAGE2) + 3 * (n % 5);
-            const int i3 = rd.icdf(ICDF_SILK_STEREO_STAGE3) * 2 + 1;
-            const int w0 = kW[i0] + (((kW[i0 + 1] - kW[i0]) * 6554) >> 16) * i1;
-            const int w1 = kW[i2] + (((kW[i2 + 1] - kW[i2]) * 6554) >> 16) * i3;
-            st.w0 = float(w0 - w1) / 8192.f;
-            st.w1 = float(w1) / 8192.f;
+        if (stereo) {
+            stereo_weights();
             midonly = side_vad[i] ? false : rd.icdf(ICDF_SILK_MID_ONLY) != 0;
         }
         f.w0 = st.w0;
         f.w1 = st.w1;
         ChanParser{st.mid, rd, f.ch[0]}.frame(bw, subframes, sf_size, mid_vad[i], first);
-        if (stereo && !midonly) {
-            ChanParser{st.side, rd, f.ch[1]}.frame(bw, subframes, sf_size, side_vad[i], first);
-        } else {
-            // side absent: the reference flushes it when mid-only (silk/decoder.rs:2097-2099); the device clears the
-            // side history on OG_S_RESET without OG_S_CODED
-            std::memset(&f.ch[1], 0, sizeof f.ch[1]);
-            f.ch[1].order = f.ch[0].order; f.ch[1].subframes = uint8_t(subframes); f.ch[1].sf_size = uint8_t(sf_size);
-            if (midonly) {
-                f.flags |= OG_SF_MID_ONLY;
-                if (st.side.coded) st.side.flush();
-                f.ch[1].flags = OG_S_RESET;             // unmix_ms of this very frame reads the cleared side history
-                st.side.flushed = false;
-            }
-        }
+        if (stereo && !midonly) ChanParser{st.side, rd, f.ch[1]}.frame(bw, subframes, sf_size, side_vad[i], first);
+        else side_absent(f, midonly);
         if (stereo && st.stereo_out) {                                       // unmix_ms consumes then updates prev (:2058-2059)
             st.prev_w0 = st.w0;
             st.prev_w1 = st.w1;

@@ -167,4 +167,69 @@ int StreamParser::parse(const uint8_t *pkt, size_t len, OgFrameInfo *frames, std
     return p.nframes;
 }
 
+int StreamParser::parse_fec(const uint8_t *pkt, size_t len, OgFrameInfo *frames, std::vector<OgCeltHdr> &celt,
+                            std::vector<OgCeltLeaf> &leaves, std::vector<OgSilkFrame> &silk)
+{
+    Packet p;
+    if (len == 0 || len > 0x7FFFFFFF) return parse(nullptr, 0, frames, celt, leaves, silk);
+    int rc = parse_packet(pkt, int(len), &p);
+    if (rc) return rc;
+    bool any = false;                                   // does any frame of the packet carry LBRR frames?  (the flag behind the VAD flags)
+    for (int f = 0; f < p.nframes && p.mode != MODE_CELT; f++) {
+        if (p.len[f] == 0) continue;
+        RangeDec rd(pkt + p.off[f], uint32_t(p.len[f]));
+        const int nsf = p.frame_size <= 960 ? 1 : p.frame_size / 960;
+        for (int i = 0; i < nsf; i++) (void)rd.bit_logp(1);
+        bool a = rd.bit_logp(1);
+        if (p.stereo) {
+            for (int i = 0; i < nsf; i++) (void)rd.bit_logp(1);
+            a = rd.bit_logp(1) || a;
+        }
+        any = any || a;
+    }
+    if (!any) {                                         // nothing to recover from: the span of this packet is concealed
+        last_packet_samples_ = p.nframes * p.frame_size;
+        return parse(nullptr, 0, frames, celt, leaves, silk);
+    }
+    // as a packet of this mode would start (see parse()); no redundancy information is available for the lost packet
+    if (p.mode != prev_mode_ && prev_mode_ == MODE_CELT) { silk_.flush(); silk_.resampler_reset = true; }
+    if (p.mode != prev_mode_ && prev_mode_ >= 0 && !prev_redundancy_ && p.mode != MODE_SILK) celt_.reset();
+    static const uint8_t kSilence[2] = {0xFF, 0xFF};
+    for (int f = 0; f < p.nframes; f++) {
+        const int N = p.frame_size;
+        OgFrameInfo &fi = frames[f];
+        std::memset(&fi, 0, sizeof fi);
+        fi.mode = uint8_t(p.mode);
+        fi.bandwidth = uint8_t(p.bandwidth);
+        fi.stereo = uint8_t(p.stereo);
+        fi.frame_size = uint16_t(N);
+        fi.celt_index = uint32_t(celt.size());
+        fi.silk_index = uint32_t(silk.size());
+        RangeDec rd(pkt + p.off[f], uint32_t(p.len[f]));
+        const int n = silk_parse(silk_, rd, std::min(p.bandwidth, int(BW_WB)), N / 48, p.stereo, silk, true);
+        if (n < 0) return n;
+        fi.nsilk = uint8_t(n);
+        if (p.mode == MODE_HYBRID || prev_mode_ != MODE_SILK) {
+            // the CELT part of a hybrid frame is not in the LBRR copy, and after CELT / hybrid audio the MDCT overlap has to fade
+            // out: silent CELT frames over the span, added onto the SILK output (as after a loss)
+            for (int o = 0, M; o < N; o += M) {
+                M = N - o >= 960 ? 960 : N - o >= 480 ? 480 : N - o >= 240 ? 240 : 120;
+                RangeDec r(kSilence, 2);
+                celt.emplace_back();
+                (void)celt_parse_frame(celt_, r, M, 0, 21, channels_, &celt.back(), leaves);
+                celt.back().flags |= OG_F_ACCUM;
+                celt.back().pcm_off = uint32_t(o);
+                celt.back().spread = uint8_t((celt.back().spread & OG_SPREAD_MASK) | OG_ROUND_MAIN << OG_ROUND_SHIFT);
+                fi.has_celt++;
+            }
+        }
+        fi.tell_bits = uint32_t(rd.tell());
+        fi.budget_bits = uint32_t(rd.storage_bits());
+        prev_mode_ = p.mode;
+    }
+    prev_redundancy_ = false;
+    last_packet_samples_ = p.nframes * p.frame_size;
+    return p.nframes;
+}
+
 }  // namespace og

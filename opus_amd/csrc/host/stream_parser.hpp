@@ -16,6 +16,12 @@ public:
     // Parses one packet, appending records.  Returns the number of Opus frames or a negative OPUSGPU_* code.
     int parse(const uint8_t *pkt, size_t len, OgFrameInfo *frames /*[48]*/, std::vector<OgCeltHdr> &celt,
               std::vector<OgCeltLeaf> &leaves, std::vector<OgSilkFrame> &silk);
+    // In-band FEC recovery (RFC 6716 4.2.4-4.2.7; libopus' decode_fec; the reference returns Unsupported at an LBRR flag,
+    // silk/decoder.rs:2070-2072): pkt is the packet FOLLOWING a lost one.  Emits the lost packet's audio -- this packet's LBRR
+    // frames decoded into the running state, over this packet's duration; the CELT part of a hybrid packet, and everything of a
+    // packet without LBRR frames, is concealed as after a loss.  The caller then parses pkt itself with parse().
+    int parse_fec(const uint8_t *pkt, size_t len, OgFrameInfo *frames /*[48]*/, std::vector<OgCeltHdr> &celt,
+                  std::vector<OgCeltLeaf> &leaves, std::vector<OgSilkFrame> &silk);
 
 private:
     int channels_;

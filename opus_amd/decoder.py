@@ -105,6 +105,12 @@ class Decoder:
         b = bytes(pkt)
         _chk(self._lib.opusgpu_decoder_send_packet(self._h, b, len(b)), "send_packet")
 
+    def send_packet_fec(self, pkt):
+        """pkt = the packet FOLLOWING a lost one: queues the lost packet's audio recovered from pkt's LBRR frames (in-band FEC);
+        send pkt itself with send_packet() afterwards."""
+        b = bytes(pkt)
+        _chk(self._lib.opusgpu_decoder_send_packet_fec(self._h, b, len(b)), "send_packet_fec")
+
     def receive_frame(self):
         n = C.c_size_t()
         ch = C.c_int()
@@ -136,15 +142,16 @@ class BatchDecoder:
         self._h = C.c_void_p()
         _chk(self._lib.opusgpu_batch_create(C.byref(self._h), nstreams, channels, device), "batch_create")
 
-    def send(self, packets, stream_ids=None):
-        """packets: list of bytes; returns per-packet error codes (0 = ok)."""
+    def send(self, packets, stream_ids=None, fec=False):
+        """packets: list of bytes; returns per-packet error codes (0 = ok).  fec: the packets are the successors of lost packets,
+        whose audio is recovered from their LBRR frames (opusgpu_batch_send_fec)."""
         n = len(packets)
         keep = [bytes(p) for p in packets]
         arr = (C.c_char_p * n)(*keep)
         lens = (C.c_uint32 * n)(*[len(p) for p in keep])
         ids = (C.c_uint32 * n)(*stream_ids) if stream_ids is not None else None
         errs = (C.c_int32 * n)()
-        _chk(self._lib.opusgpu_batch_send(self._h, arr, lens, ids, n, errs), "batch_send")
+        _chk((self._lib.opusgpu_batch_send_fec if fec else self._lib.opusgpu_batch_send)(self._h, arr, lens, ids, n, errs), "batch_send")
         return list(errs)
 
     def send_packed(self, packets, lens=None):

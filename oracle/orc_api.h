@@ -72,6 +72,7 @@ void orc_silk_destroy(OrcSilk *);
 void orc_silk_flush(OrcSilk *);
 /* bandwidth: 0 NB, 1 MB, 2 WB; duration_ms 10/20/40/60; returns samples/channel or <0 */
 int orc_silk_decode(OrcSilk *, OrcRd *, int bandwidth, int duration_ms, int stereo_pkt, float *left, float *right);
+int orc_silk_decode_fec(OrcSilk *, OrcRd *, int bandwidth, int duration_ms, int stereo_pkt, float *left, float *right);
 void orc_lsf_to_lpc(const int16_t *nlsf, int order, float *lpc);
 
 /* entropy KAT shims */
@@ -95,6 +96,7 @@ uint32_t orc_decoder_final_range(const OrcDecoder *);   /* last frame: main rang
 void orc_decoder_set_celt_trace(OrcDecoder *, OrcCeltTrace *);
 /* decode one packet -> interleaved f32 @48 kHz; returns samples per channel, <0 on error */
 int orc_decoder_decode(OrcDecoder *, const uint8_t *pkt, int len, float *pcm, int cap_samples);
+int orc_decoder_decode_fec(OrcDecoder *, const uint8_t *pkt, int len, float *pcm, int cap_samples);
 /* 8/12/16 kHz -> 48 kHz polyphase FIR used by the decoder (build's own design) */
 void orc_resample_to_48k(const float *in, int n_in, int rate_khz, float *hist /*[32]*/, float *out);
 

@@ -320,4 +320,70 @@ int orc_decoder_decode(OrcDecoder *d, const uint8_t *pkt, int len, float *pcm, i
     return total;
 }
 
+/* In-band FEC recovery (RFC 6716 4.2.4-4.2.7; libopus' decode_fec; no counterpart in the reference, which returns Unsupported at
+ * the LBRR flag, silk/decoder.rs:2070-2072): pkt is the packet FOLLOWING a lost one.  Returns the lost packet's audio over pkt's
+ * duration: pkt's LBRR frames decoded into the running state; the CELT part of a hybrid packet, and everything of a packet
+ * without LBRR frames, concealed as after a loss.  The caller decodes pkt itself afterwards. */
+int orc_decoder_decode_fec(OrcDecoder *d, const uint8_t *pkt, int len, float *pcm, int cap)
+{
+    OrcPacket p;
+    if (len <= 0) return orc_decoder_decode(d, NULL, 0, pcm, cap);
+    if (orc_packet_parse(pkt, len, &p)) return -1;
+    int any = 0;
+    for (int f = 0; f < p.nframes && p.mode != 2; f++) {
+        if (p.len[f] == 0) continue;
+        OrcRd rd;
+        orc_rd_init(&rd, pkt + p.off[f], p.len[f]);
+        int nsf = p.frame_size <= 960 ? 1 : p.frame_size / 960, a;
+        for (int i = 0; i < nsf; i++) (void)orc_rd_logp(&rd, 1);
+        a = orc_rd_logp(&rd, 1);
+        if (p.stereo) {
+            for (int i = 0; i < nsf; i++) (void)orc_rd_logp(&rd, 1);
+            a |= orc_rd_logp(&rd, 1);
+        }
+        any |= a;
+    }
+    if (!any) {
+        d->last_frame_size = p.nframes * p.frame_size;
+        return orc_decoder_decode(d, NULL, 0, pcm, cap);
+    }
+    int CC = d->channels, total = p.nframes * p.frame_size;
+    if (total > cap) return -3;
+    static const int silk_rate[3] = {8, 12, 16};
+    static const uint8_t silence[2] = {0xFF, 0xFF};
+    if (p.mode != d->prev_mode && d->prev_mode == 2) { orc_silk_flush(d->silk); memset(d->rs_hist, 0, sizeof d->rs_hist); }
+    if (p.mode != d->prev_mode && d->prev_mode >= 0 && !d->prev_redundancy && p.mode != 0) orc_celt_reset(d->celt);
+    for (int f = 0; f < p.nframes; f++) {
+        OrcRd rd;
+        int N = p.frame_size;
+        float *dst = pcm + (size_t)f * N * CC;
+        float ch[2][2880], sl[960], sr[960];
+        memset(ch, 0, sizeof ch);
+        orc_rd_init(&rd, pkt + p.off[f], p.len[f]);
+        int bw = p.bandwidth < 2 ? p.bandwidth : 2;
+        int n = orc_silk_decode_fec(d->silk, &rd, bw, N / 48, p.stereo, sl, sr);
+        if (n < 0) return n;
+        if (CC == 2) {
+            orc_resample_to_48k(sl, n, silk_rate[bw], d->rs_hist[0], ch[0]);
+            orc_resample_to_48k(sr, n, silk_rate[bw], d->rs_hist[1], ch[1]);
+        } else orc_resample_to_48k(sr, n, silk_rate[bw], d->rs_hist[0], ch[0]);
+        if (p.mode == 1 || d->prev_mode != 0) {          /* the CELT part is not in the copy; a running MDCT overlap fades out */
+            for (int o = 0, M; o < N; o += M) {
+                M = N - o >= 960 ? 960 : N - o >= 480 ? 480 : N - o >= 240 ? 240 : 120;
+                float c0[960], c1[960];
+                OrcRd r;
+                orc_rd_init(&r, silence, 2);
+                orc_celt_decode_frame(d->celt, &r, M, 0, 21, CC, c0, c1);
+                for (int i = 0; i < M; i++) { ch[0][o + i] += c0[i]; if (CC == 2) ch[1][o + i] += c1[i]; }
+            }
+        }
+        for (int i = 0; i < N; i++) for (int c = 0; c < CC; c++) dst[i * CC + c] = ch[c][i];
+        d->prev_mode = p.mode;
+    }
+    d->prev_redundancy = 0;
+    d->last_frame_size = total;
+    d->final_range = 0;
+    return total;
+}
+
 void orc_kat_rd_init(OrcRd *rd, const uint8_t *buf, int len) { orc_rd_init(rd, buf, len); }

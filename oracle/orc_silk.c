@@ -490,7 +490,19 @@ static void unmix_ms(OrcSilk *s, int bw, int f_size, float *left, float *right) 
     s->prev1 = s->weight1;
 }
 
+static int silk_decode(OrcSilk *s, OrcRd *rd, int bw, int duration_ms, int stereo, float *left, float *right, int fec);
 int orc_silk_decode(OrcSilk *s, OrcRd *rd, int bw, int duration_ms, int stereo, float *left, float *right)
+{
+    return silk_decode(s, rd, bw, duration_ms, stereo, left, right, 0);
+}
+/* In-band FEC recovery (RFC 6716 4.2.4-4.2.7; libopus' decode_fec; the reference stops at the LBRR flag, silk/decoder.rs:2070-2072):
+ * the packet's LBRR frames -- low-rate copies of the PREVIOUS packet's frames -- are decoded into the running state in place of the
+ * regular frames, which are not read.  A 20 ms frame without a copy comes out as silence and both channels start over. */
+int orc_silk_decode_fec(OrcSilk *s, OrcRd *rd, int bw, int duration_ms, int stereo, float *left, float *right)
+{
+    return silk_decode(s, rd, bw, duration_ms, stereo, left, right, 1);
+}
+static int silk_decode(OrcSilk *s, OrcRd *rd, int bw, int duration_ms, int stereo, float *left, float *right, int fec)
 {   /* silk/decoder.rs:1942-1977 (setup) + :2063-2127 (decode) */
     int frames = duration_ms <= 20 ? 1 : duration_ms / 20;
     int subframes = duration_ms == 10 ? 2 : 4;
@@ -509,6 +521,33 @@ int orc_silk_decode(OrcSilk *s, OrcRd *rd, int bw, int duration_ms, int stereo, 
         if (!any_lbrr[ch]) continue;
         int sym = frames == 1 ? 1 : orc_rd_icdf_tab(rd, frames == 2 ? LBRR40 : LBRR60);
         for (int i = 0; i < frames; i++) lbrr[ch][i] = (sym >> i) & 1;
+    }
+    if (fec) {
+        for (int i = 0; i < frames; i++) {
+            float *l = left + i * f_size, *r = right + i * f_size;
+            if (lbrr[0][i]) {
+                int midonly = 0;
+                if (stereo) midonly = parse_stereo_weight(s, rd, lbrr[1][i]);      /* the mid-only flag follows unless the side has an LBRR frame */
+                frame_parse(&s->mid, rd, bw, subframes, sf_size, 1, i == 0 || !lbrr[0][i - 1]);
+                if (stereo && lbrr[1][i]) frame_parse(&s->side, rd, bw, subframes, sf_size, 1, i == 0 || !lbrr[1][i - 1]);
+                if (midonly) frame_flush(&s->side);
+                if (stereo && s->stereo_out) unmix_ms(s, bw, f_size, l, r);
+                else {
+                    const float *in = s->mid.output + LPC_HISTORY - f_size - 2;
+                    if (s->stereo_out) memcpy(l, in, f_size * sizeof(float));
+                    memcpy(r, in, f_size * sizeof(float));
+                }
+            } else {
+                if (stereo && lbrr[1][i]) {              /* a side-only copy is read past */
+                    memset(&s->lbrr[1], 0, sizeof s->lbrr[1]);
+                    frame_parse(&s->lbrr[1], rd, bw, subframes, sf_size, 1, i == 0 || !lbrr[1][i - 1]);
+                }
+                memset(l, 0, f_size * sizeof(float));
+                memset(r, 0, f_size * sizeof(float));
+                frame_flush(&s->mid); frame_flush(&s->side);
+            }
+        }
+        return frames * f_size;
     }
     /* RFC 6716 4.2.5-4.2.7: the LBRR frames come first, interleaved mid / side per 20 ms frame.  Each is coded like a regular
        frame with the VAD flag set; it is coded independently unless the same channel had an LBRR frame in the previous 20 ms.

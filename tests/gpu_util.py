@@ -39,11 +39,11 @@ class HostParser:
         self.silk = (A.SilkFrame * 16)()
         self.max_leaves = max_leaves
 
-    def parse(self, pkt):
+    def parse(self, pkt, fec=False):
         nc, nl, ns = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
         b = bytes(pkt)
-        n = self.lib.opusgpu_parser_parse(self.h, b, len(b), self.fi, self.celt, 48, C.byref(nc), self.leaves, self.max_leaves,
-                                          C.byref(nl), self.silk, 16, C.byref(ns))
+        fn = self.lib.opusgpu_parser_parse_fec if fec else self.lib.opusgpu_parser_parse
+        n = fn(self.h, b, len(b), self.fi, self.celt, 48, C.byref(nc), self.leaves, self.max_leaves, C.byref(nl), self.silk, 16, C.byref(ns))
         return n, nc.value, nl.value, ns.value
 
     def __del__(self):

@@ -49,6 +49,7 @@ def lib():
     for f in ("orc_decoder_create", "orc_silk_create", "orc_celt_create"):
         getattr(L, f).restype = C.c_void_p
     L.orc_decoder_decode.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_int]
+    L.orc_decoder_decode_fec.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_int]
     L.orc_decoder_destroy.argtypes = [C.c_void_p]
     L.orc_decoder_set_celt_trace.argtypes = [C.c_void_p, C.c_void_p]
     L.orc_silk_destroy.argtypes = [C.c_void_p]
@@ -97,6 +98,13 @@ class Decoder:
         n = self.L.orc_decoder_decode(self.h, bytes(pkt), len(pkt), self.buf.ctypes.data, 5760)
         if n < 0:
             raise ValueError(f"oracle decode error {n}")
+        return self.buf[: n * self.ch].reshape(n, self.ch).copy()
+
+    def decode_fec(self, pkt):
+        """pkt follows a lost packet: the lost packet's audio recovered from pkt's LBRR frames (in-band FEC)"""
+        n = self.L.orc_decoder_decode_fec(self.h, bytes(pkt), len(pkt), self.buf.ctypes.data, 5760)
+        if n < 0:
+            raise ValueError(f"oracle FEC decode error {n}")
         return self.buf[: n * self.ch].reshape(n, self.ch).copy()
 
     def __del__(self):

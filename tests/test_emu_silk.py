@@ -32,9 +32,9 @@ class EmuDecoder:
         self.pcm = np.zeros(5760 * channels, np.float32)
         self.internal = np.zeros((2, 320), np.float32)
 
-    def decode(self, p):
+    def decode(self, p, fec=False):
         hp = self.hp
-        n, nc, nl, ns = hp.parse(p)
+        n, nc, nl, ns = hp.parse(p, fec)
         self.nframes = n
         if n < 0:
             return n

@@ -232,3 +232,43 @@ def test_mixed_modes_c4_shape_8192_streams():
         for s in sample:
             check_pcm(refs[s].decode(pk[s]), dec.read(s), f"stream {s} (vector {vids[s % 4]}) step {k}")
     assert len(lens_seen) > 2, "runs of several lengths in one launch"
+
+
+@pytest.mark.parametrize("vid,npk", [(2, 300), (4, 400)])
+def test_fec_recovery_on_gpu(vid, npk):
+    """in-band FEC through the one-stream C ABI (opusgpu_decoder_send_packet_fec): every third packet is lost and recovered from
+    a copy of its frames carried as LBRR frames by its successor (rebuilt with a range encoder, tests/test_lbrr.py); the HIP
+    kernels must return the lost packet's PCM bit for bit (SILK), then the successor's.  The reference stops at the LBRR flag
+    (silk/decoder.rs:2070-2072)."""
+    from test_lbrr import traced_symbols, with_fec_copy
+    extra, pk = orc.load_vectors(ids=[vid], max_packets=npk)[vid]
+    pk = [bytes(p) for p in pk]
+    d = Decoder(0)
+    d.set_extradata(extra)
+    d.configure()
+    plain = orc.Decoder(2)
+    recovered, i = 0, 0
+
+    def feed(p, want, what):
+        d.send_packet(p)
+        out = d.receive_frame()
+        assert np.array_equal(out, want), f"{what}: max diff {np.abs(out - want).max()}"
+    while i < len(pk):
+        want_i, syms_i = traced_symbols(plain, pk[i])
+        if i + 1 < len(pk) and i % 3 == 1:
+            want_n, syms_n = traced_symbols(plain, pk[i + 1])
+            q = with_fec_copy(pk[i + 1], syms_n, pk[i], syms_i)
+            if q is None:
+                feed(pk[i], want_i, f"packet {i}")
+                feed(pk[i + 1], want_n, f"packet {i + 1}")
+            else:
+                d.send_packet_fec(q)
+                out = d.receive_frame()
+                assert np.array_equal(out, want_i), f"vector {vid}: packet {i} recovered from the LBRR frames of {i + 1}"
+                feed(q, want_n, f"packet {i + 1} behind its LBRR frames")
+                recovered += 1
+            i += 2
+            continue
+        feed(pk[i], want_i, f"packet {i}")
+        i += 1
+    assert recovered >= 20, recovered

@@ -187,3 +187,111 @@ def test_random_silk_payloads_with_lbrr(emu, config, stereo):
         else:
             check_pcm(want, out, f"config {config} stereo {stereo} packet {i}")
     assert seen.value > before
+
+
+# ---------------------------------------------------------------------------------------------------
+# In-band FEC recovery: the LBRR frames decoded in place of a lost packet (decode_fec).  The reference returns Unsupported at the
+# LBRR flag; the expected result is made by re-encoding: packet n + 1 is rebuilt with LBRR frames that are a copy of packet
+# n's frames.  A decoder that lost packet n and recovers it from the rebuilt n + 1 must produce packet n's PCM bit for bit
+# (same parameters into the same state), and then packet n + 1's.
+
+def split_header(pkt, syms):
+    """-> (header symbols [VAD flags + LBRR flag per channel], body symbols without markers, qualifies_as_lbrr_source) of a code-0
+    SILK-only packet; None if the packet is something else or already carries LBRR frames"""
+    toc = pkt[0]
+    config, stereo, code = toc >> 3, (toc >> 2) & 1, toc & 3
+    if config >= 12 or code != 0:
+        return None
+    frames = (1, 1, 2, 3)[config & 3]
+    nch = 2 if stereo else 1
+    pos, hdr, all_vad = 0, [], True
+    for ch in range(nch):
+        for _ in range(frames):
+            all_vad = all_vad and syms[pos] == (1, 2, 2)
+            hdr.append(syms[pos]); pos += 1
+        if syms[pos][0] == 1:
+            return None
+        hdr.append(syms[pos]); pos += 1
+    body = syms[pos:]
+    nstart = sum(1 for s in body if s[1] == 0 and s[2] == 1)
+    last_end = max(k for k, s in enumerate(body) if s[1] == 0 and s[2] == 2)
+    clean = nstart == frames * nch and not any(s[1] != 0 for s in body[last_end + 1:])     # no mid-only frame, nothing behind the frames
+    return hdr, [s for s in body if s[1] != 0], all_vad and clean, clean, frames, nch
+
+
+def with_fec_copy(pkt_next, syms_next, pkt_prev, syms_prev):
+    """packet n + 1 rebuilt with packet n's frames in front as LBRR frames, or None"""
+    if pkt_prev[0] != pkt_next[0]:
+        return None
+    a, b = split_header(pkt_prev, syms_prev), split_header(pkt_next, syms_next)
+    if a is None or b is None or not a[2] or not b[3]:
+        return None
+    hdr, body_next, _, _, frames, nch = b
+    per = frames + 1
+    hdr = list(hdr)
+    for ch in range(nch):
+        hdr[ch * per + frames] = (1, 2, 2)              # LBRR flag set
+    lbrr_sym = []
+    if frames > 1:
+        tab = LBRR40 if frames == 2 else LBRR60
+        v = (1 << frames) - 1
+        lbrr_sym = [(tab[v - 1], tab[v], 256)] * nch
+    return pkt_next[:1] + encode_symbols(hdr + lbrr_sym + a[1] + body_next)
+
+
+@pytest.mark.parametrize("vid,channels,npk", [(2, 2, 500), (3, 1, 400), (4, 2, 700), (12, 1, 300)])
+def test_fec_recovers_the_lost_packet_bit_exact(emu, vid, channels, npk):
+    _, pk = orc.load_vectors(ids=[vid], max_packets=npk)[vid]
+    pk = [bytes(p) for p in pk]
+    plain, fec, prod = orc.Decoder(channels), orc.Decoder(channels), EmuDecoder(emu, channels)
+    traced = [None] * len(pk)
+    recovered, i = 0, 0
+    while i < len(pk):
+        want_i, syms_i = traced_symbols(plain, pk[i])
+        q = None
+        if i + 1 < len(pk) and i % 3 == 1:              # every third packet is "lost" where its successor can carry its copy
+            # (the successor's symbols: traced on a throw-away copy of the decoder state is not available, so trace it for real)
+            want_n, syms_n = traced_symbols(plain, pk[i + 1])
+            q = with_fec_copy(pk[i + 1], syms_n, pk[i], syms_i)
+            if q is None:                               # does not qualify: both packets arrive
+                for p, w in ((pk[i], want_i), (pk[i + 1], want_n)):
+                    assert np.array_equal(fec.decode(p), w)
+                    out = prod.decode(p)
+                    (np.testing.assert_array_equal if not prod.hp.fi[0].has_celt and prod.hp.fi[0].mode == 0 else check_pcm)(w, out)
+                i += 2
+                continue
+            silk_only_before = prod.hp.fi[0].mode == 0 if i else True
+            got = fec.decode_fec(q)
+            assert np.array_equal(got, want_i), f"vector {vid}: oracle, packet {i} recovered from the LBRR frames of {i + 1}"
+            assert np.array_equal(fec.decode(q), want_n), f"vector {vid}: oracle, packet {i + 1} behind its own LBRR frames"
+            out = prod.decode(q, fec=True)
+            assert not isinstance(out, int), f"vector {vid} packet {i}: host parser (FEC) returned {out}"
+            if not any(prod.hp.fi[f].has_celt for f in range(prod.nframes)):
+                assert np.array_equal(out, want_i), f"vector {vid}: host parser + kernels, packet {i} recovered from {i + 1}"
+            else:
+                check_pcm(want_i, out, f"vector {vid} packet {i} (FEC)")
+            out = prod.decode(q)
+            (np.testing.assert_array_equal if not prod.hp.fi[0].has_celt and prod.hp.fi[0].mode == 0 else check_pcm)(want_n, out)
+            recovered += 1
+            i += 2
+            continue
+        assert np.array_equal(fec.decode(pk[i]), want_i)
+        out = prod.decode(pk[i])
+        (np.testing.assert_array_equal if not prod.hp.fi[0].has_celt and prod.hp.fi[0].mode == 0 else check_pcm)(want_i, out)
+        i += 1
+    assert recovered >= 20, recovered
+
+
+def test_fec_without_lbrr_frames_conceals(emu):
+    """decode_fec on a packet that carries no LBRR frames: the lost span is concealed as by a lost packet of that duration;
+    host parser + kernels against the oracle, and the stream goes on"""
+    _, pk = orc.load_vectors(ids=[12], max_packets=200)[12]
+    ref, prod = orc.Decoder(2), EmuDecoder(emu, 2)
+    for i, p in enumerate(pk):
+        p = bytes(p)
+        if i % 7 == 3:
+            w = ref.decode_fec(p)
+            out = prod.decode(p, fec=True)
+            assert out.shape == w.shape
+            check_pcm(w, out, f"packet {i} (FEC, nothing to recover)")
+        check_pcm(ref.decode(p), prod.decode(p), f"packet {i}")
