@@ -64,8 +64,10 @@ int opusgpu_decoder_set_extradata(opusgpu_decoder *, const uint8_t *extra, size_
  * then takes RFC 7845 5.1.1 multistream packets and receive_frame returns `channels` interleaved channels. */
 int opusgpu_decoder_configure(opusgpu_decoder *);
 /* Decoder::send_packet (decoder.rs:48-127): parse, decode on the GPU, queue the PCM.  len == 0 (pkt may be NULL) reports a
- * lost packet: the span of the last frame is concealed (the previous frame's overlap fades out, then silence) and the decoder
- * restarts on the next packet; the reference has no concealment and panics on an empty packet (packet.rs:215-225). */
+ * lost packet: the span of the last packet is concealed in that packet's mode -- SILK frames continued from the last frame's
+ * parameters (pitch repetition / noise, attenuated), CELT noise under band energies that decay from frame to frame, both for
+ * hybrid -- and the decoder state runs on into the next packet; before any packet: silence.  The reference has no concealment
+ * and panics on an empty packet (packet.rs:215-225). */
 int opusgpu_decoder_send_packet(opusgpu_decoder *, const uint8_t *pkt, size_t len);
 /* In-band FEC recovery (RFC 6716 4.2.4-4.2.7; libopus' decode_fec) -- the reference returns Error::Unsupported at the LBRR
  * flag (silk/decoder.rs:2070-2072): when a packet was lost and the NEXT one has arrived, send the next one here first.  Queues

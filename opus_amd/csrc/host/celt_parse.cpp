@@ -293,8 +293,9 @@ public:
 }  // namespace
 
 int celt_parse_frame(CeltHostState &st, RangeDec &rd, int N, int start, int end, int C, OgCeltHdr *hdr,
-                     std::vector<OgCeltLeaf> &leaves)
+                     std::vector<OgCeltLeaf> &leaves, float conceal_decay)
 {
+    const bool conceal = conceal_decay >= 0.f;
     const int LM = ilog(N / 120) - 1, M = 1 << LM, CC = st.channels;
     int total_bits = rd.storage_bits(), tell = rd.tell();
     std::memset(hdr, 0, sizeof *hdr);
@@ -310,7 +311,8 @@ int celt_parse_frame(CeltHostState &st, RangeDec &rd, int N, int start, int end,
     if (C == 1) for (int i = 0; i < 21; i++) st.oldE[0][i] = std::max(st.oldE[0][i], st.oldE[1][i]);   // :2266-2274
 
     bool silence = false;                                          // :2237-2248
-    if (tell >= total_bits) silence = true;
+    if (conceal) silence = false;
+    else if (tell >= total_bits) silence = true;
     else if (tell == 1) silence = rd.bit_logp(15);
     if (silence) { rd.to_end(); tell = total_bits; hdr->flags |= OG_F_SILENCE; }
 
@@ -337,6 +339,7 @@ int celt_parse_frame(CeltHostState &st, RangeDec &rd, int N, int start, int end,
         for (int i = 0; i < 21; i++)
             for (int c = 0; c < C; c++) {
                 if (i < start || i >= end) { st.oldE[c][i] = 0.f; continue; }
+                if (conceal) { st.oldE[c][i] = std::max(st.oldE[c][i] - conceal_decay, -28.f); continue; }
                 int left = total_bits - rd.tell(), qi;
                 if (left >= 15) { int pi = 2 * std::min(i, 20); qi = rd.laplace(model[pi] << 7, model[pi + 1] << 6); }
                 else if (left >= 2) { qi = rd.icdf(ICDF_CELT_ENERGY_SMALL); qi = (qi >> 1) ^ -(qi & 1); }
@@ -643,6 +646,7 @@ int celt_parse_frame(CeltHostState &st, RangeDec &rd, int N, int start, int end,
     for (int c = 0; c < 2; c++)
         for (int i = 0; i < 21; i++)
             if (i < start || i >= end) { st.oldE[c][i] = 0.f; st.logE1[c][i] = st.logE2[c][i] = -28.f; }
+    if (conceal) { st.rng = st.rng * 1664525u + 1013904223u; return 0; }
     st.rng = rd.rng();                                             // :2322
     return rd.tell() > total_bits || overflow ? -1 : 0;
 }

@@ -37,8 +37,12 @@ struct CeltHostState {          // what must survive between frames on the host 
 // Parses one CELT frame from rd (positioned after any SILK part), fills hdr and appends its leaves.
 // N = 120/240/480/960, [start,end) band range, C coded channels.  Returns 0, or <0 if the decoder
 // ran past the end of the frame (corrupt data; the frame is still emitted, as the reference would).
+// conceal_decay >= 0 makes it the concealment of a lost frame (no counterpart in the reference; the noise branch of libopus'
+// celt_decode_lost): rd is an empty payload, the frame is not taken for silence, and the band energies are the last frame's
+// lowered by conceal_decay (log2 units) instead of being read.  With no bits every band gets no pulses, so on the device the
+// spectrum is the decoder's own noise filling, shaped by the decaying energies; the noise seed moves on by one LCG step.
 int celt_parse_frame(CeltHostState &st, RangeDec &rd, int N, int start, int end, int C, OgCeltHdr *hdr,
-                     std::vector<OgCeltLeaf> &leaves);
+                     std::vector<OgCeltLeaf> &leaves, float conceal_decay = -1.f);
 
 // ---- SILK: the entropy half of Silk::decode (src/silk/decoder.rs:2063-2127) ---------------------
 struct SilkChanHost {           // silk/decoder.rs:1296-1307 (the parse-side fields of SilkFrame)
@@ -46,6 +50,11 @@ struct SilkChanHost {           // silk/decoder.rs:1296-1307 (the parse-side fie
     int16_t nlsfs[16] = {0};
     float lpc[16] = {0};
     bool flushed = true;        // device history must be cleared before the next coded frame
+    // what concealment continues from (silk_conceal): the last subframe's parameters and the frame's excitation
+    float last_gain = 0.f, last_taps[5] = {0}, last_lpc[16] = {0};
+    int32_t last_exc[320] = {0};
+    int last_lag = 0, last_n = 0;
+    uint32_t plc_seed = 0;
     void flush();
 };
 struct SilkHostState {
@@ -57,6 +66,13 @@ struct SilkHostState {
     bool resampler_reset = true;        // device resampler history must be cleared (build's own stage)
     void flush();
 };
+// Concealment of a lost Opus frame of duration_ms (10 | 20 | 40 | 60) at the bandwidth and channel coding of the last decoded one
+// (no counterpart in the reference; after libopus' silk/PLC.c, simplified): appends one OgSilkFrame per 20 ms whose parameters
+// continue the last frame's -- voiced: no excitation, the long-term predictor repeats the last pitch period (taps normalised into
+// 0.7 .. 0.95, then attenuated); unvoiced: samples drawn at random from the last excitation, the gain attenuated; LPC bandwidth-
+// expanded by 0.99 per frame -- so the device synthesises it by the regular path.  `lost` = frames concealed so far since the
+// last decoded one.  Returns the number of frames; 0 when there is nothing to continue from.
+int silk_conceal(SilkHostState &st, int bandwidth, int duration_ms, int stereo_pkt, int lost, std::vector<OgSilkFrame> &out);
 // Parses the SILK part of one Opus frame (1-3 internal 20 ms frames); appends one OgSilkFrame each.
 // Returns number of internal frames, or <0.  LBRR frames (where the reference returns Unsupported, silk/decoder.rs:2070) are
 // parsed and dropped -- or, with `fec`, decoded IN PLACE of the regular frames, which are then not read: the packet's LBRR frames

@@ -368,8 +368,58 @@ struct ChanParser {
         st.prev_voiced = voiced;
         st.coded = 1;
         st.flushed = false;
+        st.last_gain = out.gain[subframes - 1];
+        st.last_lag = out.pitch_lag[subframes - 1];
+        std::memcpy(st.last_taps, out.ltp_taps[subframes - 1], sizeof st.last_taps);
+        std::memcpy(st.last_lpc, out.lpc, sizeof st.last_lpc);
+        st.last_n = sf_size * subframes;
+        std::memcpy(st.last_exc, out.excitation, size_t(st.last_n) * sizeof(int32_t));
     }
 };
+
+// One concealed channel frame: see silk_conceal (oracle: orc_silk.c frame_conceal, operation for operation).
+void conceal_chan(SilkChanHost &st, OgSilkChan &out, int bw, int subframes, int sf_size, int lost)
+{
+    const int f_size = sf_size * subframes, order = bw == 2 ? 16 : 10;
+    std::memset(&out, 0, sizeof out);
+    const bool voiced = st.prev_voiced != 0;
+    out.flags = uint8_t(OG_S_CODED | (voiced ? OG_S_VOICED : 0) | (st.flushed ? OG_S_RESET : 0));
+    out.order = uint8_t(order);
+    out.subframes = uint8_t(subframes);
+    out.sf_size = uint8_t(sf_size);
+    out.ltpscale = 1.f;
+    const float att = lost == 0 ? 0.99f : voiced ? 0.95f : 0.9f;
+    float chirp = 0.99f;
+    for (int k = 0; k < order; k++) { st.last_lpc[k] *= chirp; chirp *= 0.99f; }
+    if (voiced) {
+        if (lost == 0) {
+            float sum = 0;
+            for (int k = 0; k < 5; k++) sum += st.last_taps[k];
+            const float scale = sum > 0.95f ? 0.95f / sum : sum < 0.7f && sum > 0.01f ? 0.7f / sum : 1.f;
+            for (int k = 0; k < 5; k++) st.last_taps[k] *= scale;
+        }
+        for (int k = 0; k < 5; k++) st.last_taps[k] *= att;
+        std::memset(st.last_exc, 0, sizeof st.last_exc);
+    } else {
+        int32_t pick[320];
+        st.last_gain *= att;
+        for (int i = 0; i < f_size; i++) {
+            st.plc_seed = st.plc_seed * 196314165u + 907633515u;
+            pick[i] = st.last_exc[st.last_n - 64 + int(st.plc_seed >> 26)];
+        }
+        std::memcpy(st.last_exc, pick, size_t(f_size) * sizeof(int32_t));
+        std::memcpy(out.excitation, pick, size_t(f_size) * sizeof(int32_t));
+    }
+    st.last_n = f_size;
+    for (int i = 0; i < subframes; i++) {
+        out.gain[i] = st.last_gain;
+        out.pitch_lag[i] = int16_t(st.last_lag);
+        std::memcpy(out.ltp_taps[i], st.last_taps, sizeof st.last_taps);
+    }
+    std::memcpy(out.lpc, st.last_lpc, sizeof out.lpc);
+    std::memcpy(out.lpc_interp, st.last_lpc, sizeof out.lpc_interp);
+    st.flushed = false;
+}
 
 }  // namespace
 
@@ -503,6 +553,35 @@ int silk_parse(SilkHostState &st, RangeDec &rd, int bw, int duration_ms, int ste
             st.prev_w0 = st.w0;
             st.prev_w1 = st.w1;
         }
+    }
+    return frames;
+}
+
+int silk_conceal(SilkHostState &st, int bw, int duration_ms, int stereo, int lost, std::vector<OgSilkFrame> &out)
+{
+    const int frames = duration_ms <= 20 ? 1 : duration_ms / 20;
+    const int subframes = duration_ms == 10 ? 2 : 4;
+    const int sf_size = bw == 0 ? 40 : bw == 1 ? 60 : 80;
+    if (!st.mid.coded) return 0;
+    for (int i = 0; i < frames; i++) {
+        out.emplace_back();
+        OgSilkFrame &f = out.back();
+        std::memset(&f, 0, sizeof f);
+        f.bandwidth = uint8_t(bw);
+        f.f_size = uint16_t(sf_size * subframes);
+        f.flags = uint8_t((stereo ? OG_SF_STEREO : 0) | (st.stereo_out ? OG_SF_STEREO_OUT : 0));
+        if (st.resampler_reset) { f.flags |= OG_SF_RESAMPLER_RESET; st.resampler_reset = false; }
+        f.prev_w0 = st.prev_w0;
+        f.prev_w1 = st.prev_w1;
+        f.w0 = st.w0;
+        f.w1 = st.w1;
+        conceal_chan(st.mid, f.ch[0], bw, subframes, sf_size, lost + i);
+        if (stereo && st.side.coded) conceal_chan(st.side, f.ch[1], bw, subframes, sf_size, lost + i);
+        else {
+            f.ch[1].order = f.ch[0].order; f.ch[1].subframes = uint8_t(subframes); f.ch[1].sf_size = uint8_t(sf_size);
+            if (stereo) f.flags |= OG_SF_MID_ONLY;
+        }
+        if (stereo && st.stereo_out) { st.prev_w0 = st.w0; st.prev_w1 = st.w1; }
     }
     return frames;
 }

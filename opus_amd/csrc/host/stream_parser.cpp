@@ -22,7 +22,10 @@ void StreamParser::reset()
     silk_.flush();
     silk_.resampler_reset = true;
     prev_mode_ = -1;
-    last_packet_samples_ = 960;
+    last_packet_samples_ = last_frame_samples_ = 960;
+    last_bandwidth_ = 4;
+    last_stereo_ = 0;
+    lost_silk_ = lost_celt_ = 0;
     prev_redundancy_ = false;
 }
 
@@ -36,31 +39,55 @@ int StreamParser::parse(const uint8_t *pkt, size_t len, OgFrameInfo *frames, std
         if (rc0) return rc0;
         bool empty = true;
         for (int f = 0; f < p.nframes; f++) empty = empty && p.len[f] == 0;
-        if (empty) { last_packet_samples_ = p.nframes * p.frame_size; len = 0; }
+        if (empty) { last_packet_samples_ = p.nframes * p.frame_size; last_frame_samples_ = p.frame_size; len = 0; }
     }
     if (len == 0) {
-        // A lost packet (or a DTX gap): minimal concealment; the reference has none (and panics on an empty packet,
-        // packet.rs:215-225).  The span of the last packet is filled by silent CELT frames -- on the device the MDCT overlap of
-        // the last decoded frame fades out over 2.5 ms, then zeros -- and SILK restarts.
+        // A lost packet (or a DTX gap) is concealed over the span of the last packet; no counterpart in the reference (it panics
+        // on an empty packet, packet.rs:215-225).  In the mode of the last packet, as libopus does it:
+        //   SILK    the SILK frames continue from the last one's parameters (silk_conceal: pitch repetition / noise);
+        //   CELT    noise shaped by the last band energies, which decay by 1.5 (first frame) and 0.5 per frame in log2 units;
+        //   hybrid  both, the CELT part from band 17.
+        // Decoder state runs on, so the next packet continues it.  Before any packet, and when SILK has nothing to continue
+        // from: silent CELT frames (on the device the MDCT overlap fades out over 2.5 ms, then zeros) and SILK restarts.
         static const uint8_t kSilence[2] = {0xFF, 0xFF};
+        static const int kCeltEnd[5] = {13, 17, 17, 19, 21};
+        const int N = last_frame_samples_, mode = prev_mode_;
+        const bool silk_ok = mode >= 0 && mode != MODE_CELT && N >= 480 && silk_.mid.coded;
+        const bool celt_noise = mode == MODE_CELT || (mode == MODE_HYBRID && silk_ok);
         int n = 0;
-        for (int o = 0, N; o < last_packet_samples_; o += N, n++) {         // reported as Opus frames, in CELT frame sizes, largest first
-            const int left = last_packet_samples_ - o;
-            N = left >= 960 ? 960 : left >= 480 ? 480 : left >= 240 ? 240 : 120;
+        for (int o = 0; o < last_packet_samples_; o += N, n++) {
             OgFrameInfo &fi = frames[n];
             std::memset(&fi, 0, sizeof fi);
-            fi.mode = uint8_t(prev_mode_ < 0 ? MODE_CELT : prev_mode_);
+            fi.mode = uint8_t(mode < 0 ? MODE_CELT : mode);
+            fi.bandwidth = uint8_t(last_bandwidth_);
+            fi.stereo = uint8_t(last_stereo_);
             fi.frame_size = uint16_t(N);
             fi.celt_index = uint32_t(celt.size());
             fi.silk_index = uint32_t(silk.size());
-            RangeDec r(kSilence, 2);
-            celt.emplace_back();
-            (void)celt_parse_frame(celt_, r, fi.frame_size, 0, 21, channels_, &celt.back(), leaves);
-            celt.back().spread = uint8_t((celt.back().spread & OG_SPREAD_MASK) | OG_ROUND_MAIN << OG_ROUND_SHIFT);
-            fi.has_celt = 1;
+            if (silk_ok) {
+                fi.nsilk = uint8_t(silk_conceal(silk_, std::min(last_bandwidth_, int(BW_WB)), N / 48, last_stereo_, lost_silk_, silk));
+                lost_silk_ += fi.nsilk;
+            }
+            if (silk_ok && mode == MODE_SILK) continue;
+            for (int q = 0, M; q < N; q += M) {                            // in CELT frame sizes, largest first
+                const int left = N - q;
+                M = left >= 960 ? 960 : left >= 480 ? 480 : left >= 240 ? 240 : 120;
+                celt.emplace_back();
+                if (celt_noise) {
+                    RangeDec r(kSilence, 0);
+                    (void)celt_parse_frame(celt_, r, M, mode == MODE_HYBRID ? 17 : 0, kCeltEnd[last_bandwidth_], last_stereo_ + 1,
+                                           &celt.back(), leaves, lost_celt_++ ? 0.5f : 1.5f);
+                } else {
+                    RangeDec r(kSilence, 2);
+                    (void)celt_parse_frame(celt_, r, M, 0, 21, channels_, &celt.back(), leaves);
+                }
+                if (silk_ok) celt.back().flags |= OG_F_ACCUM;
+                celt.back().pcm_off = uint32_t(q);
+                celt.back().spread = uint8_t((celt.back().spread & OG_SPREAD_MASK) | OG_ROUND_MAIN << OG_ROUND_SHIFT);
+                fi.has_celt++;
+            }
         }
-        silk_.flush();
-        silk_.resampler_reset = true;
+        if (!silk_ok) { silk_.flush(); silk_.resampler_reset = true; }
         prev_redundancy_ = false;
         return n;
     }
@@ -164,6 +191,10 @@ int StreamParser::parse(const uint8_t *pkt, size_t len, OgFrameInfo *frames, std
     }
     prev_mode_ = p.mode;
     last_packet_samples_ = p.nframes * p.frame_size;
+    last_frame_samples_ = p.frame_size;
+    last_bandwidth_ = p.bandwidth;
+    last_stereo_ = p.stereo;
+    lost_silk_ = lost_celt_ = 0;
     return p.nframes;
 }
 
@@ -189,6 +220,7 @@ int StreamParser::parse_fec(const uint8_t *pkt, size_t len, OgFrameInfo *frames,
     }
     if (!any) {                                         // nothing to recover from: the span of this packet is concealed
         last_packet_samples_ = p.nframes * p.frame_size;
+        last_frame_samples_ = p.frame_size;
         return parse(nullptr, 0, frames, celt, leaves, silk);
     }
     // as a packet of this mode would start (see parse()); no redundancy information is available for the lost packet
@@ -229,6 +261,10 @@ int StreamParser::parse_fec(const uint8_t *pkt, size_t len, OgFrameInfo *frames,
     }
     prev_redundancy_ = false;
     last_packet_samples_ = p.nframes * p.frame_size;
+    last_frame_samples_ = p.frame_size;
+    last_bandwidth_ = p.bandwidth;
+    last_stereo_ = p.stereo;
+    lost_silk_ = lost_celt_ = 0;
     return p.nframes;
 }
 

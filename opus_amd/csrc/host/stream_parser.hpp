@@ -27,6 +27,9 @@ private:
     int channels_;
     int prev_mode_ = -1;
     int last_packet_samples_ = 960;                 // samples per channel of the last packet (what a lost packet is taken to span)
+    int last_frame_samples_ = 960;                  // ... of one Opus frame of the last packet
+    int last_bandwidth_ = 4, last_stereo_ = 0;      // the last packet's TOC: what a concealed frame is coded as
+    int lost_silk_ = 0, lost_celt_ = 0;             // SILK / CELT frames concealed since the last decoded packet
     bool prev_redundancy_ = false;                  // the previous frame ended in a SILK -> CELT redundant frame: CELT continues from it
     CeltHostState celt_;
     SilkHostState silk_;

@@ -54,6 +54,7 @@ void orc_celt_destroy(OrcCelt *);
 void orc_celt_reset(OrcCelt *);
 void orc_celt_set_trace(OrcCelt *, OrcCeltTrace *);
 int orc_celt_decode_frame(OrcCelt *, OrcRd *, int N, int start, int end, int C, float *pcm0, float *pcm1);
+int orc_celt_conceal_frame(OrcCelt *, int N, int start, int end, int C, float decay, float *pcm0, float *pcm1);
 uint32_t orc_cwrsi(int n, int k, uint32_t i, int *y);
 uint32_t orc_pvq_v(int n, int k);
 int orc_extract_collapse_mask(const int *y, int n, int b);
@@ -73,6 +74,8 @@ void orc_silk_flush(OrcSilk *);
 /* bandwidth: 0 NB, 1 MB, 2 WB; duration_ms 10/20/40/60; returns samples/channel or <0 */
 int orc_silk_decode(OrcSilk *, OrcRd *, int bandwidth, int duration_ms, int stereo_pkt, float *left, float *right);
 int orc_silk_decode_fec(OrcSilk *, OrcRd *, int bandwidth, int duration_ms, int stereo_pkt, float *left, float *right);
+int orc_silk_can_conceal(const OrcSilk *);
+int orc_silk_conceal(OrcSilk *, int bandwidth, int duration_ms, int stereo_pkt, int lost, float *left, float *right);
 void orc_lsf_to_lpc(const int16_t *nlsf, int order, float *lpc);
 
 /* entropy KAT shims */

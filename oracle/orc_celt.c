@@ -746,10 +746,27 @@ void orc_celt_set_trace(OrcCelt *st, OrcCeltTrace *tr) { st->trace = tr; }
 
 /* Decode one CELT frame of `N` samples/channel from rd (celt/decoder.rs:2222-2323 + RFC 6716 4.3 tail).
  * C = channels coded in the packet; output: st->channels planar arrays of N floats, full-scale +-1. */
+static int celt_frame(OrcCelt *st, OrcRd *rd, int N, int start, int end, int C, float *pcm0, float *pcm1, float decay);
 int orc_celt_decode_frame(OrcCelt *st, OrcRd *rd, int N, int start, int end, int C, float *pcm0, float *pcm1)
 {
-    int lm = orc_ilog(N / 120) - 1, M = 1 << lm, CC = st->channels;
+    return celt_frame(st, rd, N, start, end, C, pcm0, pcm1, -1.f);
+}
+/* Concealment of a lost frame (no counterpart in the reference; the noise branch of libopus' celt_decode_lost): the frame is
+ * decoded by the regular path from an empty payload, except that it is not taken for silence and that the band energies are the
+ * last frame's lowered by `decay` (log2 units) instead of being read.  With no bits every band gets no pulses, so the spectrum
+ * is the decoder's own noise filling -- LCG noise in the lowest bands, folded copies above -- shaped by the decaying energies.
+ * The noise seed moves on by one LCG step per frame, so consecutive frames are uncorrelated. */
+int orc_celt_conceal_frame(OrcCelt *st, int N, int start, int end, int C, float decay, float *pcm0, float *pcm1)
+{
+    OrcRd rd;
+    orc_rd_init(&rd, (const uint8_t *)st, 0);                 /* an empty payload: no byte of it is read */
+    return celt_frame(st, &rd, N, start, end, C, pcm0, pcm1, decay);
+}
+static int celt_frame(OrcCelt *st, OrcRd *rd, int N, int start, int end, int C, float *pcm0, float *pcm1, float decay)
+{
+    int lm = orc_ilog(N / 120) - 1, M = 1 << lm, CC = st->channels, conceal = decay >= 0.f;
     int total_bits = rd->size_bits, tell = orc_rd_tell(rd);
+    uint32_t seed_in = st->rng;
     OrcCeltTrace *tr = st->trace;
     float Xbuf[2][960];
     uint8_t collapse[42];
@@ -763,7 +780,8 @@ int orc_celt_decode_frame(OrcCelt *st, OrcRd *rd, int N, int start, int end, int
     if (C == 1) for (int i = 0; i < 21; i++) if (st->oldE[1][i] > st->oldE[0][i]) st->oldE[0][i] = st->oldE[1][i]; /* :2266 */
 
     int silence = 0;
-    if (tell >= total_bits) silence = 1;
+    if (conceal) silence = 0;
+    else if (tell >= total_bits) silence = 1;
     else if (tell == 1) silence = orc_rd_logp(rd, 15);       /* celt/decoder.rs:2237 (RFC: only when tell==1) */
     if (silence) { orc_rd_to_end(rd); tell = total_bits; }
 
@@ -793,6 +811,7 @@ int orc_celt_decode_frame(OrcCelt *st, OrcRd *rd, int N, int start, int end, int
             for (int c = 0; c < C; c++) {
                 float *en = &st->oldE[c][i];
                 if (i < start || i >= end) { *en = 0.f; continue; }
+                if (conceal) { *en = *en - decay > -28.f ? *en - decay : -28.f; continue; }
                 int avail = total_bits - orc_rd_tell(rd), qi;
                 if (avail >= 15) { int k = (i < 20 ? i : 20) << 1; qi = orc_rd_laplace(rd, model[k] << 7, model[k + 1] << 6); }
                 else if (avail >= 2) { qi = orc_rd_icdf(rd, ICDF_CELT_ENERGY_SMALL); qi = (qi >> 1) ^ -(qi & 1); }
@@ -1079,6 +1098,11 @@ int orc_celt_decode_frame(OrcCelt *st, OrcRd *rd, int N, int start, int end, int
     for (int c = 0; c < 2; c++)
         for (int i = 0; i < 21; i++)
             if (i < start || i >= end) { st->oldE[c][i] = 0; st->logE1[c][i] = st->logE2[c][i] = -28.f; }
+    if (conceal) {
+        st->rng = seed_in * 1664525u + 1013904223u;              /* (of the frame's first seed: the draws above are not counted) */
+        if (tr) tr->seed_out = st->rng;
+        return 0;
+    }
     st->rng = rd->range;                                      /* celt/decoder.rs:2322 */
     if (tr) { tr->seed_out = st->rng; tr->tell_end = orc_rd_tell(rd); }
     return orc_rd_tell(rd) > total_bits ? -1 : 0;

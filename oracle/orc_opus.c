@@ -168,6 +168,9 @@ long orc_redundant_frames[2] = {0, 0};       /* test statistics: redundant frame
 struct OrcDecoder {
     int channels, prev_mode;
     int last_frame_size;          /* samples per channel of the last packet (what a lost packet is taken to span) */
+    int last_opus_frame;          /* samples per channel of one Opus frame of the last packet */
+    int last_bandwidth, last_stereo;
+    int lost_silk, lost_celt;     /* SILK / CELT frames concealed since the last decoded packet */
     int prev_redundancy;          /* the previous frame ended in a SILK -> CELT redundant frame: CELT continues from it */
     uint32_t final_range;         /* of the last frame: the main decoder's range XOR the redundant frame's (RFC 6716 4.5.1.4) */
     OrcSilk *silk;
@@ -178,7 +181,7 @@ struct OrcDecoder {
 OrcDecoder *orc_decoder_create(int channels)   /* decoder.rs:133-182 (configure) */
 {
     OrcDecoder *d = (OrcDecoder *)calloc(1, sizeof *d);
-    d->channels = channels; d->prev_mode = -1; d->last_frame_size = 960;
+    d->channels = channels; d->prev_mode = -1; d->last_frame_size = d->last_opus_frame = 960; d->last_bandwidth = 4;
     d->silk = orc_silk_create(channels > 1);
     d->celt = orc_celt_create(channels);
     return d;
@@ -194,26 +197,55 @@ int orc_decoder_decode(OrcDecoder *d, const uint8_t *pkt, int len, float *pcm, i
         if (orc_packet_parse(pkt, len, &p)) return -1;
         int empty = 1;
         for (int f = 0; f < p.nframes; f++) empty = empty && p.len[f] == 0;
-        if (empty) { d->last_frame_size = p.nframes * p.frame_size; len = 0; }
+        if (empty) { d->last_frame_size = p.nframes * p.frame_size; d->last_opus_frame = p.frame_size; len = 0; }
     }
     if (len == 0) {
-        /* A lost packet (or a DTX gap): minimal concealment, no counterpart in the reference (it panics on an empty packet,
-           packet.rs:215-225).  The span of the last packet is filled by silent CELT frames -- the MDCT overlap of the last
-           decoded frame fades out over 2.5 ms, then zeros -- and SILK restarts; the next packet is decoded as after a switch. */
+        /* A lost packet (or a DTX gap) is concealed over the span of the last packet; no counterpart in the reference (it panics
+           on an empty packet, packet.rs:215-225).  In the mode of the last packet, as libopus does it:
+           SILK    the SILK frames continue from the last one's parameters (orc_silk_conceal: pitch repetition / noise);
+           CELT    noise shaped by the last band energies, which decay by 1.5 (first frame) and 0.5 per frame in log2 units;
+           hybrid  both, the CELT part from band 17.
+           Decoder state runs on, so the next packet continues it.  Before any packet, and when SILK has nothing to continue
+           from: silent CELT frames (the MDCT overlap fades out over 2.5 ms, then zeros) and SILK restarts. */
         static const uint8_t silence[2] = {0xFF, 0xFF};
-        int CC = d->channels, total = d->last_frame_size;
+        static const int celt_end[5] = {13, 17, 17, 19, 21};
+        static const int silk_rate[3] = {8, 12, 16};
+        int CC = d->channels, total = d->last_frame_size, N = d->last_opus_frame, mode = d->prev_mode;
         if (total > cap) return -3;
-        for (int o = 0, N; o < total; o += N) {             /* in CELT frame sizes, largest first */
-            int left = total - o;
-            N = left >= 960 ? 960 : left >= 480 ? 480 : left >= 240 ? 240 : 120;
-            float c0[960], c1[960];
-            OrcRd r;
-            orc_rd_init(&r, silence, 2);
-            orc_celt_decode_frame(d->celt, &r, N, 0, 21, CC, c0, c1);
-            for (int i = 0; i < N; i++) for (int c = 0; c < CC; c++) pcm[(size_t)(o + i) * CC + c] = c ? c1[i] : c0[i];
+        int silk_ok = mode >= 0 && mode != 2 && N >= 480 && orc_silk_can_conceal(d->silk);
+        int celt_noise = mode == 2 || (mode == 1 && silk_ok);
+        for (int o = 0; o < total; o += N) {
+            float ch[2][2880];
+            float *dst = pcm + (size_t)o * CC;
+            memset(ch, 0, sizeof ch);
+            if (silk_ok) {
+                float sl[960], sr[960];
+                int bw = d->last_bandwidth < 2 ? d->last_bandwidth : 2;
+                int n = orc_silk_conceal(d->silk, bw, N / 48, d->last_stereo, d->lost_silk, sl, sr);
+                d->lost_silk += N <= 960 ? 1 : N / 960;
+                if (CC == 2) {
+                    orc_resample_to_48k(sl, n, silk_rate[bw], d->rs_hist[0], ch[0]);
+                    orc_resample_to_48k(sr, n, silk_rate[bw], d->rs_hist[1], ch[1]);
+                } else orc_resample_to_48k(sr, n, silk_rate[bw], d->rs_hist[0], ch[0]);
+            }
+            if (!(silk_ok && mode == 0))
+                for (int q = 0, M; q < N; q += M) {             /* in CELT frame sizes, largest first */
+                    int left = N - q;
+                    M = left >= 960 ? 960 : left >= 480 ? 480 : left >= 240 ? 240 : 120;
+                    float c0[960], c1[960];
+                    if (celt_noise)
+                        orc_celt_conceal_frame(d->celt, M, mode == 1 ? 17 : 0, celt_end[d->last_bandwidth], d->last_stereo + 1,
+                                               d->lost_celt++ ? 0.5f : 1.5f, c0, c1);
+                    else {
+                        OrcRd r;
+                        orc_rd_init(&r, silence, 2);
+                        orc_celt_decode_frame(d->celt, &r, M, 0, 21, CC, c0, c1);
+                    }
+                    for (int i = 0; i < M; i++) { ch[0][q + i] += c0[i]; if (CC == 2) ch[1][q + i] += c1[i]; }
+                }
+            for (int i = 0; i < N; i++) for (int c = 0; c < CC; c++) dst[i * CC + c] = ch[c][i];
         }
-        orc_silk_flush(d->silk);
-        memset(d->rs_hist, 0, sizeof d->rs_hist);
+        if (!silk_ok) { orc_silk_flush(d->silk); memset(d->rs_hist, 0, sizeof d->rs_hist); }
         d->prev_redundancy = 0;
         d->final_range = 0;
         return total;
@@ -311,7 +343,9 @@ int orc_decoder_decode(OrcDecoder *d, const uint8_t *pkt, int len, float *pcm, i
         }
         for (int i = 0; i < N; i++) for (int c = 0; c < CC; c++) dst[i * CC + c] = ch[c][i];
         d->final_range = rd.range ^ red_range;
-        d->last_frame_size = total;
+        d->last_frame_size = total; d->last_opus_frame = N;
+        d->last_bandwidth = p.bandwidth; d->last_stereo = p.stereo;
+        d->lost_silk = d->lost_celt = 0;
         d->prev_mode = p.mode;
         d->prev_redundancy = redundancy && !celt_to_silk;
         celt_restart = 0;
@@ -344,7 +378,7 @@ int orc_decoder_decode_fec(OrcDecoder *d, const uint8_t *pkt, int len, float *pc
         any |= a;
     }
     if (!any) {
-        d->last_frame_size = p.nframes * p.frame_size;
+        d->last_frame_size = p.nframes * p.frame_size; d->last_opus_frame = p.frame_size;
         return orc_decoder_decode(d, NULL, 0, pcm, cap);
     }
     int CC = d->channels, total = p.nframes * p.frame_size;
@@ -381,7 +415,9 @@ int orc_decoder_decode_fec(OrcDecoder *d, const uint8_t *pkt, int len, float *pc
         d->prev_mode = p.mode;
     }
     d->prev_redundancy = 0;
-    d->last_frame_size = total;
+    d->last_frame_size = total; d->last_opus_frame = p.frame_size;
+    d->last_bandwidth = p.bandwidth; d->last_stereo = p.stereo;
+    d->lost_silk = d->lost_celt = 0;
     d->final_range = 0;
     return total;
 }

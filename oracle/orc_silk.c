@@ -23,6 +23,10 @@ typedef struct {                /* silk/decoder.rs:1296-1314 */
     float lpc[16], interpolated_lpc[16];
     int interpolated, interp_factor4, previous_lag;
     float output[2 * LPC_HISTORY], lpc_history[2 * LPC_HISTORY];
+    /* what concealment continues from (frame_conceal): the last subframe's parameters and the frame's excitation */
+    float last_gain, last_taps[LTP_ORDER], last_lpc[16], last_exc[320];
+    int last_lag, last_n;
+    uint32_t plc_seed;
 } SilkFrame;
 
 struct OrcSilk {
@@ -371,6 +375,7 @@ static void frame_flush(SilkFrame *f) { if (f->coded) memset(f, 0, sizeof *f); }
 
 static inline float clampf(float v, float lo, float hi) { v = v > lo ? v : lo; return v < hi ? v : hi; }
 
+static void frame_synth(SilkFrame *f, const SubFrame *sfs, float *residuals, float ltpscale, int order, int subframes, int sf_size);
 static void frame_parse(SilkFrame *f, OrcRd *rd, int bw, int subframes, int sf_size, int vad, int first)
 {   /* silk/decoder.rs:1664-1903 */
     orc_trace3(0, 0, 1);                      /* marker: a SILK frame starts */
@@ -397,7 +402,20 @@ static void frame_parse(SilkFrame *f, OrcRd *rd, int bw, int subframes, int sf_s
     }
     float ltpscale = (f->voiced && first ? (float)SILK_LTP_SCALE[orc_rd_icdf(rd, ICDF_SILK_LTP_SCALE_INDEX)] : 15565.f) / 16384.f;
     parse_excitation(f, rd, residuals + RES_HISTORY, bw, long_frame);
+    f->last_gain = sfs[subframes - 1].gain;
+    f->last_lag = sfs[subframes - 1].pitch_lag;
+    memcpy(f->last_taps, sfs[subframes - 1].ltp_taps, sizeof f->last_taps);
+    memcpy(f->last_lpc, f->lpc, sizeof f->last_lpc);
+    memcpy(f->last_exc, residuals + RES_HISTORY, f_size * sizeof(float));
+    f->last_n = f_size;
+    frame_synth(f, sfs, residuals, ltpscale, order, subframes, sf_size);
+    orc_trace3(0, 0, 2);                      /* marker: the frame's last symbol has been read */
+}
 
+/* The synthesis half of SilkFrame::parse (silk/decoder.rs:1772-1903): LTP and LPC synthesis of one channel frame. */
+static void frame_synth(SilkFrame *f, const SubFrame *sfs, float *residuals, float ltpscale, int order, int subframes, int sf_size)
+{
+    int f_size = sf_size * subframes;
     for (int i = 0; i < subframes; i++) {
         const SubFrame *sf = &sfs[i];
         const float *lpc_coeff = (i < 2 && f->interpolated) ? f->interpolated_lpc : f->lpc;
@@ -434,13 +452,60 @@ static void frame_parse(SilkFrame *f, OrcRd *rd, int bw, int subframes, int sf_s
             out[j] = clampf(sum, -1.f, 1.f);
         }
     }
-    orc_trace3(0, 0, 2);                      /* marker: the frame's last symbol has been read */
     f->prev_voiced = f->voiced;
     for (int i = 0; i < LPC_HISTORY; i++) {
         f->lpc_history[i] = f->lpc_history[i + f_size];
         f->output[i] = f->output[i + f_size];
     }
     f->coded = 1;
+}
+
+/* Concealment of one lost channel frame (no counterpart in the reference; after libopus' silk/PLC.c, simplified): the frame
+ * is synthesised by the regular path from made-up parameters that continue the last decoded frame's.  Voiced: no excitation,
+ * the long-term predictor repeats the last pitch period of the residual (taps normalised into 0.7 .. 0.95 at the first lost
+ * frame, then attenuated).  Unvoiced: samples drawn at random from the last frame's excitation, the gain attenuated.  The
+ * short-term predictor is bandwidth-expanded by 0.99 per frame.  `lost` = frames concealed so far since the last decoded one. */
+static void frame_conceal(SilkFrame *f, int bw, int subframes, int sf_size, int lost)
+{
+    int f_size = sf_size * subframes, order = bw == 2 ? 16 : 10;
+    SubFrame sfs[4];
+    float residuals[LPC_HISTORY + RES_HISTORY];
+    memset(sfs, 0, sizeof sfs);
+    memset(residuals, 0, sizeof residuals);
+    f->voiced = f->prev_voiced;
+    float att = lost == 0 ? 0.99f : f->voiced ? 0.95f : 0.9f, chirp = 0.99f;
+    for (int k = 0; k < order; k++) { f->last_lpc[k] *= chirp; chirp *= 0.99f; }
+    float kept[16];                           /* (the next decoded frame may interpolate from the last DECODED coefficients, :1441) */
+    memcpy(kept, f->lpc, sizeof kept);
+    memcpy(f->lpc, f->last_lpc, sizeof kept);
+    f->interpolated = 0; f->interp_factor4 = 0;
+    if (f->voiced) {
+        if (lost == 0) {
+            float sum = 0;
+            for (int k = 0; k < LTP_ORDER; k++) sum += f->last_taps[k];
+            float scale = sum > 0.95f ? 0.95f / sum : sum < 0.7f && sum > 0.01f ? 0.7f / sum : 1.f;
+            for (int k = 0; k < LTP_ORDER; k++) f->last_taps[k] *= scale;
+        }
+        for (int k = 0; k < LTP_ORDER; k++) f->last_taps[k] *= att;
+        memset(f->last_exc, 0, sizeof f->last_exc);
+    } else {
+        float pick[320];
+        f->last_gain *= att;
+        for (int i = 0; i < f_size; i++) {
+            f->plc_seed = f->plc_seed * 196314165u + 907633515u;
+            pick[i] = f->last_exc[f->last_n - 64 + (int)(f->plc_seed >> 26)];
+        }
+        memcpy(f->last_exc, pick, f_size * sizeof(float));
+        memcpy(residuals + RES_HISTORY, pick, f_size * sizeof(float));
+    }
+    f->last_n = f_size;
+    for (int i = 0; i < subframes; i++) {
+        sfs[i].gain = f->last_gain;
+        sfs[i].pitch_lag = f->last_lag;
+        memcpy(sfs[i].ltp_taps, f->last_taps, sizeof f->last_taps);
+    }
+    frame_synth(f, sfs, residuals, 1.f, order, subframes, sf_size);
+    memcpy(f->lpc, kept, sizeof kept);
 }
 
 uint32_t *orc_trace_buf = 0;                 /* orc_rangedec.h: optional symbol trace */
@@ -501,6 +566,28 @@ int orc_silk_decode(OrcSilk *s, OrcRd *rd, int bw, int duration_ms, int stereo, 
 int orc_silk_decode_fec(OrcSilk *s, OrcRd *rd, int bw, int duration_ms, int stereo, float *left, float *right)
 {
     return silk_decode(s, rd, bw, duration_ms, stereo, left, right, 1);
+}
+/* Concealment of a lost Opus frame of duration_ms (10 | 20 | 40 | 60) at the bandwidth and channel coding of the last decoded one.
+ * Returns the samples per channel, or 0 when there is nothing to continue from (the mid channel has not been decoded). */
+int orc_silk_can_conceal(const OrcSilk *s) { return s->mid.coded; }
+int orc_silk_conceal(OrcSilk *s, int bw, int duration_ms, int stereo, int lost, float *left, float *right)
+{
+    int frames = duration_ms <= 20 ? 1 : duration_ms / 20;
+    int subframes = duration_ms == 10 ? 2 : 4;
+    int sf_size = bw == 0 ? 40 : bw == 1 ? 60 : 80, f_size = sf_size * subframes;
+    if (!s->mid.coded) return 0;
+    for (int i = 0; i < frames; i++) {
+        float *l = left + i * f_size, *r = right + i * f_size;
+        frame_conceal(&s->mid, bw, subframes, sf_size, lost + i);
+        if (stereo && s->side.coded) frame_conceal(&s->side, bw, subframes, sf_size, lost + i);
+        if (stereo && s->stereo_out) unmix_ms(s, bw, f_size, l, r);
+        else {
+            const float *in = s->mid.output + LPC_HISTORY - f_size - 2;
+            if (s->stereo_out) memcpy(l, in, f_size * sizeof(float));
+            memcpy(r, in, f_size * sizeof(float));
+        }
+    }
+    return frames * f_size;
 }
 static int silk_decode(OrcSilk *s, OrcRd *rd, int bw, int duration_ms, int stereo, float *left, float *right, int fec)
 {   /* silk/decoder.rs:1942-1977 (setup) + :2063-2127 (decode) */

@@ -171,18 +171,19 @@ def test_random_silk_payloads_with_lbrr_on_gpu(stereo):
     assert seen.value - before >= 20
 
 
-@pytest.mark.parametrize("vid,npk", [(1, 200), (6, 200), (10, 1250), (12, 300)])
+@pytest.mark.parametrize("vid,npk", [(1, 200), (4, 200), (6, 200), (10, 1250), (12, 300)])
 def test_lost_packets_and_redundant_frames_on_gpu(vid, npk):
-    """packets reported lost (len 0) are concealed -- overlap fade-out, then silence; the decoder restarts -- and the redundant
-    CELT frames of the mode switches (vector 10: packets 965 ..; vector 12: 136 ..) are decoded and cross-faded (RFC 6716
-    4.5.1).  Neither exists in the reference (packet.rs:215-225 panics, decoder.rs:84-115 drops): HIP path against the oracle."""
+    """packets reported lost (len 0) are concealed in the mode of the last packet -- SILK frames made up from the last frame's
+    parameters, CELT noise under decaying band energies, both for hybrid; single and double losses and a burst of ten -- and the
+    redundant CELT frames of the mode switches (vector 10: packets 965 ..; vector 12: 136 ..) are decoded and cross-faded (RFC
+    6716 4.5.1).  Neither exists in the reference (packet.rs:215-225 panics, decoder.rs:84-115 drops): HIP path against the oracle."""
     extra, pk = orc.load_vectors(ids=[vid], max_packets=npk)[vid]
     d = Decoder(0)
     d.set_extradata(extra)
     d.configure()
     ref = orc.Decoder(2)
     for i, p in enumerate(pk):
-        lost = i % 41 == 30 or i % 41 == 31
+        lost = i % 41 == 30 or i % 41 == 31 or 100 <= i < 110
         d.send_packet(b"" if lost else p)
         out, r = d.receive_frame(), ref.decode(b"" if lost else p)
         assert out.shape == r.shape, f"vector {vid} packet {i}"
