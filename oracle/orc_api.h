@@ -57,6 +57,10 @@ int orc_celt_decode_frame(OrcCelt *, OrcRd *, int N, int start, int end, int C, 
 int orc_celt_conceal_frame(OrcCelt *, int N, int start, int end, int C, float decay, float *pcm0, float *pcm1);
 uint32_t orc_cwrsi(int n, int k, uint32_t i, int *y);
 uint32_t orc_pvq_v(int n, int k);
+uint32_t orc_icwrs(int n, const int *y);
+/* the decoder run as an encoder (tests/test_loopback.py; see orc_celt.c): NULL switches it off */
+typedef int64_t (*OrcEncHook)(int kind, int band, int ch, int a, int b, int c, double f, int *y);
+void orc_set_encoder(OrcEncHook hook);
 int orc_extract_collapse_mask(const int *y, int n, int b);
 void orc_haar1(float *x, int n0, int stride);
 void orc_exp_rotation(float *x, int len, int stride, int k, int spread);

@@ -5,11 +5,15 @@
  * notes).  Pinning status:
  *   pinned by reference KATs : cwrsi (celt/decoder.rs:2414-2434), extract_collapse_mask (:2398-2411),
  *                              stereo_merge (:2330-2396), haar1 (:2436-2481), range decoder (entropy.rs)
- *   PARITY UNPINNED          : tf/allocation/theta/bits2pulses/exp_rotation (no reference test) and
- *                              everything after PVQ band decoding (anti-collapse, denormalise, IMDCT,
- *                              window, post-filter, de-emphasis): the reference has no such code
- *                              (celt/decoder.rs:2320-2322 ends at decode_bands) -> written from RFC 6716
- *                              4.3.3-4.3.7 and checked against an f64 direct IMDCT in tests/.
+ *   no reference test, pinned : tf / allocation / theta / bits2pulses / exp_rotation, and everything after PVQ band decoding
+ *   from the signal side        (anti-collapse, denormalise, IMDCT, window, post-filter, de-emphasis: the reference has no such
+ *                              code, celt/decoder.rs:2320-2322 ends at decode_bands) are written from RFC 6716 4.3.3-4.3.7.
+ *                              What pins them: the RFC's own test vectors through opus_compare (tests/test_opus_compare.py);
+ *                              the fast IMDCT against an f64 evaluation of the transform's definition and the window / overlap
+ *                              against a textbook f64 MDCT (tests/test_oracle_kats.py: test_imdct_fast_against_f64_direct,
+ *                              test_imdct_and_window_reconstruct_a_textbook_mdct); and the encode -> decode loopback of
+ *                              tests/test_loopback.py, where this decoder, run forced, ENCODES a known signal and every
+ *                              decoder must return the signal (22 dB SNR at 64 kb/s per channel, 28 dB at 128).
  */
 #include <math.h>
 #include <stdlib.h>
@@ -107,6 +111,33 @@ uint32_t orc_cwrsi(int n, int k, uint32_t i, int *y)
 }
 
 uint32_t orc_pvq_v(int n, int k) { return pvq_u(n, k) + pvq_u(n, k + 1); }   /* celt/decoder.rs:666-668 */
+
+/* The inverse of orc_cwrsi (RFC 6716 cwrs.c icwrs; no counterpart in the reference, a decoder): pulse vector -> index. */
+uint32_t orc_icwrs(int n, const int *y)
+{
+    int j = n - 1, k = abs(y[j]);
+    uint32_t i = y[j] < 0;
+    do {
+        j--;
+        i += pvq_u(n - j, k);
+        k += abs(y[j]);
+        if (y[j] < 0) i += pvq_u(n - j, k + 1);
+    } while (j > 0);
+    return i;
+}
+
+/* The decoder run as an encoder (orc_rangedec.h, forced mode): at every value a frame codes, `hook` is asked what to code.
+ * kind: 1 coarse energy (a = alphabet: 0 Laplace, 1 {0,-1,+1}, 2 {0,-1}; f = the prediction the value adds to) -> qi
+ *       2 fine energy (a = bits; f = the band's energy so far) -> 0 .. 2^bits - 1      3 final bit (a = fine bits so far) -> 0 | 1
+ *       4 split angle (a = first bin of the vector in the frame, b = bins per half, c = qn) -> 0 .. qn
+ *       5 pulses (a = first bin, b = bins, c = pulses; y: out, |y|_1 = c)             6 sign of a one-bin band (a = bin) -> 0 | 1
+ * Everything else takes symbol 0 (no silence, no post-filter, no transient, inter energy, no tf change, no spreading rotation, no
+ * boosts), except the allocation trim (5), the skip flags (1: code every band) and, for two channels, intensity = none and
+ * dual stereo = 1 (each channel's bands coded like a mono band). */
+int orc_force_on = 0, orc_force_have = 0;
+int64_t orc_force_val = 0;
+static OrcEncHook enc_hook = 0;
+void orc_set_encoder(OrcEncHook h) { enc_hook = h; orc_force_on = h != 0; orc_force_have = 0; }
 
 /* celt/decoder.rs:723-736.  Divergence: the reference ORs element e into bit (e mod B); RFC 6716
  * (vq.c extract_collapse_mask) uses contiguous blocks of N/B, which is what the de-interleaved
@@ -224,6 +255,7 @@ typedef struct {
     uint32_t seed;
     float *base[2];         /* channel coefficient arrays, for trace offsets */
     OrcCeltTrace *tr;
+    float *hx;              /* the vector being split (for the encoder hook) */
 } BandCtx;
 
 static inline uint32_t lcg(uint32_t s) { return 1664525u * s + 1013904223u; }   /* :1595-1599 */
@@ -261,6 +293,7 @@ static int quant_band_n1(BandCtx *c, float *x, float *y, float *lowband_out)   /
     for (int ch = 0; ch < (y ? 2 : 1); ch++) {
         int sign = 0;
         if (c->remaining_bits >= 8) {
+            if (orc_force_on) orc_force(enc_hook(6, c->band, ch, (int)(p - c->base[ch]), 1, 0, 0., NULL));
             sign = orc_rd_rawbits(c->rd, 1);
             c->remaining_bits -= 8;
         }
@@ -291,6 +324,8 @@ static void compute_theta(BandCtx *c, SplitCtx *s, int n, int *b, int B, int B0,
     if (stereo && c->band >= c->intensity) qn = 1;
     int tell = orc_rd_tell_frac(c->rd);
     if (qn != 1) {
+        if (orc_force_on) orc_force(stereo ? 0 : enc_hook(4, c->band, c->hx >= c->base[1] && c->base[1] ? 1 : 0,
+                                                          (int)(c->hx - c->base[c->hx >= c->base[1] && c->base[1] ? 1 : 0]), n, qn, 0., NULL));
         if (stereo && n > 2) itheta = orc_rd_step(c->rd, qn / 2);
         else if (B0 > 1 || stereo) itheta = orc_rd_uniform(c->rd, qn + 1);
         else itheta = orc_rd_triangular(c->rd, qn);
@@ -323,6 +358,7 @@ static int quant_partition(BandCtx *c, float *x, int n, int b, int B, float *low
         lm -= 1;
         if (B == 1) fill = (fill & 1) | (fill << 1);
         B = (B + 1) >> 1;
+        c->hx = x;
         compute_theta(c, &s, n, &b, B, B0, lm, 0, &fill);
         float mid = (1.f / 32768) * s.imid, side = (1.f / 32768) * s.iside;
         int delta = s.delta;
@@ -362,6 +398,12 @@ static int quant_partition(BandCtx *c, float *x, int n, int b, int B, float *low
     if (q != 0) {
         int k = q < 8 ? q : (8 + (q & 7)) << ((q >> 3) - 1);
         int y[176];
+        if (orc_force_on) {
+            int ch = x >= c->base[1] && c->base[1] ? 1 : 0;
+            memset(y, 0, sizeof y);
+            enc_hook(5, c->band, ch, (int)(x - c->base[ch]), n, k, 0., y);
+            orc_force(orc_icwrs(n, y));
+        }
         uint32_t idx = orc_rd_uniform(c->rd, orc_pvq_v(n, k));   /* celt/decoder.rs:662-673 */
         float ryy = (float)orc_cwrsi(n, k, idx, y);
         float g = gain / sqrtf(ryy);                              /* celt/decoder.rs:766-786 */
@@ -813,6 +855,11 @@ static int celt_frame(OrcCelt *st, OrcRd *rd, int N, int start, int end, int C, 
                 if (i < start || i >= end) { *en = 0.f; continue; }
                 if (conceal) { *en = *en - decay > -28.f ? *en - decay : -28.f; continue; }
                 int avail = total_bits - orc_rd_tell(rd), qi;
+                if (orc_force_on && avail >= 1) {
+                    int cls = avail >= 15 ? 0 : avail >= 2 ? 1 : 2;
+                    int64_t want = enc_hook(1, i, c, cls, 0, 0, (double)((*en > -9.f ? *en : -9.f) * alpha + prev[c]), NULL);
+                    orc_force(cls == 0 ? want : cls == 1 ? (want == 0 ? 0 : want < 0 ? 1 : 2) : want < 0);
+                }
                 if (avail >= 15) { int k = (i < 20 ? i : 20) << 1; qi = orc_rd_laplace(rd, model[k] << 7, model[k + 1] << 6); }
                 else if (avail >= 2) { qi = orc_rd_icdf(rd, ICDF_CELT_ENERGY_SMALL); qi = (qi >> 1) ^ -(qi & 1); }
                 else if (avail >= 1) qi = -orc_rd_logp(rd, 1);
@@ -859,6 +906,7 @@ static int celt_frame(OrcCelt *st, OrcRd *rd, int N, int start, int end, int C, 
         offsets[i] = boost;
         if (boost > 0 && dynalloc_logp > 2) dynalloc_logp--;
     }
+    if (orc_force_on && tellf + 48 <= tbits) orc_force(5);
     int alloc_trim = tellf + 48 <= tbits ? orc_rd_icdf(rd, ICDF_CELT_ALLOC_TRIM) : 5;
     int bits = (total_bits << 3) - orc_rd_tell_frac(rd) - 1;
     int anti_rsv = transient && lm >= 2 && bits >= (lm + 2) << 3 ? 8 : 0;
@@ -943,6 +991,7 @@ static int celt_frame(OrcCelt *st, OrcRd *rd, int N, int start, int end, int C, 
             int band_width = CELT_EBANDS[coded_bands] - CELT_EBANDS[j];
             int band_bits = pulses[j] + percoeff * band_width + rem;
             if (band_bits >= (thresh[j] > alloc_floor + 8 ? thresh[j] : alloc_floor + 8)) {
+                if (orc_force_on) orc_force(1);
                 if (orc_rd_logp(rd, 1)) break;
                 psum += 8;
                 band_bits -= 8;
@@ -953,8 +1002,10 @@ static int celt_frame(OrcCelt *st, OrcRd *rd, int N, int start, int end, int C, 
             if (band_bits >= alloc_floor) { psum += alloc_floor; pulses[j] = alloc_floor; }
             else pulses[j] = 0;
         }
+        if (orc_force_on && intensity_rsv > 0) orc_force(coded_bands - start);      /* (encoder: no intensity stereo ...) */
         if (intensity_rsv > 0) intensity = start + orc_rd_uniform(rd, coded_bands + 1 - start);
         if (intensity <= start) { total += dual_rsv; dual_rsv = 0; }
+        if (orc_force_on && dual_rsv > 0) orc_force(1);                             /* (... the channels coded one by one) */
         if (dual_rsv > 0) dual_stereo = orc_rd_logp(rd, 1);
         int left = total - psum;
         int span = CELT_EBANDS[coded_bands] - CELT_EBANDS[start];
@@ -1012,6 +1063,7 @@ static int celt_frame(OrcCelt *st, OrcRd *rd, int N, int start, int end, int C, 
     for (int i = start; i < end; i++) {
         if (fine_quant[i] <= 0) continue;
         for (int c = 0; c < C; c++) {
+            if (orc_force_on) orc_force(enc_hook(2, i, c, fine_quant[i], 0, 0, (double)st->oldE[c][i], NULL));
             int q2 = orc_rd_rawbits(rd, fine_quant[i]);
             st->oldE[c][i] += ((float)q2 + 0.5f) * (float)(1 << (14 - fine_quant[i])) * (1.f / 16384) - 0.5f;
         }
@@ -1037,6 +1089,7 @@ static int celt_frame(OrcCelt *st, OrcRd *rd, int N, int start, int end, int C, 
             for (int i = start; i < end && bits_left >= C; i++) {
                 if (fine_quant[i] >= 8 || fine_priority[i] != prio) continue;
                 for (int c = 0; c < C; c++) {
+                    if (orc_force_on) orc_force(enc_hook(3, i, c, fine_quant[i], 0, 0, (double)st->oldE[c][i], NULL));
                     int q2 = orc_rd_rawbits(rd, 1);
                     st->oldE[c][i] += ((float)q2 - 0.5f) * (float)(1 << (14 - fine_quant[i] - 1)) * (1.f / 16384);
                     bits_left--;

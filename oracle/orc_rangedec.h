@@ -39,6 +39,21 @@ static inline void orc_trace3(uint32_t a, uint32_t b, uint32_t c)
     }
 }
 
+/* Forced mode (tests/test_loopback.py: the decoder run as an ENCODER).  With orc_force_on set the primitives below do not look at
+ * the payload: each takes the symbol queued with orc_force() (0 when none is queued), updates the range and the bit count exactly
+ * as if it had decoded that symbol, and logs it to the trace -- raw bits as (0xFFFFFFFF, value, count) -- from which the test
+ * range-ENcodes a packet.  The decoder thereby makes every decision of the bit allocation itself; the test only chooses values. */
+extern int orc_force_on, orc_force_have;
+extern int64_t orc_force_val;
+static inline void orc_force(int64_t v) { orc_force_val = v; orc_force_have = 1; }
+static inline int orc_forced(int64_t *v)
+{
+    if (!orc_force_on) return 0;
+    *v = orc_force_have ? orc_force_val : 0;
+    orc_force_have = 0;
+    return 1;
+}
+
 static inline int orc_ilog(uint32_t v) { return v ? 32 - __builtin_clz(v) : 0; }  /* maths.rs:8-18 */
 
 static inline uint32_t orc_fwd_byte(OrcRd *rd)   /* entropy.rs:38-56 (8-bit get at any bit offset) */
@@ -108,7 +123,9 @@ static inline int orc_rd_logp(OrcRd *rd, int logp)   /* entropy.rs:339-355 */
 {
     uint32_t scale = rd->range >> logp;
     int k;
-    if (scale > rd->value) { rd->range = scale; k = 1; }
+    int64_t fv;
+    if (orc_forced(&fv)) { k = fv != 0; if (k) rd->range = scale; else rd->range -= scale; }
+    else if (scale > rd->value) { rd->range = scale; k = 1; }
     else { rd->range -= scale; rd->value -= scale; k = 0; }
     orc_trace3(k ? (1u << logp) - 1 : 0, k ? 1u << logp : (1u << logp) - 1, 1u << logp);
     orc_rd_normalize(rd);
@@ -124,7 +141,9 @@ static inline int orc_rd_icdf_tab(OrcRd *rd, const uint16_t *t)
     uint32_t total = t[0], scale;
     uint32_t sym = orc_rd_symbol(rd, total, &scale);
     int k = 0;
-    while (t[2 + k] <= sym) k++;
+    int64_t fv;
+    if (orc_forced(&fv)) k = (int)fv < (int)t[1] ? (int)fv : (int)t[1] - 1;
+    else while (t[2 + k] <= sym) k++;
     orc_rd_update(rd, scale, k ? t[1 + k] : 0, t[2 + k], total);
     return k;
 }
@@ -132,6 +151,13 @@ static inline int orc_rd_icdf_tab(OrcRd *rd, const uint16_t *t)
 static inline uint32_t orc_rd_rawbits(OrcRd *rd, int n)   /* entropy.rs:5-19, 422-425 */
 {
     if (n == 0) return 0;
+    int64_t fv;
+    if (orc_forced(&fv)) {
+        uint32_t fb = (uint32_t)fv & (uint32_t)((1ull << n) - 1);
+        rd->total += n;
+        orc_trace3(0xFFFFFFFFu, fb, (uint32_t)n);
+        return fb;
+    }
     while (rd->ebits < n) {
         uint64_t b = rd->epos < rd->len ? rd->buf[rd->len - 1 - rd->epos] : 0;
         rd->ewin |= b << rd->ebits;
@@ -148,6 +174,12 @@ static inline uint32_t orc_rd_uniform(OrcRd *rd, uint32_t len)   /* entropy.rs:4
     int bits = orc_ilog(len - 1);
     uint32_t total = bits > 8 ? ((len - 1) >> (bits - 8)) + 1 : len, scale;
     uint32_t k = orc_rd_symbol(rd, total, &scale);
+    int64_t fv;
+    if (orc_forced(&fv)) {
+        uint32_t want = (uint64_t)fv < len ? (uint32_t)fv : len - 1;
+        k = bits > 8 ? want >> (bits - 8) : want;
+        if (bits > 8) orc_force(want & ((1u << (bits - 8)) - 1));       /* the low bits follow as raw bits */
+    }
     orc_rd_update(rd, scale, k, k + 1, total);
     if (bits > 8) {
         k = (k << (bits - 8)) | orc_rd_rawbits(rd, bits - 8);
@@ -163,6 +195,32 @@ static inline int orc_rd_laplace(OrcRd *rd, uint32_t symbol, int decay)   /* ent
     center = (1u << 15) - (center < (1u << 15) ? center : (1u << 15));
     int value = 0;
     uint32_t low = 0;
+    int64_t fv;
+    if (orc_forced(&fv)) {                  /* the intervals the loop below walks, up to the wanted value (RFC 6716 laplace.c) */
+        int want = (int)fv, mag = want < 0 ? -want : want;
+        if (mag) {
+            value = 1;
+            low = symbol;
+            symbol = 1 + ((32768 - 32 - symbol) * (16384 - (uint32_t)decay) >> 15);
+            while (symbol > 1 && value < mag) {
+                value++;
+                symbol *= 2;
+                low += symbol;
+                symbol = (((symbol - 2) * (uint32_t)decay) >> 15) + 1;
+            }
+            if (symbol <= 1 && value < mag) {
+                uint32_t dist = (uint32_t)(mag - value), room = (32768 - 2 - low) >> 1;       /* both signs must still fit below 32768 */
+                if (dist > room) dist = room;
+                value += (int)dist;
+                low += 2 * dist;
+            }
+            if (want < 0) value = -value;
+            else low += symbol;
+        }
+        uint32_t fhigh = low + symbol;
+        orc_rd_update(rd, scale, low, fhigh < 32768 ? fhigh : 32768, 32768);
+        return value;
+    }
     if (center >= symbol) {
         value = 1;
         low = symbol;
@@ -191,6 +249,8 @@ static inline uint32_t orc_rd_step(OrcRd *rd, uint32_t k0)   /* entropy.rs:487-5
     uint32_t k1 = (k0 + 1) * 3, total = k1 + k0, scale;
     uint32_t sym = orc_rd_symbol(rd, total, &scale);
     uint32_t k = sym < k1 ? sym / 3 : sym - (k0 + 1) * 2;
+    int64_t fv;
+    if (orc_forced(&fv)) k = (uint64_t)fv <= 2 * k0 ? (uint32_t)fv : 2 * k0;
     if (k <= k0) orc_rd_update(rd, scale, 3 * k, 3 * (k + 1), total);
     else orc_rd_update(rd, scale, (k - 1 - k0) + k1, (k - k0) + k1, total);
     return k;
@@ -208,6 +268,14 @@ static inline uint32_t orc_rd_triangular(OrcRd *rd, uint32_t qn)   /* entropy.rs
     uint32_t qn2 = qn >> 1, total = (qn2 + 1) * (qn2 + 1), scale;
     uint32_t center = orc_rd_symbol(rd, total, &scale);
     uint32_t k, low, sym;
+    int64_t fv;
+    if (orc_forced(&fv)) {
+        k = (uint64_t)fv <= qn ? (uint32_t)fv : qn;
+        if (k <= qn2) { low = k * (k + 1) >> 1; sym = k + 1; }
+        else { low = total - ((qn + 1 - k) * (qn + 2 - k) >> 1); sym = qn + 1 - k; }
+        orc_rd_update(rd, scale, low, low + sym, total);
+        return k;
+    }
     if (center < total >> 1) {
         k = (orc_isqrt(8 * center + 1) - 1) >> 1;
         low = k * (k + 1) >> 1;

@@ -141,6 +141,25 @@ def test_silk_wb_mono_batch_c3_shape():
             assert np.array_equal(out, r), f"stream {s} step {t}"
 
 
+def test_silk_wb_mono_c3_full_size_16384_streams():
+    """BASELINE config 3 at its full size: 16 384 SILK-only WB mono 20 ms streams in one batch, four steps; 64 sampled streams
+    (spread over the wavefronts' eight channel slots) bit-exact against the oracle, and streams fed the same packets equal"""
+    V = orc.load_vectors(ids=[4, 12])
+    pool = [p for vid in (4, 12) for p in V[vid][1] if (p[0] >> 3) == 9 and not (p[0] & 4) and (p[0] & 3) == 0]
+    ns, steps, period = 16384, 4, 2048
+    dec = BatchDecoder(ns, 1, 0)
+    sample = sorted(set(list(range(0, ns, 293)) + [1, 7, 8, ns - 1]))
+    refs = {s: orc.Decoder(1) for s in sample}
+    for t in range(steps):
+        pk = [pool[((s % period) * 7 + t) % len(pool)] for s in range(ns)]
+        assert not any(dec.send(pk))
+        dec.decode()
+        for s in sample:
+            assert np.array_equal(dec.read(s), refs[s].decode(pk[s])), f"stream {s} step {t}"
+        for s in (0, 5, 1000, 2047):                      # same packets, other slots of other wavefronts
+            assert np.array_equal(dec.read(s), dec.read(s + period)) and np.array_equal(dec.read(s), dec.read(s + 7 * period))
+
+
 @pytest.mark.parametrize("stereo", [0, 1])
 def test_random_silk_payloads_with_lbrr_on_gpu(stereo):
     """any bytes are a valid SILK packet and about half carry LBRR (in-band FEC) flags, where the reference returns
@@ -273,3 +292,26 @@ def test_fec_recovery_on_gpu(vid, npk):
         feed(pk[i], want_i, f"packet {i}")
         i += 1
     assert recovered >= 20, recovered
+
+
+def test_celt_loopback_on_gpu():
+    """encode -> decode loopback (tests/test_loopback.py: a known signal encoded into CELT packets by the oracle's decoder run
+    backwards over a textbook f64 MDCT): the HIP path must give the SOURCE back (SNR >= 20 dB at 64 kb/s per channel, the same
+    alignment to the sample), beside matching the oracle"""
+    import test_loopback as TL
+    nframes = 24
+    src, packets, _ = TL.encode_stream(2, nframes, 320)
+    d = Decoder(0)
+    d.configure()
+    ref = orc.Decoder(2)
+    outs = []
+    for i, p in enumerate(packets):
+        d.send_packet(p)
+        out = d.receive_frame()
+        check_pcm(ref.decode(p), out, f"loopback frame {i}")
+        outs.append(out)
+    got = np.concatenate(outs)[2 * TL.N:]
+    want = TL.aligned(src, nframes)
+    assert TL.snr_db(want, got) >= 20.0, TL.snr_db(want, got)
+    assert TL.snr_db(want[1:], got[:-1]) < 16.0          # (a one-sample slip would show)
+

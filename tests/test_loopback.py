@@ -1,0 +1,204 @@
+"""Encode -> decode loopback: ground truth for the CELT path that is not the oracle's own output.
+
+The reference is a decoder and holds no CELT encoder, no CELT golden PCM and no code behind the band decoding (celt/decoder.rs
+ends at decode_bands), so everything after the PVQ is pinned here from the signal side: a known signal is ENCODED into CELT
+packets, and whatever decodes them -- the oracle, the host parser + kernel bodies, the GPU -- must give the signal back.
+
+The encoder is the oracle's decoder run backwards (oracle/orc_rangedec.h, forced mode): the decoder walks a frame exactly as it
+would decode it and makes every bit-allocation decision itself, but each value it would read is ASKED of this file, which answers
+from the textbook f64 MDCT of the source (tests/test_oracle_kats.py: mdct_forward) -- band energies, split angles, pulse vectors
+(a greedy PVQ search) -- and the range ENcoder of tests/test_lbrr.py writes the answers into a packet.  A transform, window,
+overlap, band layout, energy or sign convention that is wrong in the decoder cannot reproduce the source; the PVQ codebook, the
+range coder and the allocation are exercised on bits that no decoder wrote.  Three checks per stream: the packet decodes to
+exactly what the forced run produced (the packet says what was meant); decoded vs source SNR; product vs oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import orc
+from gpu_util import check_pcm
+from test_lbrr import RangeEncoder
+from test_oracle_kats import mdct_forward
+
+L = orc.lib()
+HOOK = C.CFUNCTYPE(C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_int))
+L.orc_set_encoder.argtypes = [HOOK]
+L.orc_icwrs.restype = C.c_uint32
+N = 960
+EBANDS = [0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 20, 24, 28, 34, 40, 48, 60, 78, 100]      # RFC 6716 table 55 (x 8 bins at 20 ms)
+EMEANS = [6.4375, 6.25, 5.75, 5.3125, 5.0625, 4.8125, 4.5, 4.375, 4.875, 4.6875, 4.5625, 4.4375, 4.875, 4.625, 4.3125, 4.5,
+          4.375, 4.625, 4.75, 4.4375, 3.75]                                                       # RFC 6716 4.3.2.1 (quant_bands.c eMeans)
+PREEMPH = 0.85000610
+
+
+def pvq_search(t, k):
+    """the pulse vector y (integers, sum |y| = k) closest in direction to t: projection, then greedy pulses"""
+    a = np.abs(t)
+    s = a.sum()
+    if s < 1e-30:
+        y = np.zeros(len(t), np.int64)
+        y[0] = k
+        return y
+    y = np.floor(k * a / s).astype(np.int64)
+    xy, yy = float(a @ y), float(y @ y)
+    for _ in range(k - int(y.sum())):
+        gain = (xy + a) ** 2 / (yy + 2 * y + 1)
+        j = int(np.argmax(gain))
+        xy += a[j]
+        yy += 2 * y[j] + 1
+        y[j] += 1
+    return np.where(t < 0, -y, y)
+
+
+class Encoder:
+    """one stream: frames of N samples per channel in, CELT-only FB 20 ms packets of `nbytes` payload bytes out"""
+
+    def __init__(self, channels, nbytes):
+        self.cc, self.nbytes = channels, nbytes
+        self.dec = orc.Decoder(channels)                   # the decoder that is run forced: its state IS the encoder's state
+        self.toc = bytes([0xF8 | (4 if channels == 2 else 0)])
+        self.win = np.ctypeslib.as_array(C.cast(L.orc_celt_window(), C.POINTER(C.c_float)), (120,)).astype(np.float64)
+        self.mem = np.zeros(channels)
+        self.hist = np.zeros((channels, N))                # the previous block of pre-emphasised samples
+        self.hook = HOOK(self._ask)
+
+    def _ask(self, kind, band, ch, a, b, c, f, y):
+        if kind == 1:                                      # coarse energy: the integer that brings the prediction closest
+            want = int(np.round(self.E[ch][band] - f))
+            return max(-1, min(1, want)) if a == 1 else min(0, max(-1, want)) if a == 2 else want
+        if kind == 2:                                      # fine energy: the decoder adds (q + 1/2) / 2^bits - 1/2
+            return int(min((1 << a) - 1, max(0, np.floor((self.E[ch][band] - f + 0.5) * (1 << a)))))
+        if kind == 3:
+            return int(self.E[ch][band] > f)
+        if kind == 4:                                      # split angle between the two halves of a vector, in qn steps
+            mid, side = np.linalg.norm(self.F[ch][a:a + b]), np.linalg.norm(self.F[ch][a + b:a + 2 * b])
+            return int(min(c, max(0, np.round(np.arctan2(side, mid) * 2 / np.pi * c))))
+        if kind == 5:
+            v = pvq_search(self.F[ch][a:a + b], c)
+            for i in range(b):
+                y[i] = int(v[i])
+            return 0
+        if kind == 6:
+            return int(self.F[ch][a] < 0)
+        raise AssertionError(kind)
+
+    def encode(self, frame):
+        """frame: (N, channels) in [-1, 1) -> (packet, the PCM the forced run produced)"""
+        self.F, self.E = [], []
+        for ch in range(self.cc):
+            x = frame[:, ch].astype(np.float64) * 32768.0
+            pre = x - PREEMPH * np.concatenate([[self.mem[ch]], x[:-1]])
+            self.mem[ch] = x[-1]
+            F = mdct_forward(np.concatenate([self.hist[ch], pre]), self.win) * (2.0 / N)
+            self.hist[ch] = pre
+            self.F.append(F)
+            self.E.append([np.log2(max(1e-9, np.linalg.norm(F[8 * EBANDS[i]:8 * EBANDS[i + 1]]))) - EMEANS[i] for i in range(21)])
+        buf = (C.c_uint32 * (3 * 16384))()
+        L.orc_trace_set(buf, 16384)
+        L.orc_set_encoder(self.hook)
+        try:
+            pcm = self.dec.decode(self.toc + bytes(self.nbytes))
+            n = L.orc_trace_count()
+        finally:
+            L.orc_set_encoder(HOOK(0))
+            L.orc_trace_set(None, 0)
+        assert n < 16384
+        syms = np.ctypeslib.as_array(buf).reshape(-1, 3)[:n]
+        enc, raw, nraw = RangeEncoder(), 0, 0
+        for lo, hi, tot in syms:
+            lo, hi, tot = int(lo), int(hi), int(tot)
+            if lo == 0xFFFFFFFF:                           # raw bits: read from the END of the frame, least significant first
+                raw |= hi << nraw
+                nraw += tot
+            elif hi:
+                enc.encode(lo, hi, tot)
+        front = enc.done()
+        out = bytearray(self.nbytes)
+        out[:len(front)] = front
+        back = raw.to_bytes((nraw + 7) // 8, "little")
+        assert len(front) + len(back) <= self.nbytes + 1, (len(front), len(back))
+        for i, v in enumerate(back):
+            assert out[self.nbytes - 1 - i] & v == 0
+            out[self.nbytes - 1 - i] |= v
+        return self.toc + bytes(out), pcm
+
+
+def source(channels, nframes, seed=5):
+    """tones (different ones per channel), a slow sweep and a little noise; peak below 0.6"""
+    rng = np.random.default_rng(seed)
+    t = np.arange((nframes + 1) * N) / 48000.0
+    cols = []
+    for ch in range(channels):
+        f = [220.0, 1318.5, 4186.0] if ch == 0 else [329.6, 2093.0, 6271.9]
+        s = sum(0.15 / (1 + i) * np.sin(2 * np.pi * fi * t + i + ch) for i, fi in enumerate(f))
+        s = s + 0.08 * np.sin(2 * np.pi * (500.0 + 900.0 * t) * t) + 0.002 * rng.standard_normal(len(t))
+        cols.append(s * np.minimum(1.0, t / 0.02))
+    return np.stack(cols, axis=1)
+
+
+def encode_stream(channels, nframes, nbytes):
+    src = source(channels, nframes)
+    enc = Encoder(channels, nbytes)
+    packets, forced = [], []
+    for b in range(nframes):
+        p, pcm = enc.encode(src[b * N:(b + 1) * N])
+        packets.append(p)
+        forced.append(pcm)
+    return src, packets, forced
+
+
+def snr_db(ref, got):
+    return 10 * np.log10(float(np.sum(ref.astype(np.float64) ** 2)) / max(1e-30, float(np.sum((ref - got).astype(np.float64) ** 2))))
+
+
+def aligned(src, nframes):
+    """decoded sample j of frame b is source sample (b - 1) N + N / 2 - 60 + j: the frame the encoder's block b ENDS with is the one
+    its window is centred on (tests/test_oracle_kats.py), and block b = [previous frame | this frame]"""
+    lag = N // 2 - 60 - N
+    return src[2 * N + lag:nframes * N + lag]
+
+
+def test_icwrs_inverts_cwrsi():
+    rng = np.random.default_rng(1)
+    for n, k in [(2, 1), (3, 7), (8, 4), (16, 9), (24, 3), (48, 5), (96, 2), (176, 2), (11, 40)]:
+        v = int(L.orc_pvq_v(n, k))
+        for idx in [0, v - 1] + [int(rng.integers(0, v)) for _ in range(20)]:
+            y = (C.c_int * n)()
+            L.orc_cwrsi(n, k, C.c_uint32(idx), y)
+            assert sum(abs(t) for t in y) == k and int(L.orc_icwrs(n, y)) == idx
+
+
+@pytest.mark.parametrize("channels,nbytes,floor_db", [(1, 160, 20.0), (2, 320, 20.0), (2, 640, 26.0), (2, 120, 12.0)])
+def test_celt_loopback_oracle(channels, nbytes, floor_db):
+    nframes = 30
+    src, packets, forced = encode_stream(channels, nframes, nbytes)
+    dec = orc.Decoder(channels)
+    out = [dec.decode(p) for p in packets]
+    for b in range(nframes):                               # the packets carry exactly the values the forced run was given
+        assert np.array_equal(out[b], forced[b]), f"frame {b}"
+    got = np.concatenate(out)[2 * N:]
+    ref = aligned(src, nframes)
+    s = snr_db(ref, got.reshape(ref.shape))
+    assert s >= floor_db, f"decoded vs source: {s:.1f} dB"
+    if channels == 2:                                      # the channels carry different tones: no leakage from one into the other
+        assert snr_db(ref[:, 0], got[:, 1]) < 3.0
+
+
+def test_celt_loopback_product(request):
+    """the same packets through the host parser + the kernel bodies (g++ build): against the oracle, and against the source"""
+    from test_emu_silk import EmuDecoder
+    emu = request.getfixturevalue("emu")
+    nframes = 20
+    src, packets, _ = encode_stream(2, nframes, 320)
+    d, ref = EmuDecoder(emu, 2), orc.Decoder(2)
+    outs = []
+    for i, p in enumerate(packets):
+        out = d.decode(p)
+        check_pcm(ref.decode(p), out, f"frame {i}")
+        outs.append(out)
+    got = np.concatenate(outs)[2 * N:]
+    assert snr_db(aligned(src, nframes), got) >= 20.0
+
+
+from test_emu_silk import emu  # noqa: E402,F401  (fixture)
