@@ -53,6 +53,7 @@ def parse_args():
                          "c3: BASELINE configs[2], SILK WB mono 20 ms, 16384 streams per GPU (SURVEY.md 8d); "
                          "c4: BASELINE configs[3], hybrid SWB/FB + CELT of every frame size, 8192 streams per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end leg (packets in host memory -> PCM in HBM; reported as `end_to_end`)")
     ap.add_argument("--no-side-stream", action="store_true", help="c4: every launch of a step on one stream (default: the stateless CELT "
                                                                   "kernels on a side stream beside the SILK launches, as opusgpu_batch_decode does)")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle comparison of the last step's PCM")
@@ -272,6 +273,7 @@ def main_c3(a, rank, local_rank, world):
             dist.destroy_process_group()
         return
     alg = S * C3_ALG_BYTES
+    c3_traffic, c3_pmc = pmc_info("c3", launch_s) if S == C3_STREAMS_PER_GPU else (None, None)      # collected at the default size only
     line = {"metric": "decoded audio-sec/sec (SILK WB mono 20 ms, 16384 streams)",
             "value": round(sharding.aggregate_audio_seconds_per_second(world, S, K, FRAME_S, elapsed), 1), "unit": "audio-s/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True,
@@ -284,11 +286,13 @@ def main_c3(a, rank, local_rank, world):
                        "parallelism": f"streams sharded over {world} GPU(s), one process per GPU, no collective in the data path; "
                                       "RCCL only for the barrier and the max of the elapsed times"},
             "roofline": {"bound": "hbm", "achieved": round(alg / launch_s / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(alg / launch_s / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(alg / launch_s / 1e9 / HBM_PEAK_GBS, 5), "traffic": c3_traffic,
                          "kernel": "one opusgpu_launch_silk call: og_silk_synth_kernel + og_silk_output_kernel",
                          "avg_launch_us": round(launch_s * 1e6, 2), "algorithmic_bytes_per_launch": alg},
             "host_parse": {"value": round(S * nsteps * FRAME_S / t_parse, 1), "unit": "audio-s/s",
                            "note": "packets -> side-info on the host threads (untimed in `value`)"}}
+    if c3_pmc:
+        line["pmc"] = c3_pmc
     if not a.no_cpu_baseline:
         from concurrent.futures import ThreadPoolExecutor
         sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -507,6 +511,7 @@ def main_c4(a, rank, local_rank, world):
         return
     total_audio = audio_s * world                       # (every rank decodes the same mix: weak scaling)
     alg = alg_total / K
+    c4_traffic, c4_pmc = pmc_info("c4", step_s) if S == C4_STREAMS_PER_GPU else (None, None)
     line = {"metric": "decoded audio-sec/sec (hybrid SWB/FB + CELT 2.5-20 ms mixed, 8192 streams)",
             "value": round(total_audio / elapsed, 1), "unit": "audio-s/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True,
@@ -521,12 +526,14 @@ def main_c4(a, rank, local_rank, world):
                        "parallelism": f"streams sharded over {world} GPU(s), one process per GPU, no collective in the data path; "
                                       f"{a.backend} only for the barrier and the max of the elapsed times"},
             "roofline": {"bound": "hbm", "achieved": round(alg / step_s / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(alg / step_s / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(alg / step_s / 1e9 / HBM_PEAK_GBS, 5), "traffic": c4_traffic,
                          "kernel": "one step: opusgpu_launch_silk per SILK depth (og_silk_synth_kernel + og_silk_output_kernel) + one "
                                    "opusgpu_launch_celt[_runs] (og_pvq_all_kernel + og_plan_kernel + og_celt_kernel + og_celt_tail_kernel)",
                          "avg_launch_us": round(step_s * 1e6, 2), "algorithmic_bytes_per_launch": int(alg)},
             "host_parse": {"value": round(audio_s / K * nsteps / t_parse, 1), "unit": "audio-s/s",
                            "note": "packets -> side-info + launch plan on the host threads (untimed in `value`)"}}
+    if c4_pmc:
+        line["pmc"] = c4_pmc
     if not a.no_cpu_baseline:
         from concurrent.futures import ThreadPoolExecutor
         sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -548,6 +555,31 @@ def main_c4(a, rank, local_rank, world):
     print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def pmc_info(workload, step_s=None):
+    """profiles/pmc_traffic.json (tools/gpu_measure.sh + tools/pmc_traffic.py: rocprofv3 --pmc passes over this bench at its default
+    sizes) for one workload -> (HBM bytes per step or None, the `pmc` object of the bench line or None).  Per kernel: HBM bytes,
+    VALU issue fraction (4 x SQ_INSTS_VALU over the SIMD cycles of the dispatch) and which of the two binds it."""
+    try:
+        w = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(workload)
+    except Exception:
+        w = None
+    if not w:
+        return None, None
+    ks = []
+    for name, e in w["kernels"].items():
+        k = {"kernel": name, "avg_us": e.get("avg_us"), "hbm_bytes": e.get("hbm_bytes"), "valu_issue_frac": e.get("valu_issue_frac")}
+        if e.get("avg_us") and e.get("hbm_bytes"):
+            k["hbm_frac"] = round(e["hbm_bytes"] / (e["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+            if e.get("valu_issue_frac") is not None:
+                k["bound"] = "valu" if e["valu_issue_frac"] >= max(0.5, k["hbm_frac"]) else "hbm" if k["hbm_frac"] >= 0.5 else "latency"
+        ks.append(k)
+    out = {"source": "profiles/pmc_traffic.json", "kernels": ks}
+    if step_s and w.get("insts_valu_per_step"):
+        # 1024 SIMDs x 2.4 GHz (MI355X_MICROARCH.md) x the live step time: what share of the step's SIMD cycles issue a VALU instruction
+        out["valu_issue_frac_of_step"] = round(4 * w["insts_valu_per_step"] / (1024 * 2.4e9 * step_s), 4)
+    return w.get("launch_bytes"), out
 
 
 def main():
@@ -795,19 +827,46 @@ def main():
               "note": "same workload, consecutive steps pipelined over two HIP streams: K1 + plan of step n + 1 beside the tail kernel of "
                       "step n (two scratch blocks); the first K1 + plan of the timed steps ran before the clock started"}
 
+    # ---- end to end, at every --gpus N: packets in host memory -> opusgpu_batch_send (host parse on the rank's threads, pinned to
+    #      the GPU's NUMA node) -> opusgpu_batch_decode (H2D + the same kernels), PCM left in HBM.  Same streams, same T frames
+    #      per stream per send.  Every rank runs it at once, as in production: the figure shows what the host side sustains.
+    e2e = None
+    if not a.no_e2e and P == 1:
+        ne, we = min(6, nsteps - 1), 1
+        edec = BatchDecoder(S, 2, local_rank)
+        pk_steps = [np.ascontiguousarray(packets[:, f * T:(f + 1) * T]) for f in range(ne + we)]
+        for f in range(we):
+            assert not edec.send_packed(pk_steps[f]).any()
+            edec.decode()
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for f in range(we, we + ne):
+            errs = edec.send_packed(pk_steps[f])
+            edec.decode()                                    # (waits for the step: the next send refills the host-side records)
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        ee = sharding.max_over_ranks(time.perf_counter() - t0, dev)
+        assert not errs.any()
+        e2e = {"value": round(sharding.aggregate_audio_seconds_per_second(world, S, ne, T * FRAME_S, ee), 1), "unit": "audio-s/s",
+               "steps": ne, "warmup": we, "ms_per_step": round(ee / ne * 1e3, 3), "parse_threads_per_rank": int(os.environ.get("OPUSGPU_THREADS", 0)) or min(16, os.cpu_count() or 1),
+               "note": "packets in host memory -> opusgpu_batch_send (host parse) -> opusgpu_batch_decode (H2D + kernels), PCM left in HBM; "
+                       "all ranks at once, max over ranks; bound by the host parser"}
+        edec.close()
+
     avg_kernel_s = elapsed / K                               # the calls run back to back on one stream: per call = step time
     avg_alg = sum(alg_bytes[W:]) / K
     achieved = avg_alg / avg_kernel_s / 1e9
     k2_s = sum(e0.elapsed_time(e1) for pt in parts for e0, e1 in pt["evk"][W:]) / K / 1e3       # og_celt_kernel alone (summed over sub-batches)
     k2_bytes = S * T * K2_BYTES
-    traffic = k2_traffic = None
-    tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")      # HBM bytes per launch from the rocprofv3 --pmc passes
-    if os.path.exists(tp) and S == STREAMS_PER_GPU and T == 8:   # collected on the default workload only
-        try:
-            tj = json.load(open(tp))
-            traffic, k2_traffic = tj.get("launch_bytes"), tj.get("og_celt_kernel_bytes")
-        except Exception:
-            traffic = k2_traffic = None
+    traffic = k2_traffic = c2_pmc = k2_valu = None
+    if S == STREAMS_PER_GPU and T == 8:                          # HBM bytes / VALU issue per launch from the rocprofv3 --pmc passes: the default workload only
+        traffic, c2_pmc = pmc_info("c2", avg_kernel_s)
+        for k in (c2_pmc or {}).get("kernels", []):
+            if k["kernel"] == "og_celt_kernel":
+                k2_traffic, k2_valu = k.get("hbm_bytes"), k.get("valu_issue_frac")
 
     if rank == 0:
         out = {
@@ -835,17 +894,25 @@ def main():
                          "algorithmic_bytes_per_launch": int(avg_alg),
                          "dominant": {"kernel": "og_celt_kernel", "avg_launch_us": round(k2_s * 1e6, 2), "bytes_per_launch": int(k2_bytes),
                                       "achieved": round(k2_bytes / k2_s / 1e9, 2), "frac": round(k2_bytes / k2_s / 1e9 / HBM_PEAK_GBS, 5),
-                                      "traffic": k2_traffic}},
+                                      "traffic": k2_traffic, "valu_issue_frac": k2_valu,
+                                      "bound": "valu" if (k2_valu or 0) >= 0.5 else "hbm"}},
             "host_parse": {"value": round(S * nframes * FRAME_S / t_parse, 1), "unit": "audio-s/s",
                            "note": "packets -> side-info on the host threads (untimed in `value`)",
                            "mean_leaves_per_frame": round(sum(nleaves) / (S * nframes), 1)},
         }
+        if c2_pmc:
+            out["pmc"] = c2_pmc
+            out["roofline"]["valu_issue_frac"] = c2_pmc.get("valu_issue_frac_of_step")
+            out["roofline"]["limiter"] = ("VALU issue and latency, not HBM: see pmc.kernels (og_celt_kernel issues a VALU instruction in most "
+                                          "SIMD cycles; K1, plan and tail are bound by dependent chains at their occupancy)")
         if t1:
             out["t1"] = t1
         if ov:
             out["two_sub_batches"] = ov
         if pl:
             out["pipelined"] = pl
+        if e2e:
+            out["end_to_end"] = e2e
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(packets)
         print(json.dumps(out), flush=True)
