@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(ROOT, "opus_amd", "libopusgpu.so")
+LIB_PATH = os.environ.get("OPUSGPU_LIB") or os.path.join(ROOT, "opus_amd", "libopusgpu.so")     # (OPUSGPU_LIB: tools/build_variant.py flavours)
 
 OK, INVALID_DATA, CONFIG_INVALID, CONFIG_INCOMPLETE, UNSUPPORTED, MORE_DATA_NEEDED, DEVICE, BAD_ARG = 0, -1, -2, -3, -4, -5, -6, -7
 

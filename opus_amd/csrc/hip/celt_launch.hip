@@ -97,6 +97,7 @@ __device__ __attribute__((noinline)) void og_pvq_coop(const OgLeafRef ref, const
     __syncthreads();
     if (active) og_coop_rot_pass<NS>(xl, L, ln, B, 1, c, s, sub);
     __syncthreads();
+    if (stamps) stamps[2] = (uint64_t)__builtin_readcyclecounter();       // (profiling: [1] .. [2] = scale + rotation, [2] .. [3] = store)
     if (out >> 26) {
         const int pos = (int)(out & 0xFFFFu), n = (int)((out >> 18) & 255u);
         const bool zr = ((out >> 17) & 1u) != 0;
