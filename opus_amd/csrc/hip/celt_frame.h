@@ -780,7 +780,7 @@ OG_DEV void og_wg_fft_stage(const OgCf *src_, OgCf *dst_, int tsh, const OgCf *W
 // For T1 <= 62 the rest runs in registers: a step's T1 - 2 new samples sit in lanes 4 .. T1 + 1 of one register behind the
 // previous step's last four (lanes 0 .. 3), the five taps are that register shifted down by 0 .. 4 lanes (DPP), and LDS only
 // sees the inputs coming in and the results going out -- nothing waits for an LDS round trip.  Longer periods take steps of up to
-// 128 samples through LDS (at most a dozen steps).  Same operations in the same order on every path.
+// 256 samples through LDS (at most a dozen steps).  Same operations in the same order on every path.
 OG_DEV void og_wave_comb_filter(float *y, int T0, int T1, int n, float g0, float g1, int tap0, int tap1,
                                 const float *window, const float (*taps)[4])
 {
@@ -792,21 +792,33 @@ OG_DEV void og_wave_comb_filter(float *y, int T0, int T1, int n, float g0, float
     const int overlap = (g0 == g1 && T0 == T1 && tap0 == tap1) ? 0 : 120;
     const int stop = g1 == 0.f ? overlap : n;          // with g1 == 0 only the cross-fade runs
     {
-        int step = (T0 < T1 ? T0 : T1) - 2;
-        if (step > 64) step = 64;
+        // only a set with a gain makes a sample depend on earlier output: a silent set's period (15 when the post-filter was
+        // off) does not shorten the steps.  A step's samples (at most 128: the whole cross-fade) are fetched together.
+        int lim = 1 << 20;
+        if (g0 != 0.f && T0 < lim) lim = T0;
+        if (g1 != 0.f && T1 < lim) lim = T1;
+        int step = lim - 2;
+        if (step > 128) step = 128;
         for (int i0 = 0; i0 < overlap; i0 += step) {
             const int i1 = i0 + step < overlap ? i0 + step : overlap;
             OG_WAVE_BEGIN(lane)
-            const int i = i0 + lane;
-            if (i < i1) {
+            float r[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int iu = i0 + lane + 64 * u, i = iu < i1 ? iu : i0;       // (idle items recompute the step's first sample)
                 const float f = window[i] * window[i];
                 const float *q0 = y + i - T0, *q1 = y + i - T1;
-                y[i] = y[i] + ((1.f - f) * g00) * q0[0]
+                r[u] = y[i] + ((1.f - f) * g00) * q0[0]
                      + ((1.f - f) * g01) * (q0[1] + q0[-1])
                      + ((1.f - f) * g02) * (q0[2] + q0[-2])
                      + (f * g10) * q1[0]
                      + (f * g11) * (q1[1] + q1[-1])
                      + (f * g12) * (q1[2] + q1[-2]);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int iu = i0 + lane + 64 * u;
+                if (iu < i1) y[iu] = r[u];
             }
             OG_WAVE_END
         }
@@ -843,13 +855,21 @@ OG_DEV void og_wave_comb_filter(float *y, int T0, int T1, int n, float g0, float
         return;
     }
     int step = T1 - 2;
-    if (step > 128) step = 128;
-    for (int i0 = overlap; i0 < stop; i0 += step) {
+    if (step > 256) step = 256;
+    for (int i0 = overlap; i0 < stop; i0 += step) {     // at most a dozen steps; a step's (up to four) samples per lane are fetched together
         const int i1 = i0 + step < stop ? i0 + step : stop;
         OG_WAVE_BEGIN(lane)
-        for (int i = i0 + lane; i < i1; i += 64) {
+        float r[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int iu = i0 + lane + 64 * u, i = iu < i1 ? iu : i0;
             const float *q1 = y + i - T1;
-            y[i] = y[i] + g10 * q1[0] + g11 * (q1[1] + q1[-1]) + g12 * (q1[2] + q1[-2]);
+            r[u] = y[i] + g10 * q1[0] + g11 * (q1[1] + q1[-1]) + g12 * (q1[2] + q1[-2]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int iu = i0 + lane + 64 * u;
+            if (iu < i1) y[iu] = r[u];
         }
         OG_WAVE_END
     }
@@ -1172,6 +1192,7 @@ struct alignas(16) OgTailLds {
     float carry[2][64];               // de-emphasis carries
     float dm[2];                      // the stream's de-emphasis memory, carried from frame to frame of the run
     float pad_[2];
+    uint32_t hh[84];                  // the heads (9 dwords each) of nine consecutive headers of the run
 };
 
 // (OgHdrHead, celt_plan.h: the head of OgCeltHdr, everything up to the band arrays, is what the tail needs of a header)
@@ -1213,11 +1234,12 @@ OG_DEV void og_celt_tail_run(const OgCeltHdr *hg, uint32_t nfr, OgCeltState *sta
     const bool reset0 = (hd.flags & OG_F_RESET) != 0;
     const uint32_t pos_start = reset0 ? 0u : OG_U32(st->pos);
     // what the run's comb filters read from before its first sample (frames after a reset inside the run read nothing older)
+    const OgHdrHead hn1 = nfr > 1 ? og_uniform(*(const OgHdrHead *)(hg + 1)) : hd;
     int R = 0;
     {
         int before = 0;
         for (uint32_t t = 0; t < nfr; t++) {
-            const OgHdrHead ht = t ? og_uniform(*(const OgHdrHead *)(hg + t)) : hd;
+            const OgHdrHead ht = t == 0 ? hd : t == 1 ? hn1 : og_uniform(*(const OgHdrHead *)(hg + t));
             if (t && (ht.flags & OG_F_RESET)) break;
             const int need = og_pf_reach(ht) - before;
             if (need > R) R = need;
@@ -1244,6 +1266,8 @@ OG_DEV void og_celt_tail_run(const OgCeltHdr *hg, uint32_t nfr, OgCeltState *sta
                 hv[j] = *(const OgF4 *)&st->hist[ch][(pos_start - 4u * (uint32_t)(g + 1)) & 1023u];     // pos is a multiple of 8
             }
         }
+        uint32_t hv9 = 0;
+        if (tid < 81) { const uint32_t fr = (uint32_t)tid / 9u; hv9 = ((const uint32_t *)(hg + (fr < nfr ? fr : nfr - 1)))[tid % 9]; }
         if (tid < CC0 * 60 && !reset0) ov = st->overlap[tid >= 60][tid >= 60 ? tid - 60 : tid];       // the previous frame's IMDCT tail
         if (tid < CC0 && !reset0) dm = st->deemph[tid];
 #pragma unroll
@@ -1256,6 +1280,7 @@ OG_DEV void og_celt_tail_run(const OgCeltHdr *hg, uint32_t nfr, OgCeltState *sta
         }
         if (tid < CC0 * 60) L.out[tid >= 60][OG_HIST + (tid >= 60 ? tid - 60 : tid)] = ov;
         if (tid < 2) L.dm[tid] = dm;
+        if (tid < 81) L.hh[tid] = hv9;
         OG_TLANES_END
     }
 
@@ -1268,6 +1293,16 @@ OG_DEV void og_celt_tail_run(const OgCeltHdr *hg, uint32_t nfr, OgCeltState *sta
     for (int j = 0; j < Lc; j++) aL *= coef;            // coef^Lc
     for (uint32_t t = 0; t < nfr; t++) {
         uint64_t *cyc = cycles ? cycles + (size_t)t * 64 : nullptr;
+        // the heads of frames t .. t + 8 wait in LDS (staged nine at a time: a header is a cache line of its own in HBM, and
+        // fetched where it is needed it cost the run a memory round trip per frame)
+        if (t && (t & 7u) == 0) {
+            OG_TLANES_BEGIN(tid)
+            uint32_t hv = 0;
+            if (tid < 81) { const uint32_t fr = t + (uint32_t)tid / 9u; hv = ((const uint32_t *)(hg + (fr < nfr ? fr : nfr - 1)))[tid % 9]; }
+            if (tid < 81) L.hh[tid] = hv;
+            OG_TLANES_END
+        }
+        const OgHdrHead hn = og_uniform(*(const OgHdrHead *)&L.hh[9 * ((t & 7u) + 1)]);
         const int lm = hd.lm & 3, M = 1 << lm, N = 120 << lm;
         const uint32_t flags = hd.flags;
         const int CC = (flags & OG_F_OUT_STEREO) ? 2 : 1;
@@ -1298,7 +1333,6 @@ OG_DEV void og_celt_tail_run(const OgCeltHdr *hg, uint32_t nfr, OgCeltState *sta
         }
         OG_TLANES_END
         // ---- the next frame's row starts its way in now; TDAC mirror (RFC 6716 mdct.c) of this one
-        const OgHdrHead hn = t + 1 < nfr ? og_uniform(*(const OgHdrHead *)(hg + t + 1)) : hd;
         {
             const bool more = t + 1 < nfr;
             const int CCn = (hn.flags & OG_F_OUT_STEREO) ? 2 : 1, Nn = 120 << (hn.lm & 3);
