@@ -43,7 +43,8 @@ def parse_args():
     ap.add_argument("--frames-per-step", type=int, default=8, help="consecutive frames of every stream decoded per step")
     ap.add_argument("--streams", type=int, default=STREAMS_PER_GPU, help="streams per GPU (BASELINE: 4096)")
     ap.add_argument("--no-t1", action="store_true", help="skip the one-frame-per-launch leg (reported as `t1`)")
-    ap.add_argument("--pipeline-leg", action="store_true", help="also time the steps pipelined over two HIP streams (reported as `pipelined`)")
+    ap.add_argument("--pipeline-leg", action="store_true", default=True, help="(default) also time the steps pipelined over two HIP streams (reported as `pipelined`)")
+    ap.add_argument("--no-pipeline-leg", dest="pipeline_leg", action="store_false")
     ap.add_argument("--no-overlap-leg", action="store_true", help="skip the two-sub-batch leg (reported as `two_sub_batches`)")
     ap.add_argument("--split", type=int, default=1,
                     help="issue each step as this many independent sub-batches of streams, each on a HIP stream of its own "
@@ -85,7 +86,7 @@ def cpu_baseline(packets, budget_s=12.0):
     import orc
     cores = min(16, os.cpu_count() or 1)          # the GPU box grants 16 CPUs per GPU
     nstreams, nframes = packets.shape[0], packets.shape[1]
-    sample_streams = min(nstreams, cores * 4)
+    sample_streams = min(nstreams, cores * 16)     # about 17 s of CPU work (a frame takes the oracle 0.26 ms)
     orc.lib()
 
     def work(s):
@@ -843,8 +844,9 @@ def main():
             dist.barrier()
         t0 = time.perf_counter()
         for f in range(we, we + ne):
-            errs = edec.send_packed(pk_steps[f])
-            edec.decode()                                    # (waits for the step: the next send refills the host-side records)
+            errs = edec.send_packed(pk_steps[f])             # (waits for the previous step's H2D copies only: opusgpu_batch_send)
+            edec.decode(sync=False)                          # asynchronous: the next step's parse runs beside this step's copies and kernels
+        edec.sync()
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()

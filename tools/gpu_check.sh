@@ -11,6 +11,6 @@ tail -3 "$out/pytest.log"
 timeout -k 10 240 python bench.py > "$out/bench.json" 2> "$out/bench.err" || { tail -20 "$out/bench.err"; exit 1; }
 cat "$out/bench.json"
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof" -- python3 "$R/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --no-t1 --no-overlap-leg > "$out/prof.log" 2>&1 || { tail -20 "$out/prof.log"; exit 1; }
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof" -- python3 "$R/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --no-t1 --no-overlap-leg --no-e2e --no-pipeline-leg > "$out/prof.log" 2>&1 || { tail -20 "$out/prof.log"; exit 1; }
 find "$out/prof" -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} "$out/kernel_stats.csv"
 head -8 "$out/kernel_stats.csv" | cut -c1-200

@@ -14,7 +14,7 @@ groups=(
   "WRITE_SIZE"
 )
 for w in ${@:-c2 c3 c4}; do
-  if [ "$w" = c2 ]; then args=(--no-t1 --no-overlap-leg --no-e2e); else args=(--workload "$w"); fi
+  if [ "$w" = c2 ]; then args=(--no-t1 --no-overlap-leg --no-e2e --no-pipeline-leg); else args=(--workload "$w"); fi
   timeout -k 10 240 python3 "$R/bench.py" "${args[@]}" --no-cpu-baseline > "$out/${w}_bench.json" 2> "$out/${w}_bench.err" || { tail -20 "$out/${w}_bench.err"; exit 1; }
   timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/${w}_prof" -- python3 "$R/bench.py" "${args[@]}" --steps 10 --warmup 2 --no-cpu-baseline > "$out/${w}_prof.log" 2>&1 || { tail -20 "$out/${w}_prof.log"; exit 1; }
   f=$(find "$out/${w}_prof" -name '*kernel_stats.csv' | head -1); cp "$f" "$out/${w}_kernel_stats.csv"

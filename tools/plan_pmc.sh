@@ -4,7 +4,7 @@
 set -o pipefail
 R="$PWD"; out="$R/gpurun_out/${1:-planpmc}"; mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-timeout -s KILL 150 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES --output-format csv -d "$out/p1" -- python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-verify --no-t1 --no-overlap-leg > "$out/p1.log" 2>&1 || { tail -5 "$out/p1.log"; exit 1; }
+timeout -s KILL 150 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES --output-format csv -d "$out/p1" -- python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-verify --no-t1 --no-overlap-leg --no-e2e --no-pipeline-leg > "$out/p1.log" 2>&1 || { tail -5 "$out/p1.log"; exit 1; }
 python3 - "$out" <<'PY'
 import csv, glob, sys
 from collections import defaultdict

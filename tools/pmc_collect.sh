@@ -5,7 +5,7 @@
 set -o pipefail
 out="gpurun_out/$1"; shift
 args=("$@")
-[ ${#args[@]} -eq 0 ] && args=(--steps 5 --warmup 2 --no-cpu-baseline --no-t1 --no-overlap-leg)
+[ ${#args[@]} -eq 0 ] && args=(--steps 5 --warmup 2 --no-cpu-baseline --no-t1 --no-overlap-leg --no-e2e --no-pipeline-leg)
 repo="$PWD"
 mkdir -p "$repo/$out"
 cd /tmp && export TMPDIR=/tmp

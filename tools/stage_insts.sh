@@ -10,6 +10,6 @@ repo="$PWD"
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
 for k in 1 2 3 5 6 7 0; do
-  OPUSGPU_STOP_AFTER=$k timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d "$out/stop$k" -- python3 "$repo/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-verify --no-t1 --no-overlap-leg > "$out/stop$k.log" 2>&1 || { echo "stop $k failed"; tail -5 "$out/stop$k.log"; exit 1; }
+  OPUSGPU_STOP_AFTER=$k timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d "$out/stop$k" -- python3 "$repo/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-verify --no-t1 --no-overlap-leg --no-e2e --no-pipeline-leg > "$out/stop$k.log" 2>&1 || { echo "stop $k failed"; tail -5 "$out/stop$k.log"; exit 1; }
   echo "stop $k ok"
 done
