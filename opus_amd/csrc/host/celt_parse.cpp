@@ -120,12 +120,14 @@ public:
         for (int g = 0; g < 4; g++) { cnt_[g] = 0; fold_[g] = false; }
     }
 
-    void band_n1(bool stereo)                                  // celt/decoder.rs:1466-1495
+    void band_n1(bool stereo, int chy)                         // celt/decoder.rs:1466-1495
     {
+        // stereo: both channels' signs in one call; otherwise the one channel the call is for (a dual-stereo band comes here
+        // once per channel: the second time for Y)
         for (int c = 0; c < (stereo ? 2 : 1); c++) {
             uint32_t sign = 0;
             if (remaining_ >= 1 << BITRES) { sign = rd_.bits(1); remaining_ -= 1 << BITRES; }
-            emit(0, 1, 0, 1, sign, false, 1.f, 0, c, false, true);
+            emit(0, 1, 0, 1, sign, false, 1.f, 0, stereo ? c : chy, false, true);
         }
     }
 
@@ -240,7 +242,7 @@ public:
     // level-0 wrapper (celt/decoder.rs:1708-1768): only the integer block bookkeeping matters here
     void quant_band(int N, int b, int B, int LM, float gain, int chy, bool lowband)
     {
-        if (N == 1) { band_n1(false); return; }
+        if (N == 1) { band_n1(false, chy); return; }
         int N_B = N / B, tf = tf_change_, recombine = tf > 0 ? tf : 0;
         B >>= recombine;
         N_B <<= recombine;
@@ -251,7 +253,7 @@ public:
     void quant_band_stereo(int N, int b, int B, int LM, bool lowband)       // celt/decoder.rs:1795-1862 + RFC bands.c
     {
         OgCeltBand &bd = hdr_->band[band_];
-        if (N == 1) { band_n1(true); return; }
+        if (N == 1) { band_n1(true, 0); return; }
         bd.flags |= OG_B_JOINT;
         Theta t = theta(N, b, B, B, LM, true);
         bd.imid = uint16_t(t.imid);

@@ -293,7 +293,10 @@ static int quant_band_n1(BandCtx *c, float *x, float *y, float *lowband_out)   /
     for (int ch = 0; ch < (y ? 2 : 1); ch++) {
         int sign = 0;
         if (c->remaining_bits >= 8) {
-            if (orc_force_on) orc_force(enc_hook(6, c->band, ch, (int)(p - c->base[ch]), 1, 0, 0., NULL));
+            if (orc_force_on) {
+                int pc = p >= c->base[1] && c->base[1] ? 1 : 0;     /* (a dual-stereo band comes here once per channel, as x) */
+                orc_force(enc_hook(6, c->band, pc, (int)(p - c->base[pc]), 1, 0, 0., NULL));
+            }
             sign = orc_rd_rawbits(c->rd, 1);
             c->remaining_bits -= 8;
         }

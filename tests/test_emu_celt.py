@@ -122,6 +122,20 @@ def test_emu_synthetic(emu, payload):
         _run(emu, [pk[s, f].tobytes() for f in range(25)], 2)
 
 
+@pytest.mark.parametrize("channels", [1, 2])
+def test_emu_synthetic_every_celt_config(emu, channels):
+    """random payloads under every CELT-only TOC: NB / WB / SWB / FB x 2.5 / 5 / 10 / 20 ms, mono and stereo packets, two rates,
+    into a mono and a stereo decoder.  (The RFC vectors and the 20 ms synthetic streams leave corners dark: a dual-stereo band of
+    one bin at 2.5 ms put its second sign on the wrong channel until tests/test_loopback.py found it.)"""
+    for config in range(16, 32):
+        lm = config & 3
+        for stereo in (0, 1):
+            for rate in (1, 3):
+                payload = max(6, (10 << lm) * rate * (1 + stereo))
+                pk = synth.celt_fb_stereo_packets([1000 * config + 10 * stereo + rate], 10, payload, toc=config << 3 | stereo << 2)
+                _run(emu, [pk[0, f].tobytes() for f in range(10)], channels)
+
+
 def test_kernel_cwrsi_kats_and_exhaustive(emu):
     """the kernel's branch-uniform cwrsi (celt_pvq.h) against the reference's known answers (celt/decoder.rs:2414-2434),
     the oracle on every index of small codebooks, and on random indices of large ones (incl. the largest, V < 2^32)"""

@@ -52,15 +52,15 @@ def pvq_search(t, k):
 
 
 class Encoder:
-    """one stream: frames of N samples per channel in, CELT-only FB 20 ms packets of `nbytes` payload bytes out"""
+    """one stream: frames of n (120 | 240 | 480 | 960) samples per channel in, CELT-only FB packets of `nbytes` payload bytes out"""
 
-    def __init__(self, channels, nbytes):
-        self.cc, self.nbytes = channels, nbytes
+    def __init__(self, channels, nbytes, n=N):
+        self.cc, self.nbytes, self.n, self.m = channels, nbytes, n, n // 120
         self.dec = orc.Decoder(channels)                   # the decoder that is run forced: its state IS the encoder's state
-        self.toc = bytes([0xF8 | (4 if channels == 2 else 0)])
+        self.toc = bytes([(28 + {120: 0, 240: 1, 480: 2, 960: 3}[n]) << 3 | (4 if channels == 2 else 0)])     # CELT-only FB, code 0
         self.win = np.ctypeslib.as_array(C.cast(L.orc_celt_window(), C.POINTER(C.c_float)), (120,)).astype(np.float64)
         self.mem = np.zeros(channels)
-        self.hist = np.zeros((channels, N))                # the previous block of pre-emphasised samples
+        self.hist = np.zeros((channels, n))                # the previous block of pre-emphasised samples
         self.hook = HOOK(self._ask)
 
     def _ask(self, kind, band, ch, a, b, c, f, y):
@@ -84,16 +84,16 @@ class Encoder:
         raise AssertionError(kind)
 
     def encode(self, frame):
-        """frame: (N, channels) in [-1, 1) -> (packet, the PCM the forced run produced)"""
+        """frame: (n, channels) in [-1, 1) -> (packet, the PCM the forced run produced)"""
         self.F, self.E = [], []
         for ch in range(self.cc):
             x = frame[:, ch].astype(np.float64) * 32768.0
             pre = x - PREEMPH * np.concatenate([[self.mem[ch]], x[:-1]])
             self.mem[ch] = x[-1]
-            F = mdct_forward(np.concatenate([self.hist[ch], pre]), self.win) * (2.0 / N)
+            F = mdct_forward(np.concatenate([self.hist[ch], pre]), self.win) * (2.0 / self.n)
             self.hist[ch] = pre
             self.F.append(F)
-            self.E.append([np.log2(max(1e-9, np.linalg.norm(F[8 * EBANDS[i]:8 * EBANDS[i + 1]]))) - EMEANS[i] for i in range(21)])
+            self.E.append([np.log2(max(1e-9, np.linalg.norm(F[self.m * EBANDS[i]:self.m * EBANDS[i + 1]]))) - EMEANS[i] for i in range(21)])
         buf = (C.c_uint32 * (3 * 16384))()
         L.orc_trace_set(buf, 16384)
         L.orc_set_encoder(self.hook)
@@ -124,10 +124,10 @@ class Encoder:
         return self.toc + bytes(out), pcm
 
 
-def source(channels, nframes, seed=5):
+def source(channels, nframes, seed=5, n=N):
     """tones (different ones per channel), a slow sweep and a little noise; peak below 0.6"""
     rng = np.random.default_rng(seed)
-    t = np.arange((nframes + 1) * N) / 48000.0
+    t = np.arange((nframes + 1) * n) / 48000.0
     cols = []
     for ch in range(channels):
         f = [220.0, 1318.5, 4186.0] if ch == 0 else [329.6, 2093.0, 6271.9]
@@ -137,12 +137,12 @@ def source(channels, nframes, seed=5):
     return np.stack(cols, axis=1)
 
 
-def encode_stream(channels, nframes, nbytes):
-    src = source(channels, nframes)
-    enc = Encoder(channels, nbytes)
+def encode_stream(channels, nframes, nbytes, n=N):
+    src = source(channels, nframes, n=n)
+    enc = Encoder(channels, nbytes, n)
     packets, forced = [], []
     for b in range(nframes):
-        p, pcm = enc.encode(src[b * N:(b + 1) * N])
+        p, pcm = enc.encode(src[b * n:(b + 1) * n])
         packets.append(p)
         forced.append(pcm)
     return src, packets, forced
@@ -152,11 +152,11 @@ def snr_db(ref, got):
     return 10 * np.log10(float(np.sum(ref.astype(np.float64) ** 2)) / max(1e-30, float(np.sum((ref - got).astype(np.float64) ** 2))))
 
 
-def aligned(src, nframes):
-    """decoded sample j of frame b is source sample (b - 1) N + N / 2 - 60 + j: the frame the encoder's block b ENDS with is the one
+def aligned(src, nframes, n=N):
+    """decoded sample j of frame b is source sample (b - 1) n + n / 2 - 60 + j: the frame the encoder's block b ENDS with is the one
     its window is centred on (tests/test_oracle_kats.py), and block b = [previous frame | this frame]"""
-    lag = N // 2 - 60 - N
-    return src[2 * N + lag:nframes * N + lag]
+    lag = n // 2 - 60 - n
+    return src[2 * n + lag:nframes * n + lag]
 
 
 def test_icwrs_inverts_cwrsi():
@@ -183,6 +183,27 @@ def test_celt_loopback_oracle(channels, nbytes, floor_db):
     assert s >= floor_db, f"decoded vs source: {s:.1f} dB"
     if channels == 2:                                      # the channels carry different tones: no leakage from one into the other
         assert snr_db(ref[:, 0], got[:, 1]) < 3.0
+
+
+@pytest.mark.parametrize("n,nbytes,floor_db", [(480, 160, 18.0), (240, 80, 14.0), (120, 48, 10.0)])
+def test_celt_loopback_short_frames(request, n, nbytes, floor_db):
+    """10 / 5 / 2.5 ms frames (the 240 / 120 / 60-point transforms, one-bin bands with their sign bits at 2.5 ms): oracle and
+    kernel bodies return the source at the rate's SNR, aligned to the sample"""
+    from test_emu_silk import EmuDecoder
+    emu = request.getfixturevalue("emu")
+    nframes = 4800 // n * 4
+    src, packets, forced = encode_stream(2, nframes, nbytes, n)
+    d, ref = EmuDecoder(emu, 2), orc.Decoder(2)
+    outs = []
+    for i, p in enumerate(packets):
+        want = ref.decode(p)
+        assert np.array_equal(want, forced[i]), f"frame {i}"
+        check_pcm(want, d.decode(p), f"frame {i}")
+        outs.append(want)
+    got, want = np.concatenate(outs)[2 * n:], aligned(src, nframes, n)
+    s = snr_db(want, got)
+    assert s >= floor_db, f"decoded vs source: {s:.1f} dB"
+    assert snr_db(want[1:], got[:-1]) < s - 3.0
 
 
 def test_celt_loopback_product(request):
