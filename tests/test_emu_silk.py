@@ -131,3 +131,48 @@ def test_lbrr_packets_decode(emu):
         n, *_ = hp.parse(p)
         assert n == 1
         assert d.decode(p).shape == (960, 2)
+
+
+def random_packet(rng, config, stereo, code):
+    """a packet with TOC (config, stereo, code) and random frame contents (the range decoder is total: any bytes decode)"""
+    ms = (10, 20, 40, 60)[config & 3] if config < 12 else (10, 20)[config & 1] if config < 16 else (2.5, 5, 10, 20)[config & 3]
+    size = lambda: int(rng.integers(2, max(4, int(ms * 6))))       # noqa: E731  (bytes per frame: up to ~48 kb/s)
+    toc = bytes([config << 3 | stereo << 2 | code])
+    body = lambda n: rng.integers(0, 256, n, dtype=np.uint8).tobytes()   # noqa: E731
+    if code == 0:
+        return toc + body(size())
+    if code == 1:
+        n = size()
+        return toc + body(2 * n)
+    if code == 2:
+        n1 = min(size(), 251)
+        return toc + bytes([n1]) + body(n1) + body(size())
+    m = int(rng.integers(1, max(2, int(120 // ms) + 1)))                 # code 3: M frames, at most 120 ms
+    m = min(m, 6)
+    if rng.integers(0, 2):                                               # CBR
+        n = size()
+        return toc + bytes([m]) + body(m * n)
+    sizes = [min(size(), 251) for _ in range(m)]                         # VBR: the first M - 1 sizes are coded
+    return toc + bytes([0x80 | m]) + bytes(sizes[:-1]) + b"".join(body(n) for n in sizes)
+
+
+@pytest.mark.parametrize("channels", [1, 2])
+def test_random_packets_every_toc(emu, channels):
+    """every configuration (SILK NB / MB / WB 10-60 ms, hybrid SWB / FB, CELT NB-FB 2.5-20 ms), mono and stereo packets, all four
+    frame-count codes, random contents, in random order through ONE decoder -- so every mode switch occurs as well: host parser
+    + kernel bodies against the oracle (SILK-only frames bit-exact, the rest at the CELT bar)."""
+    rng = np.random.default_rng(100 + channels)
+    d, ref = EmuDecoder(emu, channels), orc.Decoder(channels)
+    seen = set()
+    for i in range(700):
+        config, stereo, code = int(rng.integers(0, 32)), int(rng.integers(0, 2)), int(rng.integers(0, 4))
+        p = random_packet(rng, config, stereo, code)
+        r = ref.decode(p)
+        out = d.decode(p)
+        if isinstance(r, int) or r is None:
+            assert isinstance(out, int) and out < 0, f"packet {i}: oracle rejects, parser accepts"
+            continue
+        assert not isinstance(out, int), f"packet {i} (config {config}, code {code}): parser rejects ({out}), oracle accepts"
+        check_pcm(r, out, f"packet {i} (config {config}, stereo {stereo}, code {code})")
+        seen.add((config, stereo))
+    assert len(seen) == 64

@@ -320,3 +320,23 @@ def test_celt_loopback_on_gpu():
     assert TL.snr_db(want, got) >= 20.0, TL.snr_db(want, got)
     assert TL.snr_db(want[1:], got[:-1]) < 16.0          # (a one-sample slip would show)
 
+
+
+@pytest.mark.parametrize("channels", [1, 2])
+def test_random_packets_every_toc_on_gpu(channels):
+    """tests/test_emu_silk.py::test_random_packets_every_toc through the one-stream C ABI and the HIP kernels: every TOC
+    configuration, mono / stereo packets, all frame-count codes, random contents, one decoder (every mode switch), against the oracle"""
+    from test_emu_silk import random_packet
+    rng = np.random.default_rng(200 + channels)
+    d = Decoder(0)
+    if channels == 1:
+        d.set_extradata(b"OpusHead" + bytes([1, 1, 0, 0]) + (48000).to_bytes(4, "little") + bytes([0, 0, 0]))
+    d.configure()
+    ref = orc.Decoder(channels)
+    for i in range(500):
+        config, stereo, code = int(rng.integers(0, 32)), int(rng.integers(0, 2)), int(rng.integers(0, 4))
+        p = random_packet(rng, config, stereo, code)
+        d.send_packet(p)
+        out, r = d.receive_frame(), ref.decode(p)
+        assert out.shape == r.shape, f"packet {i} (config {config}, code {code})"
+        check_pcm(r, out, f"packet {i} (config {config}, stereo {stereo}, code {code})")
