@@ -130,14 +130,20 @@ uint32_t orc_icwrs(int n, const int *y)
  * kind: 1 coarse energy (a = alphabet: 0 Laplace, 1 {0,-1,+1}, 2 {0,-1}; f = the prediction the value adds to) -> qi
  *       2 fine energy (a = bits; f = the band's energy so far) -> 0 .. 2^bits - 1      3 final bit (a = fine bits so far) -> 0 | 1
  *       4 split angle (a = first bin of the vector in the frame, b = bins per half, c = qn) -> 0 .. qn
- *       5 pulses (a = first bin, b = bins, c = pulses; y: out, |y|_1 = c)             6 sign of a one-bin band (a = bin) -> 0 | 1
+ *       5 pulses (a = first bin, b = bins, c = pulses, f = blocks + 16 * spread; y: out, |y|_1 = c)
+ *       6 sign of a one-bin band (a = bin) -> 0 | 1       7 stereo angle of a jointly coded band (a = first bin, b = bins, c = qn) -> 0 .. qn
  * Everything else takes symbol 0 (no silence, no post-filter, no transient, inter energy, no tf change, no spreading rotation, no
  * boosts), except the allocation trim (5), the skip flags (1: code every band) and, for two channels, intensity = none and
  * dual stereo = 1 (each channel's bands coded like a mono band). */
 int orc_force_on = 0, orc_force_have = 0;
 int64_t orc_force_val = 0;
 static OrcEncHook enc_hook = 0;
+static int enc_transient = 0, enc_dual = 1, enc_spread = 0;
 void orc_set_encoder(OrcEncHook h) { enc_hook = h; orc_force_on = h != 0; orc_force_have = 0; }
+/* what the forced run codes for the frame-level tools (defaults: long blocks, dual stereo, no spreading rotation): transient = 1
+ * codes short blocks with every band's tf_change brought to 0 (first tf bit 1, the others 0: RFC 6716 table 60 then gives 0 at
+ * every LM); dual = 0 codes the bands jointly (kind 7 asks for the stereo angle); spread = 0 .. 3 */
+void orc_set_encoder_opts(int transient, int dual_stereo, int spread) { enc_transient = transient; enc_dual = dual_stereo; enc_spread = spread; }
 
 /* celt/decoder.rs:723-736.  Divergence: the reference ORs element e into bit (e mod B); RFC 6716
  * (vq.c extract_collapse_mask) uses contiguous blocks of N/B, which is what the de-interleaved
@@ -327,8 +333,9 @@ static void compute_theta(BandCtx *c, SplitCtx *s, int n, int *b, int B, int B0,
     if (stereo && c->band >= c->intensity) qn = 1;
     int tell = orc_rd_tell_frac(c->rd);
     if (qn != 1) {
-        if (orc_force_on) orc_force(stereo ? 0 : enc_hook(4, c->band, c->hx >= c->base[1] && c->base[1] ? 1 : 0,
-                                                          (int)(c->hx - c->base[c->hx >= c->base[1] && c->base[1] ? 1 : 0]), n, qn, 0., NULL));
+        if (orc_force_on) orc_force(stereo ? enc_hook(7, c->band, 0, (int)(c->hx - c->base[0]), n, qn, 0., NULL)
+                                           : enc_hook(4, c->band, c->hx >= c->base[1] && c->base[1] ? 1 : 0,
+                                                      (int)(c->hx - c->base[c->hx >= c->base[1] && c->base[1] ? 1 : 0]), n, qn, 0., NULL));
         if (stereo && n > 2) itheta = orc_rd_step(c->rd, qn / 2);
         else if (B0 > 1 || stereo) itheta = orc_rd_uniform(c->rd, qn + 1);
         else itheta = orc_rd_triangular(c->rd, qn);
@@ -404,7 +411,7 @@ static int quant_partition(BandCtx *c, float *x, int n, int b, int B, float *low
         if (orc_force_on) {
             int ch = x >= c->base[1] && c->base[1] ? 1 : 0;
             memset(y, 0, sizeof y);
-            enc_hook(5, c->band, ch, (int)(x - c->base[ch]), n, k, 0., y);
+            enc_hook(5, c->band, ch, (int)(x - c->base[ch]), n, k, (double)(B + 16 * c->spread), y);
             orc_force(orc_icwrs(n, y));
         }
         uint32_t idx = orc_rd_uniform(c->rd, orc_pvq_v(n, k));   /* celt/decoder.rs:662-673 */
@@ -495,6 +502,7 @@ static int quant_band_stereo(BandCtx *c, float *x, float *y, int n, int b, int B
     if (n == 1) return quant_band_n1(c, x, y, lowband_out);
     int orig_fill = fill, cm;
     SplitCtx s;
+    c->hx = x;
     compute_theta(c, &s, n, &b, B, B, lm, 1, &fill);
     float mid = (1.f / 32768) * s.imid, side = (1.f / 32768) * s.iside;
     if (c->tr && c->band < 21) { c->tr->itheta[c->band] = s.itheta; c->tr->inv[c->band] = s.inv; }
@@ -843,6 +851,7 @@ static int celt_frame(OrcCelt *st, OrcRd *rd, int N, int start, int end, int C, 
         tell = orc_rd_tell(rd);
     }
     int transient = 0;
+    if (orc_force_on && lm > 0 && tell + 3 <= total_bits) orc_force(enc_transient);
     if (lm > 0 && tell + 3 <= total_bits) { transient = orc_rd_logp(rd, 3); tell = orc_rd_tell(rd); }
     int short_blocks = transient ? M : 0;
     int intra = tell + 3 <= total_bits ? orc_rd_logp(rd, 3) : 0;
@@ -879,6 +888,7 @@ static int celt_frame(OrcCelt *st, OrcRd *rd, int N, int start, int end, int C, 
         int rsv = lm > 0 && tell + logp + 1 <= budget;
         budget -= rsv;
         for (int i = start; i < end; i++) {
+            if (orc_force_on && enc_transient && tell + logp <= budget) orc_force(i == start);
             if (tell + logp <= budget) { curr ^= orc_rd_logp(rd, logp); tell = orc_rd_tell(rd); changed |= curr; }
             tf_res[i] = curr;
             logp = transient ? 4 : 5;
@@ -891,6 +901,7 @@ static int celt_frame(OrcCelt *st, OrcRd *rd, int N, int start, int end, int C, 
     /* allocation: celt/decoder.rs:1035-1447, arithmetic per RFC 6716 rate.c where the two differ */
     tell = orc_rd_tell(rd);
     int spread = 2;
+    if (orc_force_on && tell + 4 <= total_bits) orc_force(enc_spread);
     if (tell + 4 <= total_bits) spread = orc_rd_icdf(rd, ICDF_CELT_SPREAD);   /* :1043 (kept, not discarded) */
     for (int i = 0; i < 21; i++) cap[i] = (CELT_CAPS[lm][C - 1][i] + 64) * C * (CELT_BAND_WIDTH[i] << lm) >> 2;
     int dynalloc_logp = 6, tbits = total_bits << 3;
@@ -1008,7 +1019,7 @@ static int celt_frame(OrcCelt *st, OrcRd *rd, int N, int start, int end, int C, 
         if (orc_force_on && intensity_rsv > 0) orc_force(coded_bands - start);      /* (encoder: no intensity stereo ...) */
         if (intensity_rsv > 0) intensity = start + orc_rd_uniform(rd, coded_bands + 1 - start);
         if (intensity <= start) { total += dual_rsv; dual_rsv = 0; }
-        if (orc_force_on && dual_rsv > 0) orc_force(1);                             /* (... the channels coded one by one) */
+        if (orc_force_on && dual_rsv > 0) orc_force(enc_dual);                      /* (... the channels coded one by one, or jointly) */
         if (dual_rsv > 0) dual_stereo = orc_rd_logp(rd, 1);
         int left = total - psum;
         int span = CELT_EBANDS[coded_bands] - CELT_EBANDS[start];

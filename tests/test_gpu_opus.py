@@ -305,20 +305,22 @@ def test_celt_loopback_on_gpu():
     alignment to the sample), beside matching the oracle"""
     import test_loopback as TL
     nframes = 24
-    src, packets, _ = TL.encode_stream(2, nframes, 320)
-    d = Decoder(0)
-    d.configure()
-    ref = orc.Decoder(2)
-    outs = []
-    for i, p in enumerate(packets):
-        d.send_packet(p)
-        out = d.receive_frame()
-        check_pcm(ref.decode(p), out, f"loopback frame {i}")
-        outs.append(out)
-    got = np.concatenate(outs)[2 * TL.N:]
-    want = TL.aligned(src, nframes)
-    assert TL.snr_db(want, got) >= 20.0, TL.snr_db(want, got)
-    assert TL.snr_db(want[1:], got[:-1]) < 16.0          # (a one-sample slip would show)
+    for tools, floor in (({}, 20.0), (dict(transient=True, joint=True, spread=2), 15.0)):      # plain; short blocks + joint stereo + spreading
+        src, packets, _ = TL.encode_stream(2, nframes, 320, **tools)
+        d = Decoder(0)
+        d.configure()
+        ref = orc.Decoder(2)
+        outs = []
+        for i, p in enumerate(packets):
+            d.send_packet(p)
+            out = d.receive_frame()
+            check_pcm(ref.decode(p), out, f"loopback frame {i}")
+            outs.append(out)
+        got = np.concatenate(outs)[2 * TL.N:]
+        want = TL.aligned(src, nframes)
+        assert TL.snr_db(want, got) >= floor, (tools, TL.snr_db(want, got))
+        assert TL.snr_db(want[1:], got[:-1]) < TL.snr_db(want, got) - 3.0          # (a one-sample slip would show)
+        d.close()
 
 
 

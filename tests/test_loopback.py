@@ -51,11 +51,48 @@ def pvq_search(t, k):
     return np.where(t < 0, -y, y)
 
 
+def _rot1(x, stride, c, s):
+    n = len(x)
+    for i in range(n - stride):
+        x1, x2 = x[i], x[i + stride]
+        x[i + stride] = c * x2 + s * x1
+        x[i] = c * x1 - s * x2
+    for i in range(n - 2 * stride - 1, -1, -1):
+        x1, x2 = x[i], x[i + stride]
+        x[i + stride] = c * x2 + s * x1
+        x[i] = c * x1 - s * x2
+
+
+def exp_rotation_forward(x, blocks, k, spread):
+    """RFC 6716 vq.c exp_rotation with dir = +1 -- what an ENCODER applies to a band before the pulse search (the decoder applies
+    dir = -1 to what it decoded); written from the RFC text, f64, in place"""
+    n = len(x)
+    if 2 * k >= n or spread == 0:
+        return
+    gain = n / (n + (15, 10, 5)[spread - 1] * k)
+    theta = 0.5 * gain * gain
+    c, s = np.cos(0.5 * np.pi * theta), np.cos(0.5 * np.pi * (1.0 - theta))
+    stride2 = 0
+    if n >= 8 * blocks:
+        stride2 = 1
+        while (stride2 * stride2 + stride2) * blocks + (blocks >> 2) < n:
+            stride2 += 1
+    m = n // blocks
+    for i in range(blocks):
+        v = x[i * m:(i + 1) * m]
+        _rot1(v, 1, c, -s)
+        if stride2:
+            _rot1(v, stride2, s, -c)
+
+
 class Encoder:
     """one stream: frames of n (120 | 240 | 480 | 960) samples per channel in, CELT-only FB packets of `nbytes` payload bytes out"""
 
-    def __init__(self, channels, nbytes, n=N):
+    def __init__(self, channels, nbytes, n=N, transient=False, joint=False, spread=0):
+        """transient: every frame as short blocks (n / 120 transforms of 120 bins, interleaved); joint: the two channels' bands
+        coded as mid / side with a stereo angle (else one by one: dual stereo); spread: the spreading rotation's strength 0 .. 3"""
         self.cc, self.nbytes, self.n, self.m = channels, nbytes, n, n // 120
+        self.transient, self.joint, self.spread = transient, joint and channels == 2, spread
         self.dec = orc.Decoder(channels)                   # the decoder that is run forced: its state IS the encoder's state
         self.toc = bytes([(28 + {120: 0, 240: 1, 480: 2, 960: 3}[n]) << 3 | (4 if channels == 2 else 0)])     # CELT-only FB, code 0
         self.win = np.ctypeslib.as_array(C.cast(L.orc_celt_window(), C.POINTER(C.c_float)), (120,)).astype(np.float64)
@@ -72,36 +109,60 @@ class Encoder:
         if kind == 3:
             return int(self.E[ch][band] > f)
         if kind == 4:                                      # split angle between the two halves of a vector, in qn steps
-            mid, side = np.linalg.norm(self.F[ch][a:a + b]), np.linalg.norm(self.F[ch][a + b:a + 2 * b])
+            mid, side = np.linalg.norm(self.T[ch][a:a + b]), np.linalg.norm(self.T[ch][a + b:a + 2 * b])
             return int(min(c, max(0, np.round(np.arctan2(side, mid) * 2 / np.pi * c))))
-        if kind == 5:
-            v = pvq_search(self.F[ch][a:a + b], c)
+        if kind == 5:                                      # f = blocks + 16 * spread
+            t = self.T[ch][a:a + b].copy()
+            exp_rotation_forward(t, int(f) & 15, c, int(f) >> 4)
+            v = pvq_search(t, c)
             for i in range(b):
                 y[i] = int(v[i])
             return 0
         if kind == 6:
-            return int(self.F[ch][a] < 0)
+            return int(self.T[ch][a] < 0)
+        if kind == 7:                                      # jointly coded band: mid = l + r, side = r - l of the unit-norm bands
+            l, r = self.T[0][a:a + b].copy(), self.T[1][a:a + b].copy()
+            l, r = l / max(1e-30, np.linalg.norm(l)), r / max(1e-30, np.linalg.norm(r))
+            self.T[0][a:a + b], self.T[1][a:a + b] = l + r, r - l
+            return int(min(c, max(0, np.round(np.arctan2(np.linalg.norm(r - l), np.linalg.norm(l + r)) * 2 / np.pi * c))))
         raise AssertionError(kind)
 
     def encode(self, frame):
         """frame: (n, channels) in [-1, 1) -> (packet, the PCM the forced run produced)"""
-        self.F, self.E = [], []
+        self.F, self.E, self.T = [], [], []                # spectrum, band energies, the spectrum in the order / form it is coded in
         for ch in range(self.cc):
             x = frame[:, ch].astype(np.float64) * 32768.0
             pre = x - PREEMPH * np.concatenate([[self.mem[ch]], x[:-1]])
             self.mem[ch] = x[-1]
-            F = mdct_forward(np.concatenate([self.hist[ch], pre]), self.win) * (2.0 / self.n)
+            blk = np.concatenate([self.hist[ch], pre])
             self.hist[ch] = pre
+            T = np.zeros(self.n)
+            if self.transient:
+                # short blocks: M transforms of 120 bins over the long window's support, bin i of block j at i M + j; a band is
+                # coded block by block (decoded[j N0 + i] = band[i M + j]: RFC 6716 bands.c deinterleave_hadamard, plain form)
+                M, s0 = self.m, (self.n - 120) // 2
+                F = np.zeros(self.n)
+                for j in range(M):
+                    F[j::M] = mdct_forward(blk[s0 + 120 * j:s0 + 120 * j + 240], self.win) * (2.0 / 120)
+                for i in range(21):
+                    lo, hi = M * EBANDS[i], M * EBANDS[i + 1]
+                    T[lo:hi] = F[lo:hi].reshape(-1, M).T.reshape(-1)
+            else:
+                F = mdct_forward(blk, self.win) * (2.0 / self.n)
+                T[:] = F
             self.F.append(F)
+            self.T.append(T)
             self.E.append([np.log2(max(1e-9, np.linalg.norm(F[self.m * EBANDS[i]:self.m * EBANDS[i + 1]]))) - EMEANS[i] for i in range(21)])
         buf = (C.c_uint32 * (3 * 16384))()
         L.orc_trace_set(buf, 16384)
+        L.orc_set_encoder_opts(int(self.transient), int(not self.joint), self.spread)
         L.orc_set_encoder(self.hook)
         try:
             pcm = self.dec.decode(self.toc + bytes(self.nbytes))
             n = L.orc_trace_count()
         finally:
             L.orc_set_encoder(HOOK(0))
+            L.orc_set_encoder_opts(0, 1, 0)
             L.orc_trace_set(None, 0)
         assert n < 16384
         syms = np.ctypeslib.as_array(buf).reshape(-1, 3)[:n]
@@ -137,9 +198,9 @@ def source(channels, nframes, seed=5, n=N):
     return np.stack(cols, axis=1)
 
 
-def encode_stream(channels, nframes, nbytes, n=N):
+def encode_stream(channels, nframes, nbytes, n=N, **tools):
     src = source(channels, nframes, n=n)
-    enc = Encoder(channels, nbytes, n)
+    enc = Encoder(channels, nbytes, n, **tools)
     packets, forced = [], []
     for b in range(nframes):
         p, pcm = enc.encode(src[b * n:(b + 1) * n])
@@ -204,6 +265,30 @@ def test_celt_loopback_short_frames(request, n, nbytes, floor_db):
     s = snr_db(want, got)
     assert s >= floor_db, f"decoded vs source: {s:.1f} dB"
     assert snr_db(want[1:], got[:-1]) < s - 3.0
+
+
+@pytest.mark.parametrize("tools,nbytes,floor_db", [(dict(spread=3), 120, 11.0), (dict(joint=True), 320, 16.0), (dict(transient=True), 320, 16.0),
+                                                    (dict(transient=True, joint=True, spread=2), 320, 15.0)])
+def test_celt_loopback_coding_tools(request, tools, nbytes, floor_db):
+    """the same loopback with the tools every real stream uses, each done on the encoder side from the RFC's text in f64:
+    the spreading rotation (forward before the pulse search; at 24 kb/s per channel leaving it out costs 10 dB), jointly coded
+    stereo (mid = l + r, side = r - l of the unit-norm bands and their angle: the decoder's stereo_merge must undo it), short
+    blocks (eight 120-bin transforms interleaved, bands coded block by block), and all three together"""
+    from test_emu_silk import EmuDecoder
+    emu = request.getfixturevalue("emu")
+    nframes = 20
+    src, packets, forced = encode_stream(2, nframes, nbytes, **tools)
+    d, ref = EmuDecoder(emu, 2), orc.Decoder(2)
+    outs = []
+    for i, p in enumerate(packets):
+        want = ref.decode(p)
+        assert np.array_equal(want, forced[i]), f"frame {i}"
+        check_pcm(want, d.decode(p), f"frame {i}")
+        outs.append(want)
+    got, want = np.concatenate(outs)[2 * N:], aligned(src, nframes)
+    s = snr_db(want, got)
+    assert s >= floor_db, f"decoded vs source: {s:.1f} dB"
+    assert snr_db(want[:, 0], got[:, 1]) < 3.0             # the channels carry different tones
 
 
 def test_celt_loopback_product(request):
