@@ -13,7 +13,8 @@
  *                              against a textbook f64 MDCT (tests/test_oracle_kats.py: test_imdct_fast_against_f64_direct,
  *                              test_imdct_and_window_reconstruct_a_textbook_mdct); and the encode -> decode loopback of
  *                              tests/test_loopback.py, where this decoder, run forced, ENCODES a known signal and every
- *                              decoder must return the signal (22 dB SNR at 64 kb/s per channel, 28 dB at 128).
+ *                              decoder must return the signal (22 dB SNR at 64 kb/s per channel, 28 dB at 128), at every
+ *                              frame size, with spreading, joint stereo, short blocks and the post-filter.
  */
 #include <math.h>
 #include <stdlib.h>
@@ -144,6 +145,9 @@ void orc_set_encoder(OrcEncHook h) { enc_hook = h; orc_force_on = h != 0; orc_fo
  * codes short blocks with every band's tf_change brought to 0 (first tf bit 1, the others 0: RFC 6716 table 60 then gives 0 at
  * every LM); dual = 0 codes the bands jointly (kind 7 asks for the stereo angle); spread = 0 .. 3 */
 void orc_set_encoder_opts(int transient, int dual_stereo, int spread) { enc_transient = transient; enc_dual = dual_stereo; enc_spread = spread; }
+/* ... and for the post-filter: period 15 .. 1022 (0 = off), gain index 0 .. 7 (gain = 0.09375 (index + 1)), tap set 0 .. 2 */
+static int enc_pf_period = 0, enc_pf_gain = 0, enc_pf_tapset = 0;
+void orc_set_encoder_postfilter(int period, int gain_index, int tapset) { enc_pf_period = period; enc_pf_gain = gain_index; enc_pf_tapset = tapset; }
 
 /* celt/decoder.rs:723-736.  Divergence: the reference ORs element e into bit (e mod B); RFC 6716
  * (vq.c extract_collapse_mask) uses contiguous blocks of N/B, which is what the de-interleaved
@@ -840,10 +844,16 @@ static int celt_frame(OrcCelt *st, OrcRd *rd, int N, int start, int end, int C, 
 
     int pf_pitch = 0, pf_tapset = 0, pf_on = 0, pf_qg = 0; float pf_gain = 0;
     if (start == 0 && tell + 16 <= total_bits) {              /* celt/decoder.rs:876-901 */
+        int f_oct = enc_pf_period > 0 ? orc_ilog((uint32_t)(enc_pf_period + 1)) - 5 : 0;      /* period + 1 = (16 << octave) + bits */
+        if (orc_force_on) orc_force(enc_pf_period > 0);
         if (orc_rd_logp(rd, 1)) {
+            if (orc_force_on) orc_force(f_oct);
             int octave = orc_rd_uniform(rd, 6);
+            if (orc_force_on) orc_force(enc_pf_period + 1 - (16 << f_oct));
             pf_pitch = (16 << octave) + orc_rd_rawbits(rd, 4 + octave) - 1;
+            if (orc_force_on) orc_force(enc_pf_gain);
             pf_qg = orc_rd_rawbits(rd, 3);
+            if (orc_force_on && orc_rd_tell(rd) + 2 <= total_bits) orc_force(enc_pf_tapset);
             if (orc_rd_tell(rd) + 2 <= total_bits) pf_tapset = orc_rd_icdf(rd, ICDF_CELT_TAPSET);
             pf_gain = 0.09375f * (pf_qg + 1);
             pf_on = 1;

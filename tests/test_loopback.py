@@ -88,11 +88,15 @@ def exp_rotation_forward(x, blocks, k, spread):
 class Encoder:
     """one stream: frames of n (120 | 240 | 480 | 960) samples per channel in, CELT-only FB packets of `nbytes` payload bytes out"""
 
-    def __init__(self, channels, nbytes, n=N, transient=False, joint=False, spread=0):
+    def __init__(self, channels, nbytes, n=N, transient=False, joint=False, spread=0, postfilter=None):
         """transient: every frame as short blocks (n / 120 transforms of 120 bins, interleaved); joint: the two channels' bands
         coded as mid / side with a stereo angle (else one by one: dual stereo); spread: the spreading rotation's strength 0 .. 3"""
         self.cc, self.nbytes, self.n, self.m = channels, nbytes, n, n // 120
         self.transient, self.joint, self.spread = transient, joint and channels == 2, spread
+        # postfilter = (period, gain index, tap set): the decoder then runs its comb filter y[n] = x[n] + g sum taps y[n - T +- k]
+        # (RFC 6716 4.3.7.1) on what it decodes, so the encoder codes x[n] = y[n] - g sum taps y[n - T +- k] of the signal it wants
+        self.pf = postfilter
+        self.pre_all = [np.zeros(1100) for _ in range(channels)]       # the pre-emphasised signal so far (behind 1100 zeros)
         self.dec = orc.Decoder(channels)                   # the decoder that is run forced: its state IS the encoder's state
         self.toc = bytes([(28 + {120: 0, 240: 1, 480: 2, 960: 3}[n]) << 3 | (4 if channels == 2 else 0)])     # CELT-only FB, code 0
         self.win = np.ctypeslib.as_array(C.cast(L.orc_celt_window(), C.POINTER(C.c_float)), (120,)).astype(np.float64)
@@ -134,6 +138,14 @@ class Encoder:
             x = frame[:, ch].astype(np.float64) * 32768.0
             pre = x - PREEMPH * np.concatenate([[self.mem[ch]], x[:-1]])
             self.mem[ch] = x[-1]
+            if self.pf:
+                T_, gq, ts = self.pf
+                g = 0.09375 * (gq + 1)
+                t0, t1, t2 = ((0.3066406250, 0.2170410156, 0.1296386719), (0.4638671875, 0.2680664062, 0.0), (0.7998046875, 0.1000976562, 0.0))[ts]
+                y = np.concatenate([self.pre_all[ch], pre])
+                self.pre_all[ch] = y
+                i = np.arange(len(y) - self.n, len(y))
+                pre = y[i] - g * (t0 * y[i - T_] + t1 * (y[i - T_ - 1] + y[i - T_ + 1]) + t2 * (y[i - T_ - 2] + y[i - T_ + 2]))
             blk = np.concatenate([self.hist[ch], pre])
             self.hist[ch] = pre
             T = np.zeros(self.n)
@@ -156,6 +168,7 @@ class Encoder:
         buf = (C.c_uint32 * (3 * 16384))()
         L.orc_trace_set(buf, 16384)
         L.orc_set_encoder_opts(int(self.transient), int(not self.joint), self.spread)
+        L.orc_set_encoder_postfilter(*(self.pf or (0, 0, 0)))
         L.orc_set_encoder(self.hook)
         try:
             pcm = self.dec.decode(self.toc + bytes(self.nbytes))
@@ -163,6 +176,7 @@ class Encoder:
         finally:
             L.orc_set_encoder(HOOK(0))
             L.orc_set_encoder_opts(0, 1, 0)
+            L.orc_set_encoder_postfilter(0, 0, 0)
             L.orc_trace_set(None, 0)
         assert n < 16384
         syms = np.ctypeslib.as_array(buf).reshape(-1, 3)[:n]
@@ -268,12 +282,17 @@ def test_celt_loopback_short_frames(request, n, nbytes, floor_db):
 
 
 @pytest.mark.parametrize("tools,nbytes,floor_db", [(dict(spread=3), 120, 11.0), (dict(joint=True), 320, 16.0), (dict(transient=True), 320, 16.0),
-                                                    (dict(transient=True, joint=True, spread=2), 320, 15.0)])
+                                                    (dict(transient=True, joint=True, spread=2), 320, 15.0),
+                                                    (dict(postfilter=(15, 5, 2)), 320, 19.0), (dict(postfilter=(37, 7, 1)), 320, 19.0),
+                                                    (dict(postfilter=(100, 3, 0)), 320, 19.0), (dict(postfilter=(733, 6, 0)), 320, 18.0),
+                                                    (dict(postfilter=(1022, 2, 1), joint=True, spread=2), 320, 15.0)])
 def test_celt_loopback_coding_tools(request, tools, nbytes, floor_db):
     """the same loopback with the tools every real stream uses, each done on the encoder side from the RFC's text in f64:
     the spreading rotation (forward before the pulse search; at 24 kb/s per channel leaving it out costs 10 dB), jointly coded
     stereo (mid = l + r, side = r - l of the unit-norm bands and their angle: the decoder's stereo_merge must undo it), short
-    blocks (eight 120-bin transforms interleaved, bands coded block by block), and all three together"""
+    blocks (eight 120-bin transforms interleaved, bands coded block by block), all three together; and the pitch post-filter:
+    the encoder codes x[n] = y[n] - g sum taps y[n - T +- k], so only a decoder whose comb filter has that period, those taps
+    in that order and that gain (periods 15 .. 1022: the register path, the LDS steps, the history reach) returns y"""
     from test_emu_silk import EmuDecoder
     emu = request.getfixturevalue("emu")
     nframes = 20

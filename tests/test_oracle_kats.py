@@ -230,3 +230,35 @@ def test_silk_unmix():  # silk/tests.rs:516-845, exact f32
     l, r = _silk_packet(k["packet"])
     assert np.array_equal(r, np.array(k["right"], np.float32))
     assert np.array_equal(l, np.array(k["left"], np.float32))
+
+
+@pytest.mark.parametrize("rate_khz", [8, 12, 16])
+def test_resampler_from_the_signal_side(rate_khz):
+    """The 8 / 12 / 16 -> 48 kHz resampler is the build's own stage (the reference has none; RFC 6716 leaves it open), so nothing
+    of the reference pins it.  From the signal side: a tone below the pass-band edge comes out as the same tone at 48 kHz, unit
+    gain, 36 output samples late (the 73-tap filter's group delay, the same at every rate) at >= 60 dB; DC has unit gain; a tone in
+    the transition band's far end is attenuated; block boundaries leave no trace (one call vs many)."""
+    Lr = 48 // rate_khz
+    fs = rate_khz * 1000.0
+    def run(x, hist, chunk):
+        out = []
+        for o in range(0, len(x), chunk):
+            seg = np.ascontiguousarray(x[o:o + chunk], np.float32)
+            y = np.zeros(len(seg) * Lr, np.float32)
+            L.orc_resample_to_48k(seg.ctypes.data_as(C.c_void_p), len(seg), rate_khz, hist.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p))
+            out.append(y)
+        return np.concatenate(out)
+    n = 3200
+    t_in, t_out = np.arange(n) / fs, (np.arange(n * Lr) - 36) / 48000.0
+    for f, floor, droop in ((200.0, 60.0, 0.999), (1000.0, 50.0, 0.99), (0.35 * fs, 40.0, 0.85)):
+        x = 0.5 * np.sin(2 * np.pi * f * t_in + 0.3)
+        y = run(x, np.zeros(32, np.float32), 160)
+        want = 0.5 * np.sin(2 * np.pi * f * t_out + 0.3)
+        g = float(want[400:] @ y[400:]) / float(want[400:] @ want[400:])          # the filter's gain at f: 73 taps at 48 kHz droop towards the edge
+        assert droop <= g <= 1.001, (f, g)
+        assert _snr(g * want[400:], y[400:]) >= floor, (f, _snr(g * want[400:], y[400:]))     # same tone, same phase: 36 samples late
+        assert np.array_equal(y, run(x, np.zeros(32, np.float32), 320))          # block size leaves no trace
+    dc = run(np.full(800, 0.25), np.zeros(32, np.float32), 160)
+    assert np.abs(dc[200:] - 0.25).max() < 2e-4
+    img = run(0.5 * np.sin(2 * np.pi * 0.499 * fs * t_in), np.zeros(32, np.float32), 160)      # at the band edge: mostly gone
+    assert np.sqrt(np.mean(img[400:] ** 2)) < 0.5 * 0.5 / np.sqrt(2)
