@@ -88,7 +88,7 @@ def exp_rotation_forward(x, blocks, k, spread):
 class Encoder:
     """one stream: frames of n (120 | 240 | 480 | 960) samples per channel in, CELT-only FB packets of `nbytes` payload bytes out"""
 
-    def __init__(self, channels, nbytes, n=N, transient=False, joint=False, spread=0, postfilter=None):
+    def __init__(self, channels, nbytes, n=N, transient=False, joint=False, spread=0, postfilter=None, hybrid=False):
         """transient: every frame as short blocks (n / 120 transforms of 120 bins, interleaved); joint: the two channels' bands
         coded as mid / side with a stereo angle (else one by one: dual stereo); spread: the spreading rotation's strength 0 .. 3"""
         self.cc, self.nbytes, self.n, self.m = channels, nbytes, n, n // 120
@@ -99,6 +99,9 @@ class Encoder:
         self.pre_all = [np.zeros(1100) for _ in range(channels)]       # the pre-emphasised signal so far (behind 1100 zeros)
         self.dec = orc.Decoder(channels)                   # the decoder that is run forced: its state IS the encoder's state
         self.toc = bytes([(28 + {120: 0, 240: 1, 480: 2, 960: 3}[n]) << 3 | (4 if channels == 2 else 0)])     # CELT-only FB, code 0
+        if hybrid:                                         # hybrid FB 20 ms: a SILK WB frame in front (every symbol 0: an inactive
+            assert n == 960                                # frame at the lowest gain, next to silence), CELT from band 17 (8 kHz) up
+            self.toc = bytes([15 << 3 | (4 if channels == 2 else 0)])
         self.win = np.ctypeslib.as_array(C.cast(L.orc_celt_window(), C.POINTER(C.c_float)), (120,)).astype(np.float64)
         self.mem = np.zeros(channels)
         self.hist = np.zeros((channels, n))                # the previous block of pre-emphasised samples
@@ -199,21 +202,23 @@ class Encoder:
         return self.toc + bytes(out), pcm
 
 
-def source(channels, nframes, seed=5, n=N):
-    """tones (different ones per channel), a slow sweep and a little noise; peak below 0.6"""
+def source(channels, nframes, seed=5, n=N, high=False):
+    """tones (different ones per channel), a slow sweep and a little noise; peak below 0.6.  high: everything between 9 and 19 kHz"""
     rng = np.random.default_rng(seed)
     t = np.arange((nframes + 1) * n) / 48000.0
     cols = []
     for ch in range(channels):
         f = [220.0, 1318.5, 4186.0] if ch == 0 else [329.6, 2093.0, 6271.9]
+        if high:
+            f = [9531.0, 12345.0, 15101.0] if ch == 0 else [10007.0, 13999.0, 17203.0]
         s = sum(0.15 / (1 + i) * np.sin(2 * np.pi * fi * t + i + ch) for i, fi in enumerate(f))
-        s = s + 0.08 * np.sin(2 * np.pi * (500.0 + 900.0 * t) * t) + 0.002 * rng.standard_normal(len(t))
+        s = s + 0.08 * np.sin(2 * np.pi * ((10000.0 if high else 500.0) + 900.0 * t) * t) + (0.0 if high else 0.002) * rng.standard_normal(len(t))
         cols.append(s * np.minimum(1.0, t / 0.02))
     return np.stack(cols, axis=1)
 
 
 def encode_stream(channels, nframes, nbytes, n=N, **tools):
-    src = source(channels, nframes, n=n)
+    src = source(channels, nframes, n=n, high=bool(tools.get("hybrid")))
     enc = Encoder(channels, nbytes, n, **tools)
     packets, forced = [], []
     for b in range(nframes):
@@ -308,6 +313,29 @@ def test_celt_loopback_coding_tools(request, tools, nbytes, floor_db):
     s = snr_db(want, got)
     assert s >= floor_db, f"decoded vs source: {s:.1f} dB"
     assert snr_db(want[:, 0], got[:, 1]) < 3.0             # the channels carry different tones
+
+
+@pytest.mark.parametrize("channels", [1, 2])
+def test_hybrid_loopback(request, channels):
+    """a hybrid FB packet: the SILK part coded as an inactive frame at the lowest gain (every symbol 0: next to silence), the CELT
+    part, from band 17 (8 kHz) up, coding a source that lives between 9 and 19 kHz.  Oracle and kernel bodies return the source
+    (the SILK part, the resampler and the accumulation onto the SILK output must not disturb it): the hybrid start band, the
+    bit budget behind the SILK part and the band layout, from the signal side."""
+    from test_emu_silk import EmuDecoder
+    emu = request.getfixturevalue("emu")
+    nframes = 20
+    src, packets, forced = encode_stream(channels, nframes, 200 * channels, hybrid=True)
+    d, ref = EmuDecoder(emu, channels), orc.Decoder(channels)
+    outs = []
+    for i, p in enumerate(packets):
+        want = ref.decode(p)
+        assert np.array_equal(want, forced[i]), f"frame {i}"
+        check_pcm(want, d.decode(p), f"frame {i}")
+        assert d.hp.fi[0].mode == 1 and d.hp.fi[0].nsilk == 1 and d.hp.fi[0].has_celt == 1
+        outs.append(want)
+    got = np.concatenate(outs)[2 * N:]
+    want = aligned(src, nframes).reshape(got.shape)
+    assert snr_db(want, got) >= 25.0, snr_db(want, got)
 
 
 def test_celt_loopback_product(request):
