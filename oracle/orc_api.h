@@ -63,6 +63,7 @@ typedef int64_t (*OrcEncHook)(int kind, int band, int ch, int a, int b, int c, d
 void orc_set_encoder(OrcEncHook hook);
 void orc_set_encoder_opts(int transient, int dual_stereo, int spread);
 void orc_set_encoder_postfilter(int period, int gain_index, int tapset);
+void orc_set_encoder_tf(int mode);
 int orc_extract_collapse_mask(const int *y, int n, int b);
 void orc_haar1(float *x, int n0, int stride);
 void orc_exp_rotation(float *x, int len, int stride, int k, int spread);

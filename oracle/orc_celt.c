@@ -147,6 +147,10 @@ void orc_set_encoder(OrcEncHook h) { enc_hook = h; orc_force_on = h != 0; orc_fo
 void orc_set_encoder_opts(int transient, int dual_stereo, int spread) { enc_transient = transient; enc_dual = dual_stereo; enc_spread = spread; }
 /* ... and for the post-filter: period 15 .. 1022 (0 = off), gain index 0 .. 7 (gain = 0.09375 (index + 1)), tap set 0 .. 2 */
 static int enc_pf_period = 0, enc_pf_gain = 0, enc_pf_tapset = 0;
+/* ... and, for long blocks, the time-frequency change of every band: 1 = every tf bit's band flagged, tf_select 0 (at 20 ms: -2,
+ * two Haar levels more time resolution); 2 = the same with tf_select 1 (-3) */
+static int enc_tf = 0;
+void orc_set_encoder_tf(int mode) { enc_tf = mode; }
 void orc_set_encoder_postfilter(int period, int gain_index, int tapset) { enc_pf_period = period; enc_pf_gain = gain_index; enc_pf_tapset = tapset; }
 
 /* celt/decoder.rs:723-736.  Divergence: the reference ORs element e into bit (e mod B); RFC 6716
@@ -898,12 +902,13 @@ static int celt_frame(OrcCelt *st, OrcRd *rd, int N, int start, int end, int C, 
         int rsv = lm > 0 && tell + logp + 1 <= budget;
         budget -= rsv;
         for (int i = start; i < end; i++) {
-            if (orc_force_on && enc_transient && tell + logp <= budget) orc_force(i == start);
+            if (orc_force_on && (enc_transient || enc_tf) && tell + logp <= budget) orc_force(i == start);
             if (tell + logp <= budget) { curr ^= orc_rd_logp(rd, logp); tell = orc_rd_tell(rd); changed |= curr; }
             tf_res[i] = curr;
             logp = transient ? 4 : 5;
         }
         int sel = 0;
+        if (orc_force_on && rsv && CELT_TF_SELECT[lm][transient][0][changed] != CELT_TF_SELECT[lm][transient][1][changed]) orc_force(enc_tf == 2);
         if (rsv && CELT_TF_SELECT[lm][transient][0][changed] != CELT_TF_SELECT[lm][transient][1][changed])
             sel = orc_rd_logp(rd, 1);
         for (int i = start; i < end; i++) tf_res[i] = CELT_TF_SELECT[lm][transient][sel][tf_res[i]];

@@ -306,7 +306,8 @@ def test_celt_loopback_on_gpu():
     import test_loopback as TL
     nframes = 24
     for tools, floor in (({}, 20.0), (dict(transient=True, joint=True, spread=2), 15.0),       # plain; short blocks + joint stereo + spreading;
-                         (dict(postfilter=(37, 7, 1)), 19.0), (dict(postfilter=(733, 6, 0)), 18.0)):    # the comb filter's register and LDS paths
+                         (dict(postfilter=(37, 7, 1)), 19.0), (dict(postfilter=(733, 6, 0)), 18.0),     # the comb filter's register and LDS paths
+                         (dict(tf=2, joint=True, spread=2), 15.0)):                                     # Haar / Hadamard band transforms
         src, packets, _ = TL.encode_stream(2, nframes, 320, **tools)
         d = Decoder(0)
         d.configure()

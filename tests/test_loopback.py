@@ -85,10 +85,37 @@ def exp_rotation_forward(x, blocks, k, spread):
             _rot1(v, stride2, s, -c)
 
 
+ORDERY = {2: [1, 0], 4: [3, 0, 2, 1], 8: [7, 0, 4, 3, 6, 1, 5, 2], 16: [15, 0, 8, 7, 12, 3, 11, 4, 14, 1, 9, 6, 13, 2, 10, 5]}      # RFC 6716 bands.c ordery_table
+
+
+def haar1(x, n0, stride):
+    """RFC 6716 bands.c haar1, in place: pairs (2j, 2j + 1) of each of `stride` interleaved sequences -> (sum, difference) / sqrt 2"""
+    v = x[:n0 * stride].reshape(n0 // 2, 2, stride)
+    a, b = v[:, 0, :].copy(), v[:, 1, :].copy()
+    v[:, 0, :], v[:, 1, :] = (a + b) * np.sqrt(0.5), (a - b) * np.sqrt(0.5)
+
+
+def band_to_coding_domain(x, tf_change):
+    """what an encoder does to a long-block band before it codes it when the band's time-frequency change is negative (RFC 6716
+    bands.c quant_band): a Haar level per step (more time resolution), then the Hadamard-ordered de-interleave of the resulting
+    `blocks` sequences; the decoder undoes both after decoding.  -> the vector as coded"""
+    x = x.copy()
+    n_b, blocks = len(x), 1
+    while n_b % 2 == 0 and tf_change < 0:
+        haar1(x, n_b, blocks)
+        blocks, n_b, tf_change = blocks * 2, n_b // 2, tf_change + 1
+    if blocks > 1:
+        out = np.empty_like(x)
+        for i in range(blocks):
+            out[ORDERY[blocks][i] * n_b:(ORDERY[blocks][i] + 1) * n_b] = x[i::blocks]
+        x = out
+    return x
+
+
 class Encoder:
     """one stream: frames of n (120 | 240 | 480 | 960) samples per channel in, CELT-only FB packets of `nbytes` payload bytes out"""
 
-    def __init__(self, channels, nbytes, n=N, transient=False, joint=False, spread=0, postfilter=None, hybrid=False):
+    def __init__(self, channels, nbytes, n=N, transient=False, joint=False, spread=0, postfilter=None, hybrid=False, tf=0):
         """transient: every frame as short blocks (n / 120 transforms of 120 bins, interleaved); joint: the two channels' bands
         coded as mid / side with a stereo angle (else one by one: dual stereo); spread: the spreading rotation's strength 0 .. 3"""
         self.cc, self.nbytes, self.n, self.m = channels, nbytes, n, n // 120
@@ -96,6 +123,9 @@ class Encoder:
         # postfilter = (period, gain index, tap set): the decoder then runs its comb filter y[n] = x[n] + g sum taps y[n - T +- k]
         # (RFC 6716 4.3.7.1) on what it decodes, so the encoder codes x[n] = y[n] - g sum taps y[n - T +- k] of the signal it wants
         self.pf = postfilter
+        # tf = 1 | 2: long blocks with every band's time-frequency change at -2 | -3 (20 ms frames: RFC 6716 table 60)
+        self.tf = tf
+        assert not (tf and (transient or n != 960))
         self.pre_all = [np.zeros(1100) for _ in range(channels)]       # the pre-emphasised signal so far (behind 1100 zeros)
         self.dec = orc.Decoder(channels)                   # the decoder that is run forced: its state IS the encoder's state
         self.toc = bytes([(28 + {120: 0, 240: 1, 480: 2, 960: 3}[n]) << 3 | (4 if channels == 2 else 0)])     # CELT-only FB, code 0
@@ -165,6 +195,10 @@ class Encoder:
             else:
                 F = mdct_forward(blk, self.win) * (2.0 / self.n)
                 T[:] = F
+                if self.tf:
+                    for i in range(21):
+                        lo, hi = self.m * EBANDS[i], self.m * EBANDS[i + 1]
+                        T[lo:hi] = band_to_coding_domain(F[lo:hi], -1 - self.tf)
             self.F.append(F)
             self.T.append(T)
             self.E.append([np.log2(max(1e-9, np.linalg.norm(F[self.m * EBANDS[i]:self.m * EBANDS[i + 1]]))) - EMEANS[i] for i in range(21)])
@@ -172,6 +206,7 @@ class Encoder:
         L.orc_trace_set(buf, 16384)
         L.orc_set_encoder_opts(int(self.transient), int(not self.joint), self.spread)
         L.orc_set_encoder_postfilter(*(self.pf or (0, 0, 0)))
+        L.orc_set_encoder_tf(self.tf)
         L.orc_set_encoder(self.hook)
         try:
             pcm = self.dec.decode(self.toc + bytes(self.nbytes))
@@ -180,6 +215,7 @@ class Encoder:
             L.orc_set_encoder(HOOK(0))
             L.orc_set_encoder_opts(0, 1, 0)
             L.orc_set_encoder_postfilter(0, 0, 0)
+            L.orc_set_encoder_tf(0)
             L.orc_trace_set(None, 0)
         assert n < 16384
         syms = np.ctypeslib.as_array(buf).reshape(-1, 3)[:n]
@@ -290,14 +326,16 @@ def test_celt_loopback_short_frames(request, n, nbytes, floor_db):
                                                     (dict(transient=True, joint=True, spread=2), 320, 15.0),
                                                     (dict(postfilter=(15, 5, 2)), 320, 19.0), (dict(postfilter=(37, 7, 1)), 320, 19.0),
                                                     (dict(postfilter=(100, 3, 0)), 320, 19.0), (dict(postfilter=(733, 6, 0)), 320, 18.0),
-                                                    (dict(postfilter=(1022, 2, 1), joint=True, spread=2), 320, 15.0)])
+                                                    (dict(postfilter=(1022, 2, 1), joint=True, spread=2), 320, 15.0),
+                                                    (dict(tf=1), 320, 18.0), (dict(tf=2), 320, 17.0), (dict(tf=1, joint=True, spread=2), 320, 16.0)])
 def test_celt_loopback_coding_tools(request, tools, nbytes, floor_db):
     """the same loopback with the tools every real stream uses, each done on the encoder side from the RFC's text in f64:
     the spreading rotation (forward before the pulse search; at 24 kb/s per channel leaving it out costs 10 dB), jointly coded
     stereo (mid = l + r, side = r - l of the unit-norm bands and their angle: the decoder's stereo_merge must undo it), short
     blocks (eight 120-bin transforms interleaved, bands coded block by block), all three together; and the pitch post-filter:
     the encoder codes x[n] = y[n] - g sum taps y[n - T +- k], so only a decoder whose comb filter has that period, those taps
-    in that order and that gain (periods 15 .. 1022: the register path, the LDS steps, the history reach) returns y"""
+    in that order and that gain (periods 15 .. 1022: the register path, the LDS steps, the history reach) returns y; and the
+    time-frequency change of long blocks (-2 / -3: Haar levels and the Hadamard-ordered de-interleave, which the decoder undoes)"""
     from test_emu_silk import EmuDecoder
     emu = request.getfixturevalue("emu")
     nframes = 20
