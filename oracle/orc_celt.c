@@ -133,6 +133,8 @@ uint32_t orc_icwrs(int n, const int *y)
  *       4 split angle (a = first bin of the vector in the frame, b = bins per half, c = qn) -> 0 .. qn
  *       5 pulses (a = first bin, b = bins, c = pulses, f = blocks + 16 * spread; y: out, |y|_1 = c)
  *       6 sign of a one-bin band (a = bin) -> 0 | 1       7 stereo angle of a jointly coded band (a = first bin, b = bins, c = qn) -> 0 .. qn
+ *       8 a jointly coded band of two bins (a = first bin, c = 1: the side is the vector that is coded, 0: the mid) -> the sign
+ *         bit that orients the other one
  * Everything else takes symbol 0 (no silence, no post-filter, no transient, inter energy, no tf change, no spreading rotation, no
  * boosts), except the allocation trim (5), the skip flags (1: code every band) and, for two channels, intensity = none and
  * dual stereo = 1 (each channel's bands coded like a mono band). */
@@ -521,6 +523,7 @@ static int quant_band_stereo(BandCtx *c, float *x, float *y, int n, int b, int B
         int sw = s.itheta > 8192;
         c->remaining_bits -= s.qalloc + sbits;
         float *x2 = sw ? y : x, *y2 = sw ? x : y;
+        if (sbits && orc_force_on) orc_force(enc_hook(8, c->band, 0, (int)(x - c->base[0]), 2, sw, 0., NULL));
         if (sbits) sign = orc_rd_rawbits(c->rd, 1);
         sign = 1 - 2 * sign;
         cm = quant_band(c, x2, n, mbits, B, lowband, lm, lowband_out, 1.f, scratch, orig_fill);

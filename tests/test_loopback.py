@@ -162,6 +162,9 @@ class Encoder:
             l, r = l / max(1e-30, np.linalg.norm(l)), r / max(1e-30, np.linalg.norm(r))
             self.T[0][a:a + b], self.T[1][a:a + b] = l + r, r - l
             return int(min(c, max(0, np.round(np.arctan2(np.linalg.norm(r - l), np.linalg.norm(l + r)) * 2 / np.pi * c))))
+        if kind == 8:                                      # two-bin joint band (RFC 6716 bands.c quant_band_stereo, N == 2): the coded
+            x2, y2 = (self.T[1][a:a + 2], self.T[0][a:a + 2]) if c else (self.T[0][a:a + 2], self.T[1][a:a + 2])      # vector and the other one,
+            return int(x2[0] * y2[1] - x2[1] * y2[0] < 0)  # which the decoder rebuilds as +-(-x2[1], x2[0])
         raise AssertionError(kind)
 
     def encode(self, frame):
@@ -301,14 +304,16 @@ def test_celt_loopback_oracle(channels, nbytes, floor_db):
         assert snr_db(ref[:, 0], got[:, 1]) < 3.0
 
 
-@pytest.mark.parametrize("n,nbytes,floor_db", [(480, 160, 18.0), (240, 80, 14.0), (120, 48, 10.0)])
-def test_celt_loopback_short_frames(request, n, nbytes, floor_db):
+@pytest.mark.parametrize("n,nbytes,floor_db,joint", [(480, 160, 18.0, False), (240, 80, 14.0, False), (120, 48, 10.0, False),
+                                                     (480, 160, 15.0, True), (240, 80, 15.0, True), (120, 48, 15.0, True)])
+def test_celt_loopback_short_frames(request, n, nbytes, floor_db, joint):
     """10 / 5 / 2.5 ms frames (the 240 / 120 / 60-point transforms, one-bin bands with their sign bits at 2.5 ms): oracle and
-    kernel bodies return the source at the rate's SNR, aligned to the sample"""
+    kernel bodies return the source at the rate's SNR, aligned to the sample.  joint: the bands coded as mid / side -- at 5 and
+    2.5 ms that includes the two-bin bands, whose side is rebuilt from the mid by a rotation and a sign bit"""
     from test_emu_silk import EmuDecoder
     emu = request.getfixturevalue("emu")
     nframes = 4800 // n * 4
-    src, packets, forced = encode_stream(2, nframes, nbytes, n)
+    src, packets, forced = encode_stream(2, nframes, nbytes, n, joint=joint)
     d, ref = EmuDecoder(emu, 2), orc.Decoder(2)
     outs = []
     for i, p in enumerate(packets):
