@@ -483,6 +483,12 @@ int silk_parse(SilkHostState &st, RangeDec &rd, int bw, int duration_ms, int ste
             if (st.side.coded) st.side.flush();
             f.ch[1].flags = OG_S_RESET;                 // unmix_ms of this very frame reads the cleared side history
             st.side.flushed = false;
+        } else if (st.side.flushed) {
+            // (only an in-band FEC recovery gets here: a mid copy without a side copy and without the mid-only flag.)  The side
+            // was flushed on the host -- a CELT packet in between, say -- but no side frame has reached the device since: its
+            // history there is still the old one, and unmix_ms of this frame reads it
+            f.ch[1].flags = OG_S_RESET;
+            st.side.flushed = false;
         }
     };
     if (fec) {
@@ -580,6 +586,7 @@ int silk_conceal(SilkHostState &st, int bw, int duration_ms, int stereo, int los
         else {
             f.ch[1].order = f.ch[0].order; f.ch[1].subframes = uint8_t(subframes); f.ch[1].sf_size = uint8_t(sf_size);
             if (stereo) f.flags |= OG_SF_MID_ONLY;
+            if (stereo && st.side.flushed) { f.ch[1].flags = OG_S_RESET; st.side.flushed = false; }      // (as in side_absent)
         }
         if (stereo && st.stereo_out) { st.prev_w0 = st.w0; st.prev_w1 = st.w1; }
     }

@@ -610,6 +610,7 @@ static int silk_decode(OrcSilk *s, OrcRd *rd, int bw, int duration_ms, int stere
         for (int i = 0; i < frames; i++) lbrr[ch][i] = (sym >> i) & 1;
     }
     if (fec) {
+        memset(s->lbrr, 0, sizeof s->lbrr);
         for (int i = 0; i < frames; i++) {
             float *l = left + i * f_size, *r = right + i * f_size;
             if (lbrr[0][i]) {
@@ -625,10 +626,9 @@ static int silk_decode(OrcSilk *s, OrcRd *rd, int bw, int duration_ms, int stere
                     memcpy(r, in, f_size * sizeof(float));
                 }
             } else {
-                if (stereo && lbrr[1][i]) {              /* a side-only copy is read past */
-                    memset(&s->lbrr[1], 0, sizeof s->lbrr[1]);
+                if (stereo && lbrr[1][i])                /* a side-only copy is read past (into a scratch channel that lives as long as
+                                                            the packet: the next side copy may be coded relative to this one) */
                     frame_parse(&s->lbrr[1], rd, bw, subframes, sf_size, 1, i == 0 || !lbrr[1][i - 1]);
-                }
                 memset(l, 0, f_size * sizeof(float));
                 memset(r, 0, f_size * sizeof(float));
                 frame_flush(&s->mid); frame_flush(&s->side);

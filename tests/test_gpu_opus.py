@@ -337,9 +337,14 @@ def test_random_packets_every_toc_on_gpu(channels):
         d.set_extradata(b"OpusHead" + bytes([1, 1, 0, 0]) + (48000).to_bytes(4, "little") + bytes([0, 0, 0]))
     d.configure()
     ref = orc.Decoder(channels)
-    for i in range(500):
+    for i in range(600):
         config, stereo, code = int(rng.integers(0, 32)), int(rng.integers(0, 2)), int(rng.integers(0, 4))
         p = random_packet(rng, config, stereo, code)
+        if rng.integers(0, 25) == 0:
+            p = b""                                     # lost
+        elif rng.integers(0, 12) == 0:                  # the previous one "was lost": FEC recovery from this one first
+            d.send_packet_fec(p)
+            check_pcm(ref.decode_fec(p), d.receive_frame(), f"packet {i} (config {config}, code {code}), FEC")
         d.send_packet(p)
         out, r = d.receive_frame(), ref.decode(p)
         assert out.shape == r.shape, f"packet {i} (config {config}, code {code})"
