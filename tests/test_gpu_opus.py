@@ -349,3 +349,34 @@ def test_random_packets_every_toc_on_gpu(channels):
         out, r = d.receive_frame(), ref.decode(p)
         assert out.shape == r.shape, f"packet {i} (config {config}, code {code})"
         check_pcm(r, out, f"packet {i} (config {config}, stereo {stereo}, code {code})")
+
+
+def test_batch_engine_random_packets_losses_fec_and_multi_sends():
+    """the batch engine under the same fuzz: 96 streams, each step a random subset of them gets a random packet of any TOC (or a
+    loss, or an FEC recovery send first), some steps as a two-packets-per-stream send -- runs of uneven length, SILK depths 0-3,
+    every launch round -- every stream's PCM against its own oracle decoder after every step"""
+    from test_emu_silk import random_packet
+    rng = np.random.default_rng(77)
+    ns = 96
+    dec = BatchDecoder(ns, 2, 0)
+    refs = [orc.Decoder(2) for _ in range(ns)]
+    for step in range(50):
+        ids = [s for s in range(ns) if rng.integers(0, 5) != 0]
+        T = 2 if step % 7 == 3 else 1
+        pk = [[b"" if rng.integers(0, 25) == 0 else random_packet(rng, int(rng.integers(0, 32)), int(rng.integers(0, 2)), int(rng.integers(0, 4)))
+               for _ in range(T)] for _ in ids]
+        if T == 1 and step % 5 == 2:                     # every packet of this step follows a lost one: recover first
+            fec_ids = [s for s, p in zip(ids, pk) if p[0]]
+            fec_pk = [p[0] for p in pk if p[0]]
+            assert not any(dec.send(fec_pk, fec_ids, fec=True))
+            dec.decode()
+            for s, p in zip(fec_ids, fec_pk):
+                check_pcm(refs[s].decode_fec(p), dec.read(s), f"step {step} stream {s} FEC")
+        if T == 1:
+            assert not any(dec.send([p[0] for p in pk], ids))
+        else:
+            assert not any(any(e) for e in dec.send_multi(pk, ids))
+        dec.decode()
+        for s, p in zip(ids, pk):
+            want = np.concatenate([refs[s].decode(q) for q in p])
+            check_pcm(want, dec.read(s)[: len(want)], f"step {step} stream {s}")
