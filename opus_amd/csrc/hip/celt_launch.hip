@@ -258,6 +258,25 @@ __global__ __launch_bounds__(OG_PLAN_WG) __attribute__((amdgpu_waves_per_eu(4, 8
     }
     if (stop == 2) return;
     __syncthreads();
+    // the tasks' order by level (og_plan_sort), a lane per task: per level in use one vote of the wavefront gives the level's
+    // tasks (in band order: the lane order) and their count; each wavefront sorts half of the workgroup's frames
+    for (uint32_t k = 0; k < OG_PLAN_FPW / 2; k++) {
+        const uint32_t fr = (tid >> 6) * (OG_PLAN_FPW / 2) + k, lane = tid & 63u;
+        if (fr >= nf) break;                            // (uniform over the wavefront)
+        OgPlanShared &Sf = S[fr];
+        const uint32_t lvl = lane < 42u ? Sf.tl[lane] : 0xFFu;
+        const int maxlvl = __builtin_amdgcn_readfirstlane((int)Sf.maxlvl);
+        uint32_t n = 0, pos = 0, ts = 0;
+        for (int l = 0; l <= maxlvl; l++) {
+            const uint64_t m = __ballot(lvl == (uint32_t)l);
+            if (lane == (uint32_t)l) ts = n;
+            if (lvl == (uint32_t)l) pos = n + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            n += (uint32_t)__popcll(m);
+        }
+        if (lvl != 0xFFu) Sf.order[pos] = (uint8_t)lane;
+        if (lane <= (uint32_t)maxlvl + 2u) Sf.task_start[lane] = (uint8_t)(lane <= (uint32_t)maxlvl ? ts : n);
+    }
+    __syncthreads();
 #pragma unroll
     for (int r = 0; r < OG_PLAN_ITEMS; r++) {
         const uint32_t p = tid + r * OG_PLAN_WG;

@@ -87,7 +87,7 @@ OG_DEV void og_make_xform(int n, int B, int tf_change, OgXform *t, int *recombin
 //      `plain`, the one-bin bands' signs, the collapse masks of the calls without live fill leaves; K1's masks are consumed
 //      (and re-zeroed) here;
 //   B  per frame (serial over the bands that have fill leaves or the dual -> intensity switch): levels, which fill leaves
-//      are live and their seeds, the collapse masks that depend on lower bands, the tasks' order by level;
+//      are live and their seeds, the collapse masks that depend on lower bands; then the tasks' order by level (og_plan_sort);
 //   C  per band again: step B's amendments applied to the two task records, records out; the low work items also write
 //      the order and the header fields.
 // OgPlanShared holds what passes between the steps (LDS in the kernel, one per frame of the workgroup: 628 bytes, so that
@@ -312,24 +312,22 @@ OG_DEV void og_plan_chain(const OgHdrHead &h, const OgCeltBand *bands, const OgC
     S.seed_out = seed;
     S.nops = (uint16_t)nops; S.merge_cnt = (uint16_t)merge_cnt;
     S.maxlvl = (uint8_t)maxlvl; S.merge_level = (uint8_t)merge_level;
-    // the active tasks ordered by level (band order inside a level), by the frame's lane: one pass over the 42 levels per
-    // level in use, the levels held in registers (fetched as dwords) and the write position in a register, so that no step
-    // waits for LDS (a counting sort does, twice per task: its counters are indexed by the level)
-    // (levels above maxlvl hold nothing: the frame kernel reads task_start[0 .. nlevels + 1])
-    {
-        static_assert(offsetof(OgPlanShared, tl) % 2 == 0, "tl is fetched in 16-bit pieces");
-        uint32_t lw[21];
-#pragma unroll
-        for (int k = 0; k < 21; k++) lw[k] = ((const uint16_t *)&S.tl[0])[k];
-        int n = 0;
-        for (int l = 0; l <= maxlvl; l++) {
-            S.task_start[l] = (uint8_t)n;
-#pragma unroll
-            for (int t = 0; t < 42; t++)
-                if ((int)((lw[t >> 1] >> (8 * (t & 1))) & 255u) == l) S.order[n++] = (uint8_t)t;
-        }
-        S.task_start[maxlvl + 1] = S.task_start[maxlvl + 2] = (uint8_t)n;
+}
+
+// The active tasks ordered by level (band order inside a level): S.order, S.task_start from S.tl and S.maxlvl.  This is one
+// lane's form (CPU builds): a pass over the 42 levels per level in use.  The kernel does it with a lane per task and a
+// wavefront vote per level (celt_launch.hip, og_plan_kernel) -- in the frame's chain it was 9 of the chain's 40 us.
+// (levels above maxlvl hold nothing: the frame kernel reads task_start[0 .. nlevels + 1])
+OG_DEV void og_plan_sort(OgPlanShared &S)
+{
+    const int maxlvl = S.maxlvl;
+    int n = 0;
+    for (int l = 0; l <= maxlvl; l++) {
+        S.task_start[l] = (uint8_t)n;
+        for (int t = 0; t < 42; t++)
+            if (S.tl[t] == l) S.order[n++] = (uint8_t)t;
     }
+    S.task_start[maxlvl + 1] = S.task_start[maxlvl + 2] = (uint8_t)n;
 }
 
 // the work item of band i again: step B's amendments applied to its two task records, records out; the low work items also
@@ -378,6 +376,7 @@ OG_DEV void og_band_plan(const OgCeltHdr *hdr, const OgCeltLeaf *lv, const OgCel
     for (size_t k = 0; k < sizeof(OgPlanShared) / 4; k++) ((uint32_t *)&S)[k] = 0;      // (the kernel clears it with all its lanes)
     for (int i = 0; i < 21; i++) og_plan_band_a(h, hdr->band, lv, K, cm_row, coef_row, i, S, tk[i]);
     og_plan_chain(h, hdr->band, lv, K, la, lc, P, S);
+    og_plan_sort(S);
     for (int i = 0; i < 21; i++) og_plan_emit(h, hdr->band, i, tk[i], P, S);
 }
 
