@@ -260,21 +260,33 @@ __global__ __launch_bounds__(OG_PLAN_WG) __attribute__((amdgpu_waves_per_eu(4, 8
     __syncthreads();
     // the tasks' order by level (og_plan_sort), a lane per task: per level in use one vote of the wavefront gives the level's
     // tasks (in band order: the lane order) and their count; each wavefront sorts half of the workgroup's frames
-    for (uint32_t k = 0; k < OG_PLAN_FPW / 2; k++) {
-        const uint32_t fr = (tid >> 6) * (OG_PLAN_FPW / 2) + k, lane = tid & 63u;
-        if (fr >= nf) break;                            // (uniform over the wavefront)
-        OgPlanShared &Sf = S[fr];
-        const uint32_t lvl = lane < 42u ? Sf.tl[lane] : 0xFFu;
-        const int maxlvl = __builtin_amdgcn_readfirstlane((int)Sf.maxlvl);
-        uint32_t n = 0, pos = 0, ts = 0;
-        for (int l = 0; l <= maxlvl; l++) {
-            const uint64_t m = __ballot(lvl == (uint32_t)l);
-            if (lane == (uint32_t)l) ts = n;
-            if (lvl == (uint32_t)l) pos = n + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            n += (uint32_t)__popcll(m);
+    {
+        constexpr uint32_t H = OG_PLAN_FPW / 2;
+        const uint32_t fr0 = (tid >> 6) * H, lane = tid & 63u;
+        uint32_t lv_[H], mx_[H];
+#pragma unroll
+        for (uint32_t k = 0; k < H; k++) {              // every fetch first (frames past the launch's end: nothing to sort)
+            const bool in = fr0 + k < nf;
+            const OgPlanShared &Sf = S[in ? fr0 + k : 0u];
+            lv_[k] = in && lane < 42u ? Sf.tl[lane] : 0xFFu;
+            mx_[k] = in ? Sf.maxlvl : 0u;
         }
-        if (lvl != 0xFFu) Sf.order[pos] = (uint8_t)lane;
-        if (lane <= (uint32_t)maxlvl + 2u) Sf.task_start[lane] = (uint8_t)(lane <= (uint32_t)maxlvl ? ts : n);
+#pragma unroll
+        for (uint32_t k = 0; k < H; k++) {
+            if (fr0 + k >= nf) break;                   // (uniform over the wavefront)
+            OgPlanShared &Sf = S[fr0 + k];
+            const uint32_t lvl = lv_[k];
+            const int maxlvl = __builtin_amdgcn_readfirstlane((int)mx_[k]);
+            uint32_t n = 0, pos = 0, ts = 0;
+            for (int l = 0; l <= maxlvl; l++) {
+                const uint64_t m = __ballot(lvl == (uint32_t)l);
+                if (lane == (uint32_t)l) ts = n;
+                if (lvl == (uint32_t)l) pos = n + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                n += (uint32_t)__popcll(m);
+            }
+            if (lvl != 0xFFu) Sf.order[pos] = (uint8_t)lane;
+            if (lane <= (uint32_t)maxlvl + 2u) Sf.task_start[lane] = (uint8_t)(lane <= (uint32_t)maxlvl ? ts : n);
+        }
     }
     __syncthreads();
 #pragma unroll
