@@ -65,6 +65,7 @@ struct SilkHostState {
     bool stereo_reset = true;
     bool resampler_reset = true;        // device resampler history must be cleared (build's own stage)
     void flush();
+    void reset();                       // both channels, coded or not (Decoder::flush; a side channel may hold a flush that never reached the device)
 };
 // Concealment of a lost Opus frame of duration_ms (10 | 20 | 40 | 60) at the bandwidth and channel coding of the last decoded one
 // (no counterpart in the reference; after libopus' silk/PLC.c, simplified): appends one OgSilkFrame per 20 ms whose parameters

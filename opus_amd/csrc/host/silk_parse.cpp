@@ -22,6 +22,16 @@ void SilkHostState::flush()                                                  // 
     prev_w0 = prev_w1 = 0.f;
 }
 
+// The whole state, whether a channel has been coded or not: the side channel's `flushed` can have been spent on a reset record
+// that never reached the device (its packet was refused further on), and a later flush() would then skip the channel.
+void SilkHostState::reset()
+{
+    mid.flush();
+    side.flush();
+    stereo_reset = true;
+    w0 = w1 = prev_w0 = prev_w1 = 0.f;
+}
+
 namespace {
 
 inline int32_t mul_shift(int32_t a, int32_t b, int bits) { return int32_t((int64_t(a) * b) >> bits); }                // :104-110

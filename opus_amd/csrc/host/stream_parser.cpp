@@ -19,7 +19,7 @@ StreamParser::StreamParser(int channels) : channels_(channels)
 void StreamParser::reset()
 {
     celt_.reset();
-    silk_.flush();
+    silk_.reset();
     silk_.resampler_reset = true;
     prev_mode_ = -1;
     last_packet_samples_ = last_frame_samples_ = 960;
@@ -27,6 +27,16 @@ void StreamParser::reset()
     last_stereo_ = 0;
     lost_silk_ = lost_celt_ = 0;
     prev_redundancy_ = false;
+}
+
+// A packet refused after its parsing has begun (the reference returns its error from the middle of the frame as well, e.g.
+// decoder.rs:104, with its state as far as it got; what follows such a packet is not defined there): the records of the packet
+// are dropped by the caller, so the device has seen none of it, and the host state must not run ahead of the device's -- the
+// stream starts again, as after flush(): the next frames carry the reset flags.
+int StreamParser::refuse(int rc)
+{
+    reset();
+    return rc;
 }
 
 int StreamParser::parse(const uint8_t *pkt, size_t len, OgFrameInfo *frames, std::vector<OgCeltHdr> &celt,
@@ -115,7 +125,7 @@ int StreamParser::parse(const uint8_t *pkt, size_t len, OgFrameInfo *frames, std
 
         if (p.mode != MODE_CELT) {                                          // decoder.rs:75-77
             int n = silk_parse(silk_, rd, std::min(p.bandwidth, int(BW_WB)), N / 48, p.stereo, silk);
-            if (n < 0) return n;
+            if (n < 0) return refuse(n);
             fi.nsilk = uint8_t(n);
         } else {
             silk_.flush();                                                  // decoder.rs:79
@@ -131,7 +141,7 @@ int StreamParser::parse(const uint8_t *pkt, size_t len, OgFrameInfo *frames, std
         if (redundancy) {
             celt_to_silk = rd.bit_logp(1);                                  // position: 1 = the redundant frame belongs in front
             rbytes = p.mode == MODE_HYBRID ? int(rd.uint(256)) + 2 : flen - ((rd.tell() + 7) >> 3);
-            if (rbytes >= flen) return OPUSGPU_INVALID_DATA;                // decoder.rs:104
+            if (rbytes >= flen) return refuse(OPUSGPU_INVALID_DATA);        // decoder.rs:104
             int keep = flen - rbytes;
             if (keep * 8 < rd.tell()) { keep = 0; redundancy = false; rbytes = 0; }
             else rdata = pkt + p.off[f] + keep;
@@ -143,7 +153,7 @@ int StreamParser::parse(const uint8_t *pkt, size_t len, OgFrameInfo *frames, std
         if (redundancy && celt_to_silk) {
             RangeDec r2(rdata, uint32_t(rbytes));
             celt.emplace_back();
-            if (celt_parse_frame(celt_, r2, 240, 0, p.celt_end_band(), p.stereo + 1, &celt.back(), leaves) < 0) return OPUSGPU_INVALID_DATA;
+            if (celt_parse_frame(celt_, r2, 240, 0, p.celt_end_band(), p.stereo + 1, &celt.back(), leaves) < 0) return refuse(OPUSGPU_INVALID_DATA);
             tag(celt.back(), OG_X_RED_HEAD, OG_ROUND_HEAD);
             red_range = r2.rng();
             fi.has_celt++;
@@ -154,7 +164,7 @@ int StreamParser::parse(const uint8_t *pkt, size_t len, OgFrameInfo *frames, std
         if (p.mode != MODE_SILK && N <= 960) {                              // decoder.rs:117-123
             const int start = p.mode == MODE_HYBRID ? 17 : 0;
             celt.emplace_back();
-            if (celt_parse_frame(celt_, rd, N, start, p.celt_end_band(), p.stereo + 1, &celt.back(), leaves) < 0) return OPUSGPU_INVALID_DATA;
+            if (celt_parse_frame(celt_, rd, N, start, p.celt_end_band(), p.stereo + 1, &celt.back(), leaves) < 0) return refuse(OPUSGPU_INVALID_DATA);
             if (p.mode == MODE_HYBRID) celt.back().flags |= OG_F_ACCUM;
             tag(celt.back(), redundancy && celt_to_silk ? OG_X_AFTER_RED_HEAD : OG_X_NONE, OG_ROUND_MAIN);
             fi.has_celt++;
@@ -177,7 +187,7 @@ int StreamParser::parse(const uint8_t *pkt, size_t len, OgFrameInfo *frames, std
             RangeDec r2(rdata, uint32_t(rbytes));
             celt_.reset();
             celt.emplace_back();
-            if (celt_parse_frame(celt_, r2, 240, 0, p.celt_end_band(), p.stereo + 1, &celt.back(), leaves) < 0) return OPUSGPU_INVALID_DATA;
+            if (celt_parse_frame(celt_, r2, 240, 0, p.celt_end_band(), p.stereo + 1, &celt.back(), leaves) < 0) return refuse(OPUSGPU_INVALID_DATA);
             celt.back().pcm_off = uint32_t(N - 240);
             tag(celt.back(), OG_X_RED_TAIL, OG_ROUND_TAIL);
             red_range = r2.rng();
@@ -239,7 +249,7 @@ int StreamParser::parse_fec(const uint8_t *pkt, size_t len, OgFrameInfo *frames,
         fi.silk_index = uint32_t(silk.size());
         RangeDec rd(pkt + p.off[f], uint32_t(p.len[f]));
         const int n = silk_parse(silk_, rd, std::min(p.bandwidth, int(BW_WB)), N / 48, p.stereo, silk, true);
-        if (n < 0) return n;
+        if (n < 0) return refuse(n);
         fi.nsilk = uint8_t(n);
         if (p.mode == MODE_HYBRID || prev_mode_ != MODE_SILK) {
             // the CELT part of a hybrid frame is not in the LBRR copy, and after CELT / hybrid audio the MDCT overlap has to fade

@@ -24,6 +24,7 @@ public:
                   std::vector<OgCeltLeaf> &leaves, std::vector<OgSilkFrame> &silk);
 
 private:
+    int refuse(int rc);                             // a packet refused midway: the stream starts again (stream_parser.cpp)
     int channels_;
     int prev_mode_ = -1;
     int last_packet_samples_ = 960;                 // samples per channel of the last packet (what a lost packet is taken to span)

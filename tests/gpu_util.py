@@ -20,7 +20,9 @@ def check_pcm(ref, out, what=""):
     scale = max(1.0, float(np.abs(ref).max()))
     e = float(np.abs(out - ref).max()) / scale
     assert e <= 1e-4, f"{what}: max abs error {e:.3e} (scaled) > 1e-4"
-    if float((ref.astype(np.float64) ** 2).sum()) > 1e-12:
+    # (the SNR is asked of audio above -120 dB full scale: below that -- the last ripples of an overlap fading out, 6e-7 at the
+    # peak in the case the long GPU fuzz found -- it measures float32 rounding against nothing; the absolute bound still holds)
+    if ref.size and float((ref.astype(np.float64) ** 2).mean()) > 1e-12:
         s = snr_db(ref, out)
         assert s >= 90.0, f"{what}: SNR {s:.1f} dB < 90"
     return e

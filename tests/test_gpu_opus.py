@@ -326,41 +326,73 @@ def test_celt_loopback_on_gpu():
 
 
 
+def fuzz_one_stream(channels, seed, npackets):
+    """random packets under every TOC (losses and FEC recoveries strewn in) through the one-stream C ABI against the oracle
+    (also run for many seeds by tools/fuzz_gpu.py).  A random packet is now and then one that the decoder must refuse (a hybrid
+    frame whose redundancy length leaves no room for the frame itself: decoder.rs:100-104): then both refuse it, and both start
+    again from a fresh state, since what a refused packet leaves behind is not defined."""
+    from test_emu_silk import random_packet
+    from opus_amd.decoder import OpusError
+    rng = np.random.default_rng(seed)
+
+    def fresh():
+        d = Decoder(0)
+        if channels == 1:
+            d.set_extradata(b"OpusHead" + bytes([1, 1, 0, 0]) + (48000).to_bytes(4, "little") + bytes([0, 0, 0]))
+        d.configure()
+        return d, orc.Decoder(channels)
+    d, ref = fresh()
+    refused = 0
+    for i in range(npackets):
+        config, stereo, code = int(rng.integers(0, 32)), int(rng.integers(0, 2)), int(rng.integers(0, 4))
+        what = f"seed {seed} packet {i} (config {config}, stereo {stereo}, code {code})"
+        p = random_packet(rng, config, stereo, code)
+        try:
+            if rng.integers(0, 25) == 0:
+                p = b""                                 # lost
+            elif rng.integers(0, 12) == 0:              # the previous one "was lost": FEC recovery from this one first
+                d.send_packet_fec(p)
+                check_pcm(ref.decode_fec(p), d.receive_frame(), what + ", FEC")
+            d.send_packet(p)
+        except OpusError:
+            with pytest.raises(ValueError):             # the oracle refuses it as well (FEC recovery included)
+                ref.decode_fec(p)
+                ref.decode(p)
+            refused += 1
+            d.close()
+            d, ref = fresh()
+            continue
+        out, r = d.receive_frame(), ref.decode(p)
+        assert out.shape == r.shape, what
+        check_pcm(r, out, what)
+    d.close()
+    assert refused <= npackets // 100, refused
+
+
 @pytest.mark.parametrize("channels", [1, 2])
 def test_random_packets_every_toc_on_gpu(channels):
     """tests/test_emu_silk.py::test_random_packets_every_toc through the one-stream C ABI and the HIP kernels: every TOC
     configuration, mono / stereo packets, all frame-count codes, random contents, one decoder (every mode switch), against the oracle"""
-    from test_emu_silk import random_packet
-    rng = np.random.default_rng(200 + channels)
-    d = Decoder(0)
-    if channels == 1:
-        d.set_extradata(b"OpusHead" + bytes([1, 1, 0, 0]) + (48000).to_bytes(4, "little") + bytes([0, 0, 0]))
-    d.configure()
-    ref = orc.Decoder(channels)
-    for i in range(600):
-        config, stereo, code = int(rng.integers(0, 32)), int(rng.integers(0, 2)), int(rng.integers(0, 4))
-        p = random_packet(rng, config, stereo, code)
-        if rng.integers(0, 25) == 0:
-            p = b""                                     # lost
-        elif rng.integers(0, 12) == 0:                  # the previous one "was lost": FEC recovery from this one first
-            d.send_packet_fec(p)
-            check_pcm(ref.decode_fec(p), d.receive_frame(), f"packet {i} (config {config}, code {code}), FEC")
-        d.send_packet(p)
-        out, r = d.receive_frame(), ref.decode(p)
-        assert out.shape == r.shape, f"packet {i} (config {config}, code {code})"
-        check_pcm(r, out, f"packet {i} (config {config}, stereo {stereo}, code {code})")
+    fuzz_one_stream(channels, 200 + channels, 600)
 
 
-def test_batch_engine_random_packets_losses_fec_and_multi_sends():
-    """the batch engine under the same fuzz: 96 streams, each step a random subset of them gets a random packet of any TOC (or a
-    loss, or an FEC recovery send first), some steps as a two-packets-per-stream send -- runs of uneven length, SILK depths 0-3,
-    every launch round -- every stream's PCM against its own oracle decoder after every step"""
+def fuzz_batch_engine(seed, nsteps, ns=96):
+    """the batch engine under the same fuzz (also run for many seeds by tools/fuzz_gpu.py)"""
     from test_emu_silk import random_packet
-    rng = np.random.default_rng(77)
-    ns = 96
+    rng = np.random.default_rng(seed)
     dec = BatchDecoder(ns, 2, 0)
     refs = [orc.Decoder(2) for _ in range(ns)]
-    for step in range(50):
+    refused = [0]
+
+    def refuse(s, packets, fec=False):
+        """the engine refused a packet of stream s (see fuzz_one_stream): so does the oracle; both start the stream afresh"""
+        with pytest.raises(ValueError):
+            for q in packets:
+                refs[s].decode_fec(q) if fec else refs[s].decode(q)
+        refs[s] = orc.Decoder(2)
+        dec.flush(s)
+        refused[0] += 1
+    for step in range(nsteps):
         ids = [s for s in range(ns) if rng.integers(0, 5) != 0]
         T = 2 if step % 7 == 3 else 1
         pk = [[b"" if rng.integers(0, 25) == 0 else random_packet(rng, int(rng.integers(0, 32)), int(rng.integers(0, 2)), int(rng.integers(0, 4)))
@@ -368,15 +400,30 @@ def test_batch_engine_random_packets_losses_fec_and_multi_sends():
         if T == 1 and step % 5 == 2:                     # every packet of this step follows a lost one: recover first
             fec_ids = [s for s, p in zip(ids, pk) if p[0]]
             fec_pk = [p[0] for p in pk if p[0]]
-            assert not any(dec.send(fec_pk, fec_ids, fec=True))
+            errs = dec.send(fec_pk, fec_ids, fec=True)
             dec.decode()
-            for s, p in zip(fec_ids, fec_pk):
-                check_pcm(refs[s].decode_fec(p), dec.read(s), f"step {step} stream {s} FEC")
+            for s, p, e in zip(fec_ids, fec_pk, errs):
+                if e:
+                    refuse(s, [p], fec=True)
+                else:
+                    check_pcm(refs[s].decode_fec(p), dec.read(s), f"seed {seed} step {step} stream {s} FEC")
         if T == 1:
-            assert not any(dec.send([p[0] for p in pk], ids))
+            errs = [[e] for e in dec.send([p[0] for p in pk], ids)]
         else:
-            assert not any(any(e) for e in dec.send_multi(pk, ids))
+            errs = dec.send_multi(pk, ids)
         dec.decode()
-        for s, p in zip(ids, pk):
+        for s, p, e in zip(ids, pk, errs):
+            if any(e):
+                refuse(s, p)
+                continue
             want = np.concatenate([refs[s].decode(q) for q in p])
-            check_pcm(want, dec.read(s)[: len(want)], f"step {step} stream {s}")
+            check_pcm(want, dec.read(s)[: len(want)], f"seed {seed} step {step} stream {s}")
+    dec.close()
+    assert refused[0] <= 1 + nsteps * ns // 100, refused
+
+
+def test_batch_engine_random_packets_losses_fec_and_multi_sends():
+    """the batch engine under the same fuzz: 96 streams, each step a random subset of them gets a random packet of any TOC (or a
+    loss, or an FEC recovery send first), some steps as a two-packets-per-stream send -- runs of uneven length, SILK depths 0-3,
+    every launch round -- every stream's PCM against its own oracle decoder after every step"""
+    fuzz_batch_engine(77, 50)
