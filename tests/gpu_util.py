@@ -48,6 +48,9 @@ class HostParser:
         n = fn(self.h, b, len(b), self.fi, self.celt, 48, C.byref(nc), self.leaves, self.max_leaves, C.byref(nl), self.silk, 16, C.byref(ns))
         return n, nc.value, nl.value, ns.value
 
+    def reset(self):
+        self.lib.opusgpu_parser_reset(self.h)
+
     def __del__(self):
         try:
             self.lib.opusgpu_parser_destroy(self.h)

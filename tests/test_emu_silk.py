@@ -182,3 +182,34 @@ def test_random_packets_every_toc(emu, channels):
         if p:
             seen.add((config, stereo))
     assert len(seen) == 64
+
+
+# A hybrid packet (config 13, mono, code 3) that the decoder must refuse in the middle of a frame: the frame's redundancy length
+# leaves no room for the frame itself (decoder.rs:100-104).  Found by the long fuzz runs (about one random hybrid packet in 20 000).
+REFUSED_HYBRID_PACKET = bytes.fromhex(
+    "6b844743321935fb956732ba1843e717e4a1b64205a825f34e31c89f1fe99c71d6e79323ca5d6c2b41e1a45479fd48ec1dac885c9a116f8c"
+    "dbb554824e094b592274ed82d7421d1bddad9af52b201edaa25dd371e573a9a40f1c7a7bcf8365c861bee8ee612865d41748921f4afec4cc"
+    "dbe0d47bf2fe90e2cca00316a2d9749c0856715bf02f1df9b89416392cf4f434dc024e29a1d7a4ae06ea47cd1a8c83b869750d60006c3e7f"
+    "9c1acb7a125aaa6d84433191b399d9759446f2f862aebbd34f19a456e381fef8d16cfbece161be1f93a247f0f3f859283175df749ca5e09f")
+
+
+def test_refused_packet_restarts_the_stream(emu):
+    """stereo SILK, then a mono hybrid packet refused midway, then stereo SILK again: the host parser must not run ahead of the
+    device state (the refused packet's records are dropped) -- the stream starts again, as the oracle does from a fresh decoder;
+    the same with an explicit flush after the refusal.  (Before the fix the side channel kept its old history on the device: its
+    reset record went out with the refused packet, and flush skipped the channel as never coded.)"""
+    for explicit_flush in (False, True):
+        rng = np.random.default_rng(31)
+        d, ref = EmuDecoder(emu, 2), orc.Decoder(2)
+        for i in range(4):
+            p = random_packet(rng, 9, 1, 0)
+            check_pcm(ref.decode(p), d.decode(p), f"packet {i}")
+        assert d.decode(REFUSED_HYBRID_PACKET) < 0
+        with pytest.raises(ValueError):
+            ref.decode(REFUSED_HYBRID_PACKET)
+        if explicit_flush:
+            d.hp.reset()
+        ref = orc.Decoder(2)
+        for i in range(4):
+            p = random_packet(rng, 9, 1, int(rng.integers(0, 2)))
+            check_pcm(ref.decode(p), d.decode(p), f"packet {i} after the refused one")
