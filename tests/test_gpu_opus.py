@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 import orc
-from gpu_util import HostParser, check_pcm
+from gpu_util import HostParser, RecentPeak, check_pcm
 from opus_amd import BatchDecoder, Decoder, _abi as A, parse_packet
 
 pytestmark = pytest.mark.gpu
@@ -342,7 +342,7 @@ def fuzz_one_stream(channels, seed, npackets):
         d.configure()
         return d, orc.Decoder(channels)
     d, ref = fresh()
-    refused = 0
+    refused, recent = 0, RecentPeak()
     for i in range(npackets):
         config, stereo, code = int(rng.integers(0, 32)), int(rng.integers(0, 2)), int(rng.integers(0, 4))
         what = f"seed {seed} packet {i} (config {config}, stereo {stereo}, code {code})"
@@ -352,7 +352,9 @@ def fuzz_one_stream(channels, seed, npackets):
                 p = b""                                 # lost
             elif rng.integers(0, 12) == 0:              # the previous one "was lost": FEC recovery from this one first
                 d.send_packet_fec(p)
-                check_pcm(ref.decode_fec(p), d.receive_frame(), what + ", FEC")
+                r = ref.decode_fec(p)
+                check_pcm(r, d.receive_frame(), what + ", FEC", recent.value())
+                recent.push(r)
             d.send_packet(p)
         except OpusError:
             with pytest.raises(ValueError):             # the oracle refuses it as well (FEC recovery included)
@@ -361,10 +363,12 @@ def fuzz_one_stream(channels, seed, npackets):
             refused += 1
             d.close()
             d, ref = fresh()
+            recent = RecentPeak()
             continue
         out, r = d.receive_frame(), ref.decode(p)
         assert out.shape == r.shape, what
-        check_pcm(r, out, what)
+        check_pcm(r, out, what, recent.value())
+        recent.push(r)
     d.close()
     assert refused <= npackets // 100, refused
 
@@ -376,13 +380,15 @@ def test_random_packets_every_toc_on_gpu(channels):
     fuzz_one_stream(channels, 200 + channels, 600)
 
 
-def fuzz_batch_engine(seed, nsteps, ns=96):
-    """the batch engine under the same fuzz (also run for many seeds by tools/fuzz_gpu.py)"""
+def fuzz_batch_engine(seed, nsteps, ns=96, wide=False):
+    """the batch engine under the same fuzz (also run for many seeds by tools/fuzz_gpu.py; `wide`: sends of 1-8 packets per
+    stream, and every third step the same CELT-only configuration and frame count for every stream -- the sends that become one
+    launch with several frames per workgroup)"""
     from test_emu_silk import random_packet
     rng = np.random.default_rng(seed)
     dec = BatchDecoder(ns, 2, 0)
     refs = [orc.Decoder(2) for _ in range(ns)]
-    refused = [0]
+    refused, recent = [0], [RecentPeak() for _ in range(ns)]
 
     def refuse(s, packets, fec=False):
         """the engine refused a packet of stream s (see fuzz_one_stream): so does the oracle; both start the stream afresh"""
@@ -390,13 +396,26 @@ def fuzz_batch_engine(seed, nsteps, ns=96):
             for q in packets:
                 refs[s].decode_fec(q) if fec else refs[s].decode(q)
         refs[s] = orc.Decoder(2)
+        recent[s] = RecentPeak()
         dec.flush(s)
         refused[0] += 1
     for step in range(nsteps):
         ids = [s for s in range(ns) if rng.integers(0, 5) != 0]
         T = 2 if step % 7 == 3 else 1
-        pk = [[b"" if rng.integers(0, 25) == 0 else random_packet(rng, int(rng.integers(0, 32)), int(rng.integers(0, 2)), int(rng.integers(0, 4)))
-               for _ in range(T)] for _ in ids]
+        if wide and step % 5 != 2:
+            T = int(rng.choice([1, 1, 2, 3, 4, 8]))
+        if wide and step % 3 == 0:
+            config, code = int(rng.integers(16, 32)), int(rng.integers(0, 4))
+            pk = [[random_packet(rng, config, int(rng.integers(0, 2)), code) for _ in range(T)] for _ in ids]
+            if code == 3:                               # (code 3 draws its own frame count: keep the streams that drew the first one's)
+                n0 = pk[0][0][1] & 63
+                keep = [j for j, p in enumerate(pk) if all(q[1] & 63 == n0 for q in p)]
+                ids, pk = [ids[j] for j in keep], [pk[j] for j in keep]
+                if not ids:
+                    continue
+        else:
+            pk = [[b"" if rng.integers(0, 25) == 0 else random_packet(rng, int(rng.integers(0, 32)), int(rng.integers(0, 2)), int(rng.integers(0, 4)))
+                   for _ in range(T)] for _ in ids]
         if T == 1 and step % 5 == 2:                     # every packet of this step follows a lost one: recover first
             fec_ids = [s for s, p in zip(ids, pk) if p[0]]
             fec_pk = [p[0] for p in pk if p[0]]
@@ -406,7 +425,9 @@ def fuzz_batch_engine(seed, nsteps, ns=96):
                 if e:
                     refuse(s, [p], fec=True)
                 else:
-                    check_pcm(refs[s].decode_fec(p), dec.read(s), f"seed {seed} step {step} stream {s} FEC")
+                    want = refs[s].decode_fec(p)
+                    check_pcm(want, dec.read(s), f"seed {seed} step {step} stream {s} FEC", recent[s].value())
+                    recent[s].push(want)
         if T == 1:
             errs = [[e] for e in dec.send([p[0] for p in pk], ids)]
         else:
@@ -417,7 +438,8 @@ def fuzz_batch_engine(seed, nsteps, ns=96):
                 refuse(s, p)
                 continue
             want = np.concatenate([refs[s].decode(q) for q in p])
-            check_pcm(want, dec.read(s)[: len(want)], f"seed {seed} step {step} stream {s}")
+            check_pcm(want, dec.read(s)[: len(want)], f"seed {seed} step {step} stream {s}", recent[s].value())
+            recent[s].push(want)
     dec.close()
     assert refused[0] <= 1 + nsteps * ns // 100, refused
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Long fuzz run on the GPU behind tests/test_gpu_opus.py's two fuzz tests: random packets under every TOC with losses, FEC
-recoveries and two-packet sends, through the one-stream C ABI and through the batch engine, every PCM block against the oracle.
+recoveries and sends of 1-8 packets per stream (uniform CELT-only sends among them), through the one-stream C ABI and through the batch engine, every PCM block against the oracle.
    usage (GPU box): python3 -u tools/fuzz_gpu.py <first seed> <seconds>       prints a line per seed; exit status 1 on a mismatch"""
 import os
 import sys
@@ -19,7 +19,8 @@ while time.time() - t0 < budget:
             T.fuzz_one_stream(ch, 1000 * seed + ch, 1500)
             packets += 1500
         T.fuzz_batch_engine(1000 * seed + 7, 60)
-        sends += 60
+        T.fuzz_batch_engine(1000 * seed + 8, 60, wide=True)
+        sends += 120
     except AssertionError as e:
         bad += 1
         print("MISMATCH seed", seed, str(e)[:300], flush=True)

@@ -13,6 +13,7 @@ from opus_amd.decoder import BatchDecoder                    # noqa: E402
 from test_emu_silk import random_packet                      # noqa: E402
 
 seed, nsteps, ns = int(sys.argv[1]), int(sys.argv[2]) if len(sys.argv) > 2 else 60, 96
+wide = seed % 1000 == 8                                    # (tools/fuzz_gpu.py: seeds ...008 are the wide runs)
 rng = np.random.default_rng(seed)
 dec = BatchDecoder(ns, 2, 0)
 refs = [orc.Decoder(2) for _ in range(ns)]
@@ -38,8 +39,20 @@ def refuse(s, packets, fec=False):
 for step in range(nsteps):
     ids = [s for s in range(ns) if rng.integers(0, 5) != 0]
     T = 2 if step % 7 == 3 else 1
-    pk = [[b"" if rng.integers(0, 25) == 0 else random_packet(rng, int(rng.integers(0, 32)), int(rng.integers(0, 2)), int(rng.integers(0, 4)))
-           for _ in range(T)] for _ in ids]
+    if wide and step % 5 != 2:
+        T = int(rng.choice([1, 1, 2, 3, 4, 8]))
+    if wide and step % 3 == 0:
+        config, code = int(rng.integers(16, 32)), int(rng.integers(0, 4))
+        pk = [[random_packet(rng, config, int(rng.integers(0, 2)), code) for _ in range(T)] for _ in ids]
+        if code == 3:
+            n0 = pk[0][0][1] & 63
+            keep = [j for j, p in enumerate(pk) if all(q[1] & 63 == n0 for q in p)]
+            ids, pk = [ids[j] for j in keep], [pk[j] for j in keep]
+            if not ids:
+                continue
+    else:
+        pk = [[b"" if rng.integers(0, 25) == 0 else random_packet(rng, int(rng.integers(0, 32)), int(rng.integers(0, 2)), int(rng.integers(0, 4)))
+               for _ in range(T)] for _ in ids]
     bad = []
     if T == 1 and step % 5 == 2:
         fec_ids = [s for s, p in zip(ids, pk) if p[0]]
@@ -57,6 +70,11 @@ for step in range(nsteps):
                 except AssertionError as ex:
                     got = got[: len(want)]
                     d = np.abs(want - got).max(axis=1)
+                    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                    np.savez(os.path.join(ROOT, "gpurun_out", f"replay_{seed}.npz"), want=want, got=got)
+                    print("   per 120 samples: rms of the reference | max abs diff")
+                    for o in range(0, len(want), 120):
+                        print(f"     {o:5d}  {np.sqrt((want[o:o + 120] ** 2).mean()):.3e}  {d[o:o + 120].max():.3e}")
                     bad.append((s, "FEC " + str(ex)[:100] + f"; {len(want)} samples, peak {np.abs(want).max():.3e}, rms {np.sqrt((want ** 2).mean()):.3e}, "
                                    f"max abs diff {d.max():.3e} at {int(d.argmax())}, differing > 1e-7: {int((d > 1e-7).sum())}"))
     if T == 1:
@@ -76,7 +94,8 @@ for step in range(nsteps):
         except AssertionError as ex:
             d = np.abs(want - got).max(axis=1)
             nz = np.nonzero(d > 1e-4 * max(1.0, np.abs(want).max()))[0]
-            bad.append((s, str(ex)[:100] + f"; {len(want)} samples, differing {nz[0]}..{nz[-1]} ({len(nz)})"))
+            bad.append((s, str(ex)[:100] + f"; {len(want)} samples, peak {np.abs(want).max():.3e}, rms {np.sqrt((want ** 2).mean()):.3e}, max abs diff {d.max():.3e}"
+                           + (f", differing {nz[0]}..{nz[-1]} ({len(nz)})" if len(nz) else "")))
     if bad:
         for s, msg in bad:
             print("step", step, "stream", s, msg)
