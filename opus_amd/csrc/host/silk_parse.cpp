@@ -83,13 +83,17 @@ void stabilize(const BandTables &t, int16_t *nlsf)
             const int sum = nlsf[k - 1] + nlsf[k];
             const int center = std::min(cmax, std::max(cmin, (sum >> 1) + (sum & 1)));
             nlsf[k - 1] = int16_t(center - half);
-            nlsf[k] = int16_t(nlsf[k - 1] + ms[k]);
+            nlsf[k] = int16_t(std::min(32767, nlsf[k - 1] + ms[k]));
         }
     }
-    std::sort(nlsf, nlsf + order);                                           // fallback: sort and clamp both ways
+    // fallback: sort and clamp both ways.  The way up saturates at 32767 (libopus' silk_NLSF_stabilize; the reference adds in
+    // i16, decoder.rs:189, which overflows -- a panic in a checked build, and a negative table index at :335-339 otherwise --
+    // when a packet crowds the coefficients at the top; the way down then brings them into range).  Found by
+    // tools/parse_fuzz_asan.cpp.
+    std::sort(nlsf, nlsf + order);
     int prev = 0;
     for (int i = 0; i < order; i++) {
-        nlsf[i] = int16_t(std::max<int>(nlsf[i], prev + ms[i]));
+        nlsf[i] = int16_t(std::min(32767, std::max<int>(nlsf[i], prev + ms[i])));
         prev = nlsf[i];
     }
     int next = 32768;
@@ -120,7 +124,8 @@ bool is_stable(const int16_t *lpc, int order)
         const int32_t gain = int32_t(uint32_t(inv) << 16) + (err * inv >> 13);
         const int32_t *src = buf[cur];
         int32_t *dst = buf[cur ^ 1];
-        for (int j = 0; j < k; j++) dst[j] = mul_shift(src[j] - mul_shift(src[k - j - 1], rc, 31), gain, b1);
+        // (the difference wraps for coefficients far outside a stable filter's, as in the reference's release build: unsigned here)
+        for (int j = 0; j < k; j++) dst[j] = mul_shift(int32_t(uint32_t(src[j]) - uint32_t(mul_shift(src[k - j - 1], rc, 31))), gain, b1);
         cur ^= 1;
     }
 }
@@ -167,7 +172,7 @@ void lsf_to_lpc(const BandTables &t, float *lpc, const int16_t *nlsf)
     const int order = t.order, half = order / 2;
     int32_t c[16], p[9] = {0}, q[9] = {0}, a[16];
     for (int i = 0; i < order; i++) {
-        const int idx = nlsf[i] >> 8, frac = nlsf[i] & 255;
+        const int idx = std::min(127, std::max(0, nlsf[i] >> 8)), frac = nlsf[i] & 255;       // (in range by construction: stabilize)
         const int c0 = SILK_COSINE[idx], c1 = SILK_COSINE[idx + 1];
         c[t.ordering[i]] = (c0 * 256 + (c1 - c0) * frac + 4) >> 3;
     }

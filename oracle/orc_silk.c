@@ -91,14 +91,14 @@ static void stabilize(const BandTab *t, int16_t *nlsf)   /* silk/decoder.rs:137-
             if (center < min_center) center = min_center;
             if (center > max_center) center = max_center;
             nlsf[k - 1] = (int16_t)(center - half_delta);
-            nlsf[k] = (int16_t)(nlsf[k - 1] + ms[k]);
+            { int v = nlsf[k - 1] + ms[k]; nlsf[k] = (int16_t)(v > 32767 ? 32767 : v); }
         }
     }
     qsort(nlsf, order, sizeof(int16_t), cmp_i16);
     int prev = 0;
     for (int i = 0; i < order; i++) {
         int v = prev + ms[i];
-        if (nlsf[i] < v) nlsf[i] = (int16_t)v;
+        if (nlsf[i] < v) nlsf[i] = (int16_t)(v > 32767 ? 32767 : v);     /* saturating, as libopus: decoder.rs:189 adds in i16 and overflows (panic / negative index at :335) */
         prev = nlsf[i];
     }
     int next = 32768;
@@ -128,7 +128,8 @@ static int is_stable(const int16_t *lpcs, int order)   /* silk/decoder.rs:206-26
         int32_t gain = (int32_t)((uint32_t)inv << 16) + (err * inv >> 13);
         int32_t *prev = (k & 1) ? even : odd, *cur = (k & 1) ? odd : even;
         for (int j = 0; j < k; j++) {
-            int32_t v = prev[j] - mul_shift(prev[k - j - 1], rc, 31);
+            /* (wraps for coefficients far outside a stable filter's, as the reference's release build does: unsigned here) */
+            int32_t v = (int32_t)((uint32_t)prev[j] - (uint32_t)mul_shift(prev[k - j - 1], rc, 31));
             cur[j] = mul_shift(v, gain, b1);
         }
         k--;
@@ -183,6 +184,8 @@ static void lsf_to_lpc(const BandTab *t, float *lpcs, const int16_t *nlsf)   /* 
     int32_t lsps[16], p[9], q[9], a[16];
     for (int i = 0; i < order; i++) {
         int idx = nlsf[i] >> 8, off = nlsf[i] & 255;
+        if (idx < 0) idx = 0;                           /* (in range by construction: stabilize saturates) */
+        if (idx > 127) idx = 127;
         int c = SILK_COSINE[idx], nc = SILK_COSINE[idx + 1];
         lsps[t->ordering[i]] = (c * 256 + (nc - c) * off + 4) >> 3;
     }

@@ -1,6 +1,7 @@
 """CPU CI of the SILK kernel logic + the whole packet pipeline (host parser -> SILK kernels -> CELT kernel) in the
 g++ emulation build (tests/emu), against the oracle and the reference's golden PCM.  See test_emu_celt.py."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -213,3 +214,13 @@ def test_refused_packet_restarts_the_stream(emu):
         for i in range(4):
             p = random_packet(rng, 9, 1, int(rng.integers(0, 2)))
             check_pcm(ref.decode(p), d.decode(p), f"packet {i} after the refused one")
+
+
+def test_hostile_packets_are_refused_or_decoded_alike():
+    """tools/fuzz_hostile.py, short: random lengths, random TOCs, runs of 0x00 / 0xFF -- the host parser + kernel bodies and the
+    oracle refuse the same packets and agree on the PCM of the others"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_hostile.py"), "3", "400"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "bad 0" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])

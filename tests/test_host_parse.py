@@ -247,3 +247,26 @@ def test_tell_frac_thresholds_match_the_squaring_loop():
     src = open(os.path.join(os.path.dirname(__file__), "..", "opus_amd", "csrc", "host", "rangedec.hpp")).read()
     body = src[src.index("int tell_frac() const"):src.index("void to_end()")]
     assert [int(x) for x in re.findall(r"r >= (\d+)u", body)] == steps and len(steps) == 7
+
+
+def test_host_parser_under_sanitizers_on_arbitrary_bytes(tmp_path):
+    """tools/parse_fuzz_asan.cpp: the host parser built with AddressSanitizer + UBSan (bounds, signed overflow) fed packets nobody
+    would send -- random lengths, random TOCs, runs of 0x00 / 0xFF, losses, FEC calls: no report.  (Seed 1 is the run that found
+    the NLSF stabilisation's i16 overflow -- a negative cosine-table index, decoder.rs:189 / :335 -- and the wrapping difference
+    in the LPC stability test.)"""
+    import shutil
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    host = os.path.join(root, "opus_amd", "csrc", "host")
+    exe = str(tmp_path / "parse_fuzz_asan")
+    srcs = [os.path.join(host, f + ".cpp") for f in ("celt_parse", "packet", "stream_parser", "silk_parse", "silk_tables", "celt_tables")]
+    cmd = ["g++", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize=shift", "-fno-sanitize-recover=all", "-std=c++17",
+           "-fno-strict-aliasing", "-o", exe, os.path.join(root, "tools", "parse_fuzz_asan.cpp")] + srcs
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode and "sanitize" in r.stderr and "cannot find" in r.stderr:
+        pytest.skip("sanitizer runtimes not installed")
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([exe, "1", "100000"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "no sanitizer report" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
