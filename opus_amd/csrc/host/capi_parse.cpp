@@ -80,8 +80,10 @@ static int parser_parse(opusgpu_parser *p, bool fec, const uint8_t *pkt, size_t 
     p->celt.clear(); p->leaves.clear(); p->silk.clear();
     int n = fec ? p->sp.parse_fec(pkt, len, frames, p->celt, p->leaves, p->silk) : p->sp.parse(pkt, len, frames, p->celt, p->leaves, p->silk);
     if (n < 0) return n;
-    if (*ncelt + p->celt.size() > celt_cap || *nleaves + p->leaves.size() > leaf_cap || *nsilk + p->silk.size() > silk_cap)
+    if (*ncelt + p->celt.size() > celt_cap || *nleaves + p->leaves.size() > leaf_cap || *nsilk + p->silk.size() > silk_cap) {
+        p->sp.reset();                                  // the records are not handed over: the stream starts again (as a refused packet's)
         return OPUSGPU_BAD_ARG;
+    }
     for (int f = 0; f < n; f++) { frames[f].celt_index += *ncelt; frames[f].silk_index += *nsilk; }
     for (auto &h : p->celt) h.leaf_begin += *nleaves;
     if (!p->celt.empty()) std::memcpy(celt + *ncelt, p->celt.data(), p->celt.size() * sizeof(OgCeltHdr));

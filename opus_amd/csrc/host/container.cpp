@@ -111,7 +111,7 @@ struct opusgpu_demux {
         const uint8_t flags = c.u8();
         if (!c.ok) return false;
         if (!have_track || track != opus_track) return true;    // another track: skip
-        const int64_t pts = (cluster_tc + rel) * int64_t(timecode_scale);
+        const int64_t pts = int64_t((uint64_t(cluster_tc) + uint64_t(int64_t(rel))) * timecode_scale);    // (a hostile scale wraps: unsigned)
         const int lacing = (flags >> 1) & 3;
         if (lacing == 0) { add_packet(b + c.p, end - c.p, pts); return true; }
         const int nfr = int(c.u8()) + 1;
@@ -128,6 +128,7 @@ struct opusgpu_demux {
             if (nfr > 1) sz[0] = size_t(cur);
             for (int i = 1; i + 1 < nfr; i++) {
                 const uint64_t raw = c.vint(false, nullptr, &w);
+                if (!c.ok) return false;                        // (w is not set then)
                 cur += int64_t(raw) - ((int64_t(1) << (7 * w - 1)) - 1);
                 if (cur < 0) return false;
                 sz[i] = size_t(cur);

@@ -261,7 +261,7 @@ def test_host_parser_under_sanitizers_on_arbitrary_bytes(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     host = os.path.join(root, "opus_amd", "csrc", "host")
     exe = str(tmp_path / "parse_fuzz_asan")
-    srcs = [os.path.join(host, f + ".cpp") for f in ("celt_parse", "packet", "stream_parser", "silk_parse", "silk_tables", "celt_tables")]
+    srcs = [os.path.join(host, f + ".cpp") for f in ("celt_parse", "packet", "stream_parser", "silk_parse", "silk_tables", "celt_tables", "capi_parse")]
     cmd = ["g++", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize=shift", "-fno-sanitize-recover=all", "-std=c++17",
            "-fno-strict-aliasing", "-o", exe, os.path.join(root, "tools", "parse_fuzz_asan.cpp")] + srcs
     r = subprocess.run(cmd, capture_output=True, text=True)

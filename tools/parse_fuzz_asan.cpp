@@ -1,7 +1,7 @@
 // Host parser under AddressSanitizer + UBSan: arbitrary bytes (not only well-formed packets) through StreamParser::parse /
 // parse_fec and the Ogg / container reader -- nothing may read or write out of bounds, whatever the packet says.
 //   g++ -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=all -std=c++17 -fno-strict-aliasing -o /tmp/parse_fuzz_asan \
-//       tools/parse_fuzz_asan.cpp opus_amd/csrc/host/{celt_parse,packet,stream_parser,silk_parse,silk_tables,celt_tables}.cpp
+//       tools/parse_fuzz_asan.cpp opus_amd/csrc/host/{celt_parse,packet,stream_parser,silk_parse,silk_tables,celt_tables,capi_parse}.cpp
 //   /tmp/parse_fuzz_asan [seed] [packets]
 #include <cstdio>
 #include <cstdlib>
@@ -45,6 +45,36 @@ int main(int argc, char **argv)
             if (rnd() % 5000 == 0) sp.reset();
         }
     }
+    // the same kind of input through the C ABI's parser entry points, into record arrays of random (often too small) capacity,
+    // and through the framing helpers (RFC 6716 3.2 packets, self-delimited framing of appendix B)
+    long abi_ok = 0, abi_refused = 0;
+    for (int ch = 1; ch <= 2; ch++) {
+        opusgpu_parser *ps = nullptr;
+        if (opusgpu_parser_create(&ps, ch) != 0) { std::printf("parser_create failed\n"); return 1; }
+        for (long i = 0; i < N / 4; i++) {
+            const size_t len = rnd() % 3 == 0 ? rnd() % 8 : 1 + rnd() % 300;
+            std::vector<uint8_t> p(len);
+            for (auto &b : p) b = uint8_t(rnd());
+            const uint32_t ccap = rnd() % 50, lcap = rnd() % 4 == 0 ? rnd() % 64 : 8192, scap = rnd() % 8;
+            std::vector<OgCeltHdr> c(ccap);
+            std::vector<OgCeltLeaf> l(lcap);
+            std::vector<OgSilkFrame> sf(scap);
+            uint32_t nc = 0, nl = 0, ns = 0;
+            const int n = (rnd() % 8 ? opusgpu_parser_parse : opusgpu_parser_parse_fec)(ps, len ? p.data() : nullptr, len, fi, c.data(), ccap, &nc, l.data(), lcap, &nl,
+                                                                                         sf.data(), scap, &ns);
+            if (n < 0) abi_refused++; else abi_ok++;
+            if (nc > ccap || nl > lcap || ns > scap) { std::printf("more records than room\n"); return 1; }
+            OgPacket pk;
+            (void)opusgpu_packet_parse(len ? p.data() : nullptr, len, &pk);
+            std::vector<uint8_t> out(rnd() % 400);
+            size_t out_len = 0;
+            int consumed = 0;
+            const int rc = opusgpu_packet_undelimit(p.data(), len, out.data(), out.size(), &out_len, &consumed);
+            if (rc == 0 && (out_len > out.size() || consumed < 0 || size_t(consumed) > len)) { std::printf("undelimit out of range\n"); return 1; }
+        }
+        opusgpu_parser_destroy(ps);
+    }
+    std::printf("C ABI parser: %ld accepted, %ld refused\n", abi_ok, abi_refused);
     std::printf("parse_fuzz_asan: %ld packets accepted (%ld frames), %ld refused, no sanitizer report\n", ok, frames, refused);
     return 0;
 }
