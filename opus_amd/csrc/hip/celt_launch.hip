@@ -234,6 +234,7 @@ __global__ __launch_bounds__(OG_PLAN_WG) __attribute__((amdgpu_waves_per_eu(4, 8
         for (uint32_t p = tid; p < nf * (sizeof(OgPlanShared) / 4); p += OG_PLAN_WG) ((uint32_t *)&S[0])[p] = 0;
     }
     __syncthreads();
+    if (stop == 3) return;            // (profiling: the fetches alone)
     OgTask tk[OG_PLAN_ITEMS][2];      // the work items' task records
 #pragma unroll
     for (int r = 0; r < OG_PLAN_ITEMS; r++) {

@@ -380,14 +380,14 @@ def test_random_packets_every_toc_on_gpu(channels):
     fuzz_one_stream(channels, 200 + channels, 600)
 
 
-def fuzz_batch_engine(seed, nsteps, ns=96, wide=False):
+def fuzz_batch_engine(seed, nsteps, ns=96, wide=False, channels=2):
     """the batch engine under the same fuzz (also run for many seeds by tools/fuzz_gpu.py; `wide`: sends of 1-8 packets per
     stream, and every third step the same CELT-only configuration and frame count for every stream -- the sends that become one
     launch with several frames per workgroup)"""
     from test_emu_silk import random_packet
     rng = np.random.default_rng(seed)
-    dec = BatchDecoder(ns, 2, 0)
-    refs = [orc.Decoder(2) for _ in range(ns)]
+    dec = BatchDecoder(ns, channels, 0)
+    refs = [orc.Decoder(channels) for _ in range(ns)]
     refused, recent = [0], [RecentPeak() for _ in range(ns)]
 
     def refuse(s, packets, fec=False):
@@ -395,7 +395,7 @@ def fuzz_batch_engine(seed, nsteps, ns=96, wide=False):
         with pytest.raises(ValueError):
             for q in packets:
                 refs[s].decode_fec(q) if fec else refs[s].decode(q)
-        refs[s] = orc.Decoder(2)
+        refs[s] = orc.Decoder(channels)
         recent[s] = RecentPeak()
         dec.flush(s)
         refused[0] += 1

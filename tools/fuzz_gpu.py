@@ -20,7 +20,8 @@ while time.time() - t0 < budget:
             packets += 1500
         T.fuzz_batch_engine(1000 * seed + 7, 60)
         T.fuzz_batch_engine(1000 * seed + 8, 60, wide=True)
-        sends += 120
+        T.fuzz_batch_engine(1000 * seed + 9, 60, wide=bool(seed & 1), channels=1)
+        sends += 180
     except AssertionError as e:
         bad += 1
         print("MISMATCH seed", seed, str(e)[:300], flush=True)
