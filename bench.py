@@ -49,7 +49,7 @@ def parse_args():
     ap.add_argument("--split", type=int, default=1,
                     help="issue each step as this many independent sub-batches of streams, each on a HIP stream of its own "
                          "(the sub-batches share nothing: their kernels may run side by side)")
-    ap.add_argument("--workload", choices=["c2", "c3", "c4"], default="c2",
+    ap.add_argument("--workload", choices=["c2", "c3", "c4", "c5"], default="c2",
                     help="c2 (default, the headline): BASELINE configs[1], synthetic CELT FB stereo 20 ms, 4096 streams per GPU; "
                          "c3: BASELINE configs[2], SILK WB mono 20 ms, 16384 streams per GPU (SURVEY.md 8d); "
                          "c4: BASELINE configs[3], hybrid SWB/FB + CELT of every frame size, 8192 streams per GPU")
@@ -321,6 +321,8 @@ def main_c3(a, rank, local_rank, world):
 
 C4_STREAMS_PER_GPU = 8192
 C4_VECTORS = (5, 6, 7, 10)
+C5_STREAMS_PER_GPU = 12 * 512
+C5_VECTORS = tuple(range(1, 13))
 
 
 def vector_packets(ids):
@@ -389,16 +391,19 @@ def main_c4(a, rank, local_rank, world):
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     lib = A.load()
-    S = a.streams if a.streams != STREAMS_PER_GPU else C4_STREAMS_PER_GPU
+    c5 = a.workload == "c5"                             # BASELINE configs[4]: all twelve vectors, the same launches
+    VECS, S_DEFAULT, wl = (C5_VECTORS, C5_STREAMS_PER_GPU, "c5") if c5 else (C4_VECTORS, C4_STREAMS_PER_GPU, "c4")
+    S = a.streams if a.streams != STREAMS_PER_GPU else S_DEFAULT
     K, W = a.steps, a.warmup
     nsteps = K + W
-    pools = vector_packets(C4_VECTORS)
+    pools = vector_packets(VECS)
     ids = sharding.shard_stream_ids(rank, world, S)
+    NV = len(VECS)
 
-    def packet(s, k):                                   # stream s replays one of the four vectors from its own offset, in file order
+    def packet(s, k):                                   # stream s replays one of the vectors from its own offset, in file order
         g = int(ids[s])
-        v = pools[C4_VECTORS[g % 4]]
-        return v[((g // 4) * 7919 + k) % len(v)]
+        v = pools[VECS[g % NV]]
+        return v[((g // NV) * 7919 + k) % len(v)]
 
     parser = BatchDecoder(S, 2, local_rank)             # host half only: packets -> side-info + launch plan
     steps, t_parse, audio_s, alg_total, rec_total = [], 0.0, 0.0, 0, [0, 0]
@@ -497,13 +502,13 @@ def main_c4(a, rank, local_rank, world):
         import orc
         from gpu_util import check_pcm
         rows = pcm.view(S, stride).cpu().numpy()
-        sample = sorted({0, 1, 2, 3, S // 3, S // 2, S // 2 + 1, 2 * S // 3 + 2, S - 1})
+        sample = sorted(set(range(NV)) | {S // 3, S // 2, S // 2 + 1, 2 * S // 3 + 2, S - 1})    # every vector at least once
         worst = 0.0
         for s in sample:
             d = orc.Decoder(2)
             for k in range(nsteps):
                 want = d.decode(packet(s, k))
-            worst = max(worst, check_pcm(want, rows[s][: want.size].reshape(want.shape), f"c4 stream {s}"))
+            worst = max(worst, check_pcm(want, rows[s][: want.size].reshape(want.shape), f"{wl} stream {s}"))
         verify = {"ok": True, "streams": sample, "max_scaled_err": float(f"{worst:.3e}"),
                   "bar": "max abs err <= 1e-4 (scaled by the reference peak when that exceeds 1), SNR >= 90 dB vs the CPU oracle"}
     if rank != 0:
@@ -512,13 +517,19 @@ def main_c4(a, rank, local_rank, world):
         return
     total_audio = audio_s * world                       # (every rank decodes the same mix: weak scaling)
     alg = alg_total / K
-    c4_traffic, c4_pmc = pmc_info("c4", step_s) if S == C4_STREAMS_PER_GPU else (None, None)
-    line = {"metric": "decoded audio-sec/sec (hybrid SWB/FB + CELT 2.5-20 ms mixed, 8192 streams)",
+    c4_traffic, c4_pmc = pmc_info(wl, step_s) if S == S_DEFAULT else (None, None)
+    line = {"metric": "decoded audio-sec/sec (the 12 RFC 6716 vectors, 512 replicas each)" if c5 else
+                      "decoded audio-sec/sec (hybrid SWB/FB + CELT 2.5-20 ms mixed, 8192 streams)",
             "value": round(total_audio / elapsed, 1), "unit": "audio-s/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "RFC 6716 vectors 05 / 06 / 07 / 10 replayed",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "RFC 6716 vectors 01 .. 12 replayed" if c5 else "RFC 6716 vectors 05 / 06 / 07 / 10 replayed",
             "verified": bool(verify and verify["ok"]), "verify": verify,
-            "config": {"workload": "BASELINE configs[3] (SURVEY.md 8d C4): hybrid SWB / FB 10 and 20 ms (RFC vectors 05, 06), CELT of every "
+            "config": {"workload": ("BASELINE configs[4] (SURVEY.md 8d C5): all twelve RFC 6716 vectors -- SILK NB / MB / WB 10-60 ms, hybrid, CELT of "
+                                    "every bandwidth and frame size, mode switches with redundant frames, mono and stereo packets; stream s replays "
+                                    f"vector 1 + s % 12 from its own offset, one packet per stream per step, {S} streams per GPU; device-only: "
+                                    "side-info and launch plan pre-parsed and resident in HBM, PCM stays in HBM") if c5 else
+                                   "BASELINE configs[3] (SURVEY.md 8d C4): hybrid SWB / FB 10 and 20 ms (RFC vectors 05, 06), CELT of every "
                                    "bandwidth and frame size incl. transients (07), hybrid <-> CELT switching with redundant frames (10); stream s "
                                    f"replays vector (05, 06, 07, 10)[s % 4] from its own offset, one packet per stream per step, {S} streams per "
                                    "GPU; device-only: side-info and launch plan pre-parsed and resident in HBM, PCM stays in HBM",
@@ -594,7 +605,7 @@ def main():
         sys.exit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {a.gpus}")
     if a.workload == "c3":
         return main_c3(a, rank, local_rank, world)
-    if a.workload == "c4":
+    if a.workload in ("c4", "c5"):
         return main_c4(a, rank, local_rank, world)
     import numpy as np
     import torch

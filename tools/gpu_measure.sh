@@ -1,5 +1,5 @@
 #!/bin/bash
-# One measurement session on the GPU box (run from the repo root): for each workload (c2 c3 c4) the bench line, a
+# One measurement session on the GPU box (run from the repo root): for each workload (c2 c3 c4 c5) the bench line, a
 # rocprofv3 --kernel-trace --stats run and three --pmc passes (instruction mix + busy cycles, FETCH_SIZE, WRITE_SIZE: each pass a
 # process of its own under its own time limit), all from the same build.  tools/pmc_traffic.py turns the directory into
 # profiles/pmc_traffic.json (HBM bytes and VALU issue fraction per kernel).
@@ -13,7 +13,7 @@ groups=(
   "FETCH_SIZE"
   "WRITE_SIZE"
 )
-for w in ${@:-c2 c3 c4}; do
+for w in ${@:-c2 c3 c4 c5}; do
   if [ "$w" = c2 ]; then args=(--no-t1 --no-overlap-leg --no-e2e --no-pipeline-leg); else args=(--workload "$w"); fi
   timeout -k 10 240 python3 "$R/bench.py" "${args[@]}" --no-cpu-baseline > "$out/${w}_bench.json" 2> "$out/${w}_bench.err" || { tail -20 "$out/${w}_bench.err"; exit 1; }
   timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/${w}_prof" -- python3 "$R/bench.py" "${args[@]}" --steps 10 --warmup 2 --no-cpu-baseline > "$out/${w}_prof.log" 2>&1 || { tail -20 "$out/${w}_prof.log"; exit 1; }

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/pmc_traffic.json from one tools/gpu_measure.sh session: per workload (c2 c3 c4) and kernel, per launch --
+"""profiles/pmc_traffic.json from one tools/gpu_measure.sh session: per workload (c2 c3 c4 c5) and kernel, per launch --
 HBM bytes from the FETCH_SIZE / WRITE_SIZE passes, the VALU issue fraction from SQ_INSTS_VALU and GRBM_GUI_ACTIVE of the same
 dispatches, and the kernel's average duration from the session's rocprofv3 --kernel-trace --stats run.
 Units and the gfx950 correction as /opt/skills/guides/MI355X_MICROARCH.md prescribes: both size counters are in KiB; FETCH_SIZE
@@ -44,7 +44,7 @@ def durations(path):
 
 STEPS_RUN = 7      # tools/gpu_measure.sh runs the --pmc passes with --steps 5 --warmup 2 (and --no-verify): seven steps per process
 doc = {"source": root, "note": __doc__.split("usage:")[0].strip(), "steps_per_pmc_run": STEPS_RUN}
-for w in ("c2", "c3", "c4"):
+for w in ("c2", "c3", "c4", "c5"):
     cs = counters(os.path.join(root, f"{w}_pmc"))
     if not cs:
         continue
