@@ -259,6 +259,33 @@ def test_mixed_modes_c4_shape_8192_streams():
     assert len(lens_seen) > 2, "runs of several lengths in one launch"
 
 
+def test_all_vectors_c5_shape_6144_streams():
+    """BASELINE config 5 at full size through layer 2: the twelve RFC vectors x 512 replicas, each stream from its own offset, one
+    packet per stream per step -- SILK NB / MB / WB with 10-60 ms packets (depths 1-3), hybrid, CELT of every size, the mode
+    switches of vectors 08-10 with their redundant frames, all in the same launches.  One stream of every vector and a few more are
+    compared with the oracle at every step."""
+    vids = tuple(range(1, 13))
+    V = orc.load_vectors(ids=list(vids))
+    ns, steps = 12 * 512, 8
+    dec = BatchDecoder(ns, 2, 0)
+
+    def packet(s, k):
+        v = V[vids[s % 12]][1]
+        return v[((s // 12) * 7919 + k) % len(v)]
+    sample = sorted(set(range(12)) | {2047, 3073, 4100, 6142, 6143})
+    refs = {s: orc.Decoder(2) for s in sample}
+    recent = {s: RecentPeak() for s in sample}
+    for k in range(steps):
+        pk = [packet(s, k) for s in range(ns)]
+        assert not any(dec.send(pk))
+        dec.decode()
+        for s in sample:
+            want = refs[s].decode(pk[s])
+            check_pcm(want, dec.read(s), f"stream {s} (vector {vids[s % 12]}) step {k}", recent[s].value())
+            recent[s].push(want)
+    dec.close()
+
+
 @pytest.mark.parametrize("vid,npk", [(2, 300), (4, 400)])
 def test_fec_recovery_on_gpu(vid, npk):
     """in-band FEC through the one-stream C ABI (opusgpu_decoder_send_packet_fec): every third packet is lost and recovered from
