@@ -159,3 +159,63 @@ def test_undelimit_round_trip():
             a, b = parse_packet(got), parse_packet(p)
             assert (a["nframes"], a["frame_size"], a["code"]) == (b["nframes"], b["frame_size"], b["code"])
             assert [got[o: o + n] for o, n in a["frames"]] == [p[o: o + n] for o, n in b["frames"]]
+
+
+def fuzz_multistream(seed, npackets):
+    """random multistream decoders (1-4 streams, any number of them coupled, mapping family 255 with a random table -- silent
+    channels and channels fed twice included) on random packets: per packet one duration for all streams, every stream its own
+    mode / bandwidth / stereo flag / framing code (0-2), all but the last self-delimited; losses strewn in.  Expected: each
+    stream decoded on its own by the oracle, dealt to the channels by the table.  (Also run for many seeds by tools/fuzz_gpu.py.)"""
+    from gpu_util import RecentPeak
+    from opus_amd.decoder import OpusError
+    from test_emu_silk import random_packet
+    rng = np.random.default_rng(seed)
+    done = 0
+    while done < npackets:
+        ns = int(rng.integers(1, 5))
+        nc = int(rng.integers(0, ns + 1))
+        nch = int(rng.integers(1, 9))
+        mapping = [255 if rng.integers(0, 6) == 0 else int(rng.integers(0, ns + nc)) for _ in range(nch)]
+        d = Decoder(0)
+        d.set_extradata(opus_head(nch, 255, ns, nc, mapping))
+        d.configure()
+        refs = [orc.Decoder(2 if s < nc else 1) for s in range(ns)]
+        recent = RecentPeak()
+        for i in range(int(rng.integers(20, 60))):
+            ms = [10, 20, 20, 20, 2.5, 5, 40, 60][int(rng.integers(0, 8))]
+            code = int(rng.integers(0, 3))
+            parts = []
+            for s in range(ns):
+                if ms in (10, 20):
+                    k = 0 if ms == 10 else 1
+                    config = int(rng.choice([0 + k, 4 + k, 8 + k, 12 + k, 14 + k, 18 + k, 22 + k, 26 + k, 30 + k]))
+                elif ms in (2.5, 5):
+                    config = int(rng.choice([16, 20, 24, 28])) + (0 if ms == 2.5 else 1)
+                else:
+                    config = int(rng.choice([0, 4, 8])) + (2 if ms == 40 else 3)
+                parts.append(random_packet(rng, config, int(rng.integers(0, 2)), code))
+            lost = rng.integers(0, 25) == 0
+            pkt = b"" if lost else b"".join(self_delimit(p) for p in parts[:-1]) + parts[-1]
+            what = f"seed {seed} decoder ({ns} streams, {nc} coupled, mapping {mapping}) packet {i}"
+            try:
+                d.send_packet(pkt)
+            except OpusError:
+                with pytest.raises(ValueError):         # (a hybrid frame refused midway: tests/test_gpu_opus.py::fuzz_one_stream)
+                    for s in range(ns):
+                        refs[s].decode(parts[s])
+                break                                   # a fresh decoder set
+            out = d.receive_frame()
+            w = [refs[s].decode(b"" if lost else parts[s]) for s in range(ns)]
+            assert len({len(x) for x in w}) == 1, what
+            dec = np.concatenate(w, axis=1)
+            want = np.stack([dec[:, m] if m != 255 else np.zeros(len(dec), np.float32) for m in mapping], axis=1)
+            assert out.shape == want.shape, what
+            check_pcm(want, out, what, recent.value())
+            recent.push(dec)
+            done += 1
+        d.close()
+
+
+@pytest.mark.gpu
+def test_multistream_random_decoders_and_packets():
+    fuzz_multistream(5, 400)
