@@ -236,6 +236,7 @@ OG_DEV OgXfAddr og_xf_addr(const OgTask tk, int first, int STEP)
             if (k * STEP < nmax) {                                                                                  \
                 OG_WAVE_XCH(ex, rv, .v[k], 1 << (B))                                                                \
                 OG_WAVE_REGS_BEGIN(lane)                                                                            \
+                (void)lane;                                                                                         \
                 OG_WV(rv).v[k] = fmaf(OG_WV(rv).v[k], OG_WV(ca), OG_WV(cb) * OG_WV(ex));                            \
                 OG_WAVE_REGS_END                                                                                    \
             }                                                                                                       \
