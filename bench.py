@@ -49,6 +49,8 @@ def parse_args():
     ap.add_argument("--split", type=int, default=1,
                     help="issue each step as this many independent sub-batches of streams, each on a HIP stream of its own "
                          "(the sub-batches share nothing: their kernels may run side by side)")
+    ap.add_argument("--cu-mask", default="", help="experiment: the pipelined leg's second stream (K1 + plan of the next step) on the first N compute units "
+                                                  "('N'), the first stream on the others ('N:rest')")
     ap.add_argument("--workload", choices=["c2", "c3", "c4", "c5"], default="c2",
                     help="c2 (default, the headline): BASELINE configs[1], synthetic CELT FB stereo 20 ms, 4096 streams per GPU; "
                          "c3: BASELINE configs[2], SILK WB mono 20 ms, 16384 streams per GPU (SURVEY.md 8d); "
@@ -569,6 +571,20 @@ def main_c4(a, rank, local_rank, world):
         dist.destroy_process_group()
 
 
+def cu_masked_stream(dev, cus):
+    """a HIP stream whose kernels run on the compute units `cus` only (hipExtStreamCreateWithCUMask), as a torch stream"""
+    import torch
+    hip = C.CDLL("libamdhip64.so")
+    words = [0] * 8
+    for c in cus:
+        words[c >> 5] |= 1 << (c & 31)
+    h = C.c_void_p()
+    rc = hip.hipExtStreamCreateWithCUMask(C.byref(h), C.c_uint32(len(words)), (C.c_uint32 * len(words))(*words))
+    if rc:
+        raise RuntimeError(f"hipExtStreamCreateWithCUMask -> {rc}")
+    return torch.cuda.ExternalStream(h.value, device=dev)
+
+
 def pmc_info(workload, step_s=None):
     """profiles/pmc_traffic.json (tools/gpu_measure.sh + tools/pmc_traffic.py: rocprofv3 --pmc passes over this bench at its default
     sizes) for one workload -> (HBM bytes per step or None, the `pmc` object of the bench line or None).  Per kernel: HBM bytes,
@@ -795,7 +811,12 @@ def main():
         pt = parts[0]
         works = [pt["work"], torch.zeros_like(pt["work"])]
         sA, sB = pt["stream"], torch.cuda.Stream(dev)
-        pA, pB = pt["ps"], C.c_void_p(sB.cuda_stream)
+        if a.cu_mask:                                   # experiment: the two streams on disjoint sets of CUs
+            nb = int(a.cu_mask.split(":")[0])           # "NB" : K1 + plan on NB CUs, the rest unmasked; "NB:rest": the others on the remaining CUs
+            sB = cu_masked_stream(dev, range(nb))
+            if a.cu_mask.endswith(":rest"):
+                sA = cu_masked_stream(dev, range(nb, 256))
+        pA, pB = C.c_void_p(sA.cuda_stream), C.c_void_p(sB.cuda_stream)
         state2 = torch.zeros_like(state)
         ev_plan = [torch.cuda.Event() for _ in range(nsteps)]
         ev_tail = [torch.cuda.Event() for _ in range(nsteps)]
@@ -839,6 +860,7 @@ def main():
             worstp = oracle_check_last_step({s: rows[i] for i, s in enumerate(sample)}, packets, sample, nframes, T, "bench last step (pipelined)")
             okp = float(f"{worstp:.3e}")
         pl = {"value": round(S * K * T * FRAME_S / ep, 1), "unit": "audio-s/s", "steps": K, "warmup": W, "ms_per_step": round(ep / K * 1e3, 4),
+              "cu_mask": a.cu_mask or None,
               "verified_max_scaled_err": okp,
               "note": "same workload, consecutive steps pipelined over two HIP streams: K1 + plan of step n + 1 beside the tail kernel of "
                       "step n (two scratch blocks); every kernel of the timed steps inside the timed region.  Worth 3-6 %: every kernel "
