@@ -275,8 +275,11 @@ OG_DEV void og_plan_chain(const OgHdrHead &h, const OgCeltBand *bands, const OgC
                 int m = r.raw[slot];                    // PVQ leaves: expanded (and masks collected) by K1
                 int live = 0;
                 const int first_op = nops;
+                OgCeltLeaf nx = {};                         // (the next leaf is on its way while this one is worked on)
+                if (nfill > 0) nx = lv[g0];
                 for (int l = 0; l < nfill; l++) {
-                    const OgCeltLeaf lf = lv[g0 + l];
+                    const OgCeltLeaf lf = nx;
+                    if (l + 1 < nfill) nx = lv[g0 + l + 1];
                     const int Bl = 1 << (lf.meta & OG_L_LOGB_MASK), sh = lf.cmshift;
                     // the leaf's share of the fill: the recursion only shifts it (side halves) or clears it (theta)
                     const int fl = (lf.meta & OG_L_FILL_DEAD) ? 0 : (fill >> sh) & ((1 << Bl) - 1);
