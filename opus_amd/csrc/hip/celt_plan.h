@@ -33,6 +33,12 @@ struct OgFillOp {                     // one live fill leaf (celt/decoder.rs:163
     uint8_t level, task, pad_[2];     // level and id of the quant_band call it belongs to
 };
 enum { OG_OP_FOLD = 1 };
+struct OgLeafWords { uint32_t w[4]; };                  // an OgCeltLeaf: index | gain | off, n << 8, k << 16, meta << 24 | cmshift, band << 8, pos << 16
+static_assert(sizeof(OgCeltLeaf) == 16 && offsetof(OgCeltLeaf, gain) == 4 && offsetof(OgCeltLeaf, off) == 8 && offsetof(OgCeltLeaf, n) == 9 &&
+              offsetof(OgCeltLeaf, meta) == 11 && offsetof(OgCeltLeaf, cmshift) == 12, "OgCeltLeaf as four words");
+struct OgFillOpWords { uint32_t w[4]; };                // seed | gain | pos, n << 16, flags << 24 | level, task << 8
+static_assert(sizeof(OgFillOp) == 16 && offsetof(OgFillOp, pos) == 8 && offsetof(OgFillOp, n) == 10 && offsetof(OgFillOp, flags) == 11 &&
+              offsetof(OgFillOp, level) == 12 && offsetof(OgFillOp, task) == 13, "OgFillOp as four words");
 
 #define OG_MAXLEVEL 23                // 21 bands + the intensity switch, and level 0
 struct alignas(16) OgBandPlan {
@@ -275,11 +281,16 @@ OG_DEV void og_plan_chain(const OgHdrHead &h, const OgCeltBand *bands, const OgC
                 int m = r.raw[slot];                    // PVQ leaves: expanded (and masks collected) by K1
                 int live = 0;
                 const int first_op = nops;
-                OgCeltLeaf nx = {};                         // (the next leaf is on its way while this one is worked on)
-                if (nfill > 0) nx = lv[g0];
+                // (the next leaf is on its way while this one is worked on; a record is fetched as its four words in one piece --
+                // field by field it took a load per field -- and the fields read here are cut out of the words)
+                OgLeafWords nx = {{0, 0, 0, 0}};
+                if (nfill > 0) nx = *(const OgLeafWords *)&lv[g0];
                 for (int l = 0; l < nfill; l++) {
-                    const OgCeltLeaf lf = nx;
-                    if (l + 1 < nfill) nx = lv[g0 + l + 1];
+                    const OgLeafWords lw = nx;
+                    if (l + 1 < nfill) nx = *(const OgLeafWords *)&lv[g0 + l + 1];
+                    struct { float gain; int off, n, meta, cmshift; } lf;
+                    memcpy(&lf.gain, &lw.w[1], 4);
+                    lf.off = (int)(lw.w[2] & 255u); lf.n = (int)((lw.w[2] >> 8) & 255u); lf.meta = (int)(lw.w[2] >> 24); lf.cmshift = (int)(lw.w[3] & 255u);
                     const int Bl = 1 << (lf.meta & OG_L_LOGB_MASK), sh = lf.cmshift;
                     // the leaf's share of the fill: the recursion only shifts it (side halves) or clears it (theta)
                     const int fl = (lf.meta & OG_L_FILL_DEAD) ? 0 : (fill >> sh) & ((1 << Bl) - 1);
@@ -287,12 +298,14 @@ OG_DEV void og_plan_chain(const OgHdrHead &h, const OgCeltBand *bands, const OgC
                     const bool fold = (lf.meta & OG_L_HAS_LOWBAND) != 0;
                     const int nn = lf.n < 184 ? lf.n : 183;
                     if (nops < OG_MAXLEAF) {
-                        OgFillOp op;
-                        op.seed = seed; op.gain = lf.gain;
-                        op.pos = (uint16_t)(slot * 960 + boff + lf.off);
-                        op.n = (uint8_t)nn; op.flags = fold ? OG_OP_FOLD : 0;
-                        op.level = (uint8_t)lvl; op.task = (uint8_t)(2 * i + slot); op.pad_[0] = op.pad_[1] = 0;
-                        P->op[nops++] = op;
+                        // the record as its four words, one store (field by field it went out in four pieces)
+                        OgFillOpWords ow;
+                        float g = lf.gain;
+                        ow.w[0] = seed;
+                        memcpy(&ow.w[1], &g, 4);
+                        ow.w[2] = (uint32_t)((slot * 960 + boff + lf.off) & 0xFFFF) | (uint32_t)nn << 16 | (fold ? (uint32_t)OG_OP_FOLD << 24 : 0u);
+                        ow.w[3] = (uint32_t)lvl | (uint32_t)(2 * i + slot) << 8;
+                        *(OgFillOpWords *)&P->op[nops++] = ow;
                         live++;
                     }
                     m |= (fold ? fl : (1 << Bl) - 1) << sh;
