@@ -439,10 +439,7 @@ def main_c4(a, rank, local_rank, world):
     cstate = torch.zeros(S * SS, dtype=torch.uint8, device=dev)
     work = torch.zeros(lib.opusgpu_celt_work_bytes(max_celt), dtype=torch.uint8, device=dev)
     pcm = torch.zeros(S * stride, dtype=torch.float32, device=dev)
-    # The main stream (the SILK launches by depth, then the tail: the step's critical path) at high priority, as in the engine: the
-    # stateless CELT kernels on the side stream fill the chip, and whenever they got ahead of the SILK chain they slowed it down
-    # (a faster plan kernel made the step *longer*: 0.403 -> 0.43 ms; with the priority 0.41).  OPUSGPU_BENCH_PRIO=off: both normal.
-    strm = torch.cuda.Stream(dev) if os.environ.get("OPUSGPU_BENCH_PRIO", "") == "off" else torch.cuda.Stream(dev, priority=-1)
+    strm = torch.cuda.Stream(dev)
     ps = C.c_void_p(strm.cuda_stream)
 
     def check(rc):

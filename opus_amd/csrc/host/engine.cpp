@@ -366,12 +366,7 @@ int opusgpu_batch_create(opusgpu_batch **out, uint32_t nstreams, int channels, i
     b->nsamples.assign(nstreams, 0);
     b->seen.assign(nstreams, 0);
     b->pcm_stride = size_t(OPUSGPU_MAX_FRAME) * channels;
-    // The main stream carries a step's critical path (the SILK launches by depth, then the tail kernel); the stateless CELT kernels
-    // run beside it on the side stream and fill the chip, so the main stream gets the higher dispatch priority (measured at the C4
-    // shape: 0.43 -> 0.41 ms per step; without it a faster plan kernel made the step longer).
-    int prio_lo = 0, prio_hi = 0;
-    hipError_t e = hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-    if (e == hipSuccess) e = hipStreamCreateWithPriority(&b->stream, hipStreamNonBlocking, prio_hi);
+    hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&b->h2d_done, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&b->fork, hipEventDisableTiming);

@@ -39,7 +39,9 @@ static std::vector<uint8_t> random_packet(int config, int stereo, int code)
     return p;
 }
 
-#define CHECK(call) { const int rc_ = (call); if (rc_ != 0) { std::printf("%s -> %d (%s)\n", #call, rc_, opusgpu_last_error()); return 1; } }
+static bool g_trace = false;
+#define MARK(what) { if (g_trace) { std::printf("  . %s\n", what); std::fflush(stdout); } }
+#define CHECK(call) { MARK(#call) const int rc_ = (call); if (rc_ != 0) { std::printf("%s -> %d (%s)\n", #call, rc_, opusgpu_last_error()); return 1; } }
 
 int main(int argc, char **argv)
 {
@@ -52,6 +54,8 @@ int main(int argc, char **argv)
     double last = 0;
     while (elapsed() < budget) {
         rounds++;
+        g_trace = getenv("ENGINE_FUZZ_TRACE_AFTER") && elapsed() > atof(getenv("ENGINE_FUZZ_TRACE_AFTER"));
+        MARK("round")
         // ---- a batch of streams of random size
         const uint32_t ns = 1 + below(160);
         opusgpu_batch *b = nullptr;
@@ -95,7 +99,9 @@ int main(int argc, char **argv)
             if (below(4) == 0) { OgBatchPlan pl; CHECK(opusgpu_batch_plan(b, &pl)); }
         }
         CHECK(opusgpu_batch_sync(b));
+        MARK("batch_destroy")
         opusgpu_batch_destroy(b);
+        MARK("batch destroyed")
         // ---- the one-stream decoder: plain, or multistream with a random (valid) mapping
         opusgpu_decoder *d = nullptr;
         CHECK(opusgpu_decoder_create(&d, 0));
@@ -128,15 +134,20 @@ int main(int argc, char **argv)
                 size_t n = 0;
                 int ch = 0;
                 if (below(15) == 0) (void)opusgpu_decoder_receive_frame(d, out.data(), out.size(), &n, &ch);
+                MARK("decoder_send_packet")
                 if (opusgpu_decoder_send_packet(d, pkt.empty() ? nullptr : pkt.data(), pkt.size()) != 0) { refused++; continue; }
+                MARK("decoder_receive_frame")
                 packets++;
                 (void)opusgpu_decoder_receive_frame(d, out.data(), below(10) == 0 ? 100 : out.size(), &n, &ch);
                 if (below(30) == 0) (void)opusgpu_decoder_flush(d);
             }
         }
+        MARK("decoder_destroy")
         opusgpu_decoder_destroy(d);
+        MARK("decoder destroyed")
         if (elapsed() - last > 30) { last = elapsed(); std::printf("%.0f s: %ld rounds, %ld sends, %ld packets, %ld refused\n", last, rounds, sends, packets, refused); fflush(stdout); }
     }
     std::printf("engine_fuzz_asan: %ld rounds, %ld batch sends, %ld packets, %ld refused, no sanitizer report\n", rounds, sends, packets, refused);
-    return 0;
+    std::fflush(stdout);
+    std::_Exit(0);                                      // (not through the HIP runtime's exit-time teardown: the sanitizer's allocator checks the order it unloads in)
 }
